@@ -1,0 +1,364 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own classes on CPU.
+
+Runs only in the build container (needs /root/reference).  The reference never
+travels: this script records inputs-by-seed and the reference's OUTPUTS as small
+fixtures, and cross-checks the oracle restatement (oracle/ref_torch.py) against the
+reference on full tensors, writing the max deviations to tests/golden/PIN_REPORT.json.
+
+Import recipe: SURVEY.md Appendix B (inert stubs for torchvision / ipywidgets /
+utils.cfg_utils; notebook definitions extracted one at a time with ``ast`` so that no
+notebook top-level code runs).
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+"""
+import ast
+import importlib.machinery as mach
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+from oracle import ref_torch as O  # noqa: E402
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+REPORT = {}
+
+
+def _stub(name):
+    m = types.ModuleType(name)
+    m.__spec__ = mach.ModuleSpec(name, None)
+    return m
+
+
+def import_reference():
+    import transformers  # noqa: F401  (real package; must precede the torchvision stub)
+    tv, tvm = _stub("torchvision"), _stub("torchvision.models")
+    tv.__path__ = []
+    tvm.vit_b_16 = None
+    tv.models = tvm
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "ipywidgets": _stub("ipywidgets")})
+    u, c = _stub("utils"), _stub("utils.cfg_utils")
+    u.__path__ = []
+
+    class CFG:
+        N_CLASSES = 6
+    c.CFG, c._Logger, c._seed_everything = CFG, object, (lambda s: None)
+    u.cfg_utils = c
+    sys.modules.update({"utils": u, "utils.cfg_utils": c})
+    sys.path.insert(0, os.path.join(REF, "root", "src"))
+    import models.models as M
+    return M
+
+
+def extract(path, name, ns):
+    """exec exactly one top-level def/class of a reference file into ``ns``."""
+    tree = ast.parse(open(path).read())
+    node = next(n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name == name)
+    exec(compile(ast.Module([node], []), os.path.basename(path), "exec"), ns)
+    return ns[name]
+
+
+def maxdiff(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def note(key, a, b):
+    REPORT[key] = max(REPORT.get(key, 0.0), maxdiff(a, b))
+
+
+BIG = 20000
+
+
+def save(name, **arrays):
+    """Arrays above BIG elements are stored as '<key>#sum' (O.summarize) + '<key>#head'
+    (first 512 values, flattened); tests/golden_util.py applies the same rule when checking."""
+    out = {}
+    for k, v in arrays.items():
+        t = torch.as_tensor(v)
+        if t.numel() > BIG:
+            out[k + "#sum"] = O.summarize(t)
+            out[k + "#head"] = t.detach().flatten()[:512].numpy()
+        else:
+            out[k] = t.detach().cpu().numpy()
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  {name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def grads_digest(model):
+    d = {}
+    for n, p in model.named_parameters():
+        d["gsum." + n] = O.summarize(p.grad)
+        d["ghead." + n] = p.grad.detach().flatten()[:32].clone()
+    return d
+
+
+def state_digest(model):
+    d = {}
+    for n, t in model.state_dict().items():
+        d["ssum." + n] = O.summarize(t.float())
+        d["shead." + n] = t.detach().float().flatten()[:32].clone()
+    return d
+
+
+# ---------------------------------------------------------------------------------------
+def gen_blocks(M):
+    cases = {"b4_16_max": (4, 16, 32, 64, "max"), "b16_32_avg": (16, 32, 16, 32, "avg"),
+             "b3_16_max_odd": (3, 16, 50, 37, "max"), "b64_128_avg_odd": (64, 128, 25, 18, "avg")}
+    for tag, (cin, c, h, w, kind) in cases.items():
+        ref = O.fill_params(M.Block(cin, c, kind, (2, 2), dropout_p=0.0), seed=7)
+        mine = O.fill_params(O.Block(cin, c, kind, (2, 2), dropout_p=0.0), seed=7)
+        x = O.seeded((2, cin, h, w), 11, "randn")
+        r = O.seeded((2, c, h // 2, w // 2), 12, "randn")
+        rec = {"x": x, "r": r}
+        for mode in ("eval", "train"):
+            outs = []
+            for net in (ref, mine):
+                net.train(mode == "train")
+                net.zero_grad()
+                xi = x.clone().requires_grad_(True)
+                y = net(xi)
+                (y * r).sum().backward()
+                outs.append((y.detach(), xi.grad.detach(), net))
+            (y, dx, _), (y2, dx2, _) = outs
+            note(f"block.{mode}.out", y2, y); note(f"block.{mode}.dx", dx2, dx)
+            for (n, p), (_, q) in zip(ref.named_parameters(), mine.named_parameters()):
+                note(f"block.{mode}.dparam", q.grad, p.grad)
+            rec[f"{mode}.out"], rec[f"{mode}.dx"] = y, dx
+            for n, p in ref.named_parameters():
+                rec[f"{mode}.grad.{n}"] = p.grad.detach().clone()
+        rec["after.running_mean"] = ref.bn.running_mean.clone()
+        rec["after.running_var"] = ref.bn.running_var.clone()
+        note("block.running_var", mine.bn.running_var, ref.bn.running_var)
+        save("block_" + tag, **rec)
+    return cases
+
+
+def make_ref_spec(M, in_channels):
+    m = M.Spectrogram_Model(6)
+    if in_channels != 3:
+        m.block1 = M.Block(in_channels, 16, "max", (2, 2))
+    return m
+
+
+def make_ref_multimodal(M, MM, chans, samples, in_channels, p=0.0):
+    mm = MM(M.EEGNet(6, Chans=chans, Samples=samples), make_ref_spec(M, in_channels))
+    O.set_dropout(mm, p)
+    return mm
+
+
+def gen_spec_models(M):
+    for tag, (cin, h, w) in {"spec3_64x96": (3, 64, 96), "spec4_32x64": (4, 32, 64),
+                             "spec3_100x75": (3, 100, 75)}.items():
+        ref = O.fill_params(make_ref_spec(M, cin), seed=21).eval()
+        mine = O.fill_params(O.Spectrogram_Model(6, in_channels=cin), seed=21).eval()
+        x = O.seeded((2, cin, h, w), 22, "rand")
+        feats = {}
+        hk = ref.block5.register_forward_hook(lambda m, i, o: feats.__setitem__("b5", o.detach().clone()))
+        y = ref(x).detach()
+        hk.remove()
+        note("spec.eval.logits", mine(x), y)
+        note("spec.eval.block5", mine.features(x), feats["b5"])
+        rec = {"x": x, "eval.logits": y, "eval.block5": feats["b5"]}
+        O.set_dropout(ref, 0.0); O.set_dropout(mine, 0.0)
+        ref.train(); mine.train()
+        yt = ref(x).detach()
+        note("spec.train.logits", mine(x), yt)
+        rec["train.logits"] = yt
+        save(tag, **rec)
+
+
+def gen_eegnet(M):
+    for tag, (chans, samples) in {"eeg19x2000": (19, 2000), "eeg37x3000": (37, 3000)}.items():
+        ref = O.fill_params(M.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0), seed=31)
+        mine = O.fill_params(O.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0), seed=31)
+        x = O.seeded((2, 1, chans, samples), 32, "randn")
+        r = O.seeded((2, 6), 33, "randn")
+        rec = {"r": r}
+        for mode in ("eval", "train"):
+            ref.train(mode == "train"); mine.train(mode == "train")
+            grabbed = {}
+            hooks = [getattr(ref, n).register_forward_hook(
+                lambda m, i, o, n=n: grabbed.__setitem__(n, o.detach().clone()))
+                for n in ("conv1", "batchnorm1", "depthwiseConv", "batchnorm2", "separableConv", "batchnorm3")]
+            ref.zero_grad(); mine.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            y = ref(xi); (y * r).sum().backward()
+            for h in hooks:
+                h.remove()
+            xj = x.clone().requires_grad_(True)
+            st = mine.stages(xj); (st["out"] * r).sum().backward()
+            note(f"eeg.{mode}.out", st["out"], y); note(f"eeg.{mode}.dx", xj.grad, xi.grad)
+            for a, b in (("conv1", "conv1"), ("bn1", "batchnorm1"), ("dw", "depthwiseConv"),
+                         ("bn2", "batchnorm2"), ("sep", "separableConv"), ("bn3", "batchnorm3")):
+                note(f"eeg.{mode}.{a}", st[a], grabbed[b])
+            for (n, p), (_, q) in zip(ref.named_parameters(), mine.named_parameters()):
+                note(f"eeg.{mode}.dparam", q.grad, p.grad)
+                rec[f"{mode}.grad.{n}"] = p.grad.detach().clone()
+            rec[f"{mode}.out"] = y.detach()
+            rec[f"{mode}.dx.head"] = xi.grad.detach()[..., :96].clone()
+            rec[f"{mode}.dx.tail"] = xi.grad.detach()[..., -96:].clone()
+            rec[f"{mode}.dx.sum"] = O.summarize(xi.grad)
+            c1 = grabbed["conv1"]
+            rec[f"{mode}.conv1.head"] = c1[..., :80].clone()      # left pad 31
+            rec[f"{mode}.conv1.tail"] = c1[..., -80:].clone()     # right pad 32
+            rec[f"{mode}.conv1.sum"] = O.summarize(c1)
+            rec[f"{mode}.dw"] = grabbed["depthwiseConv"]
+            rec[f"{mode}.bn2"] = grabbed["batchnorm2"]
+            rec[f"{mode}.sep"] = grabbed["separableConv"]         # pad L7 / R8
+            rec[f"{mode}.bn3"] = grabbed["batchnorm3"]
+        for k in ("batchnorm1", "batchnorm2", "batchnorm3"):
+            rec[f"after.{k}.running_mean"] = getattr(ref, k).running_mean.clone()
+            rec[f"after.{k}.running_var"] = getattr(ref, k).running_var.clone()
+            note("eeg.running_var", getattr(mine, k).running_var, getattr(ref, k).running_var)
+        save(tag, **rec)
+
+
+def gen_multimodal(M, MM):
+    """Logits, both KLDiv reductions, gradient digests, state after 3 AdamW steps (dropout 0)."""
+    for tag, (chans, samples, cin, h, w, b) in {"mm_bench_small": (19, 2000, 4, 32, 64, 4),
+                                                  "mm_native_small": (37, 3000, 3, 50, 37, 2)}.items():
+        ref = O.fill_params(make_ref_multimodal(M, MM, chans, samples, cin), seed=41)
+        mine = O.fill_params(O.build_multimodal(chans, samples, cin, dropout=0.0), seed=41)
+        eeg = O.seeded((b, 1, chans, samples), 42, "randn")
+        spec = O.seeded((b, cin, h, w), 43, "rand")
+        labels = torch.softmax(O.seeded((b, 6), 44, "randn"), 1)
+        rec = {"labels": labels}
+        ref.eval(); mine.eval()
+        y = ref(eeg, spec).detach()
+        note("mm.eval.logits", mine(eeg, spec), y)
+        rec["eval.logits"] = y
+        rec["eval.loss_mean"] = nn.KLDivLoss()(y, labels)
+        rec["eval.loss_batchmean"] = nn.KLDivLoss(reduction="batchmean")(y, labels)
+        note("mm.kldiv.mean", O.kl_div(y, labels, "mean"), rec["eval.loss_mean"])
+        note("mm.kldiv.batchmean", O.kl_div(y, labels, "batchmean"), rec["eval.loss_batchmean"])
+        onehot = F.one_hot(labels.argmax(1), 6).float()
+        rec["eval.loss_onehot"] = nn.KLDivLoss()(y, onehot)
+        note("mm.kldiv.onehot", O.kl_div(y, onehot, "mean"), rec["eval.loss_onehot"])
+        ref.train(); mine.train()
+        opt_r = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+        opt_m = torch.optim.AdamW(mine.parameters(), lr=1e-3)
+        losses = []
+        for step in range(3):
+            lr_, _ = O.train_step(ref, opt_r, eeg, spec, labels)
+            lm_, _ = O.train_step(mine, opt_m, eeg, spec, labels)
+            losses.append(lr_)
+            note("mm.train.loss", lm_, lr_)
+            if step == 0:
+                rec.update({"step0." + k: v for k, v in grads_digest(ref).items()})
+                for (n, p), (_, q) in zip(ref.named_parameters(), mine.named_parameters()):
+                    note("mm.train.grad", q.grad, p.grad)
+        rec["train.losses"] = np.array(losses)
+        rec.update({"after3." + k: v for k, v in state_digest(ref).items()})
+        for (n, t), (_, t2) in zip(ref.state_dict().items(), mine.state_dict().items()):
+            note("mm.train.state_after3", t2.float(), t.float())
+        save(tag, **rec)
+
+
+def gen_attribution(M, MM, NB):
+    chans, samples, cin, h, w = 19, 2000, 4, 64, 128
+    ref = O.fill_params(make_ref_multimodal(M, MM, chans, samples, cin), seed=51).eval()
+    mine = O.fill_params(O.build_multimodal(chans, samples, cin, dropout=0.0), seed=51).eval()
+    eeg = O.seeded((2, 1, chans, samples), 52, "randn")
+    spec = O.seeded((2, cin, h, w), 53, "rand")
+    rec = {}
+    # Grad-CAM: canonical definition applied to the REFERENCE classes (reference has none).
+    for layer in ("spectrogram_model.block5", "spectrogram_model.block5.conv3", "spectrogram_model.block3"):
+        cam, raw, wts, A, out = O.grad_cam(ref, eeg, spec, layer, "all", upsample=False, return_parts=True)
+        cam2, raw2, wts2, A2, out2 = O.grad_cam(mine, eeg, spec, layer, "all", upsample=False, return_parts=True)
+        note("gradcam.raw", raw2, raw); note("gradcam.weights", wts2, wts)
+        key = layer.replace("spectrogram_model.", "")
+        rec[f"{key}.raw"], rec[f"{key}.cam"], rec[f"{key}.w"] = raw, cam, wts
+    rec["up.block5"] = O.grad_cam(ref, eeg, spec, "spectrogram_model.block5", "all", upsample=True)
+    rec["argmax.block5"] = O.grad_cam(ref, eeg, spec, "spectrogram_model.block5", None, upsample=True)
+    rec["logits"] = out
+    save("gradcam_4x64x128", **rec)
+
+    # Saliency: the reference's own function (NB:3101-3133), plotting replaced by capture.
+    captured = {}
+    class _CFG:
+        device = "cpu"; SPECTR_COLUMNS = None
+    ns = {"torch": torch, "CFG": _CFG,
+          "plot_eeg_saliency": lambda s, cfg: captured.__setitem__("eeg", np.array(s)),
+          "plot_spectrogram_saliency": lambda s, cols: captured.__setitem__("spec", np.array(s))}
+    ref_sal = extract(NB, "generate_saliency_maps", ns)
+    e1 = eeg[:1].clone().requires_grad_(True)
+    s1 = spec[:1].clone().requires_grad_(True)
+    ref_sal(ref, [((e1, s1), torch.zeros(1, 6))])
+    se, ss = O.saliency(mine, eeg[:1], spec[:1], reference_quirk=True)
+    note("saliency.eeg", se[0], captured["eeg"]); note("saliency.spec_x2", ss[0], captured["spec"])
+    te, ts = O.saliency(mine, eeg[:1], spec[:1], reference_quirk=False)
+    save("saliency_4x64x128", eeg_ref=captured["eeg"], spec_ref_x2=captured["spec"], eeg_true=te[0], spec_true=ts[0])
+
+    # Integrated gradients (Captum defaults; canonical, run on the reference classes).
+    small = spec[:1, :, :32, :64].contiguous()
+    ie, is_ = O.integrated_gradients(ref, (eeg[:1], small), n_steps=50)
+    ie2, is2 = O.integrated_gradients(mine, (eeg[:1], small), n_steps=50)
+    note("ig.eeg", ie2, ie); note("ig.spec", is2, is_)
+    save("ig_4x32x64", eeg_attr=ie, spec_attr=is_)
+
+
+def gen_stacker():
+    ns = {"np": np, "Optional": __import__("typing").Optional}
+    from scipy.signal import butter, lfilter
+    ns.update(butter=butter, lfilter=lfilter)
+
+    class CFG:
+        EEG_PTS = 10000
+        feats = ["Fp1", "T3", "C3", "O1", "Fp2", "C4", "T4", "O2"]
+        channel_feats = ["Fp1", "F3", "C3", "P3", "F7", "T3", "T5", "O1", "Fz", "Cz", "Pz",
+                         "Fp2", "F4", "C4", "P4", "F8", "T4", "T6", "O2"]
+    ns["CFG"] = CFG
+    T = extract(os.path.join(REF, "root/src/data/dataset.py"), "_EEGTransformer", ns)
+    trafo = T(n_feats=19, apply_chris_magic_ch8=False, normalize=True, apply_butter_lowpass_filter=True,
+              apply_mu_law_encoding=False, downsample=5)
+    raw = O.synthetic_batch(batch=2, seed=61, stacked=False)["raw_eeg"].numpy()
+    outs = np.stack([trafo.transform(r).astype(np.float32) for r in raw])     # [2, 2000, 19]
+    mine = np.stack([O.eeg_transform(r) for r in raw])
+    note("stacker", mine, outs)
+    b, a = O.butter_lowpass_coeffs()
+    save("stacker_2x10000x19", out=outs, b=b, a=a)
+
+
+def gen_manifest(M, MM):
+    man = {}
+    for name, net in {"Block(4,16)": M.Block(4, 16), "Spectrogram_Model": M.Spectrogram_Model(6),
+                      "EEGNet(6,19,2000)": M.EEGNet(6, Chans=19, Samples=2000),
+                      "EEGNet(6,37,3000)": M.EEGNet(6),
+                      "MultimodalModel(bench)": make_ref_multimodal(M, MM, 19, 2000, 4),
+                      "MultimodalModel(native)": make_ref_multimodal(M, MM, 37, 3000, 3)}.items():
+        man[name] = {k: list(v.shape) for k, v in net.state_dict().items()}
+        man[name + "#params"] = sum(p.numel() for p in net.parameters())
+    json.dump(man, open(os.path.join(OUT, "state_dict_manifest.json"), "w"), indent=0)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    NB = os.path.join(REF, "root/jupyter_notebooks/XAI_Multimodality.py")
+    M = import_reference()
+    MM = extract(NB, "MultimodalModel", {"nn": nn, "torch": torch, "F": F})
+    print("blocks"); gen_blocks(M)
+    print("spectrogram models"); gen_spec_models(M)
+    print("eegnet"); gen_eegnet(M)
+    print("multimodal"); gen_multimodal(M, MM)
+    print("attribution"); gen_attribution(M, MM, NB)
+    print("stacker"); gen_stacker()
+    gen_manifest(M, MM)
+    REPORT["_meta"] = {"torch": torch.__version__, "note": "max |oracle - reference| / max|reference| on full tensors"}
+    json.dump(REPORT, open(os.path.join(OUT, "PIN_REPORT.json"), "w"), indent=1, sort_keys=True)
+    worst = max(v for k, v in REPORT.items() if k != "_meta")
+    print(json.dumps(REPORT, indent=1, sort_keys=True))
+    print("worst relative deviation oracle vs reference:", worst)
+    assert worst < 2e-5, "oracle restatement deviates from the reference"

@@ -1,0 +1,424 @@
+"""CPU oracle for the multimodal brain-pattern hot path (TEST INFRASTRUCTURE ONLY).
+
+This file is a plain CPU / fp32 PyTorch + numpy restatement of the reference's
+algorithm for the path named in BASELINE.json.  It is the *checker*: only
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import it.  Nothing in the product package imports it and the
+product never falls back to it.
+
+Pinned by: ``tests/golden/*.npz`` produced by ``oracle/make_golden.py`` which
+imports the reference's own classes in the build container
+(/root/reference/root/src/models/models.py, XAI_Multimodality.py) and records
+their outputs on seeded inputs; ``tests/test_oracle_golden.py`` replays those
+fixtures through this file.
+
+Parity status per piece
+  * Block / Spectrogram_Model / EEGNet / MultimodalModel / KLDiv / AdamW step /
+    saliency / EEG stacker: pinned by reference outputs (fixtures).
+  * Grad-CAM, Integrated Gradients: the reference ships NO implementation
+     -> "parity unpinned" by the reference; pinned here by the
+    canonical definitions applied to the *reference's* model classes when the
+    fixtures were generated.
+
+Reference anchors (paths relative to /root/reference):
+  M  = root/src/models/models.py
+  NB = root/jupyter_notebooks/XAI_Multimodality.py
+"""
+from __future__ import annotations
+
+import math
+from typing import Iterable, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+N_CLASSES = 6
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+# Pool schedule of the five residual stages (M:86-90).
+_STAGES = ((16, "max"), (32, "avg"), (64, "max"), (128, "avg"), (256, "max"))
+
+
+# --------------------------------------------------------------------------------------
+# Row A -- residual stage of the spectrogram CNN (M:42-77)
+# --------------------------------------------------------------------------------------
+class Block(nn.Module):
+    """relu(conv3x3) x3 -> 2x2 pool -> BatchNorm -> dropout -> + conv1x1(bilinear(x)).
+
+    Follows M:47-60 (parameters) and M:62-77 (op order: pool BEFORE bn, dropout after
+    bn, skip added last).  Parameter names equal the reference's so state_dicts swap.
+    """
+
+    def __init__(self, in_channels, out_channels, pool_type="max", pool_size=(2, 2), dropout_p=0.5):
+        super().__init__()
+        chans = (in_channels, out_channels, out_channels, out_channels)
+        for i in range(3):
+            setattr(self, f"conv{i + 1}", nn.Conv2d(chans[i], chans[i + 1], 3, 1, 1))
+        if pool_type not in ("max", "avg"):
+            raise ValueError(f"pool_type must be 'max' or 'avg', got {pool_type!r}")
+        self.pool = (nn.MaxPool2d if pool_type == "max" else nn.AvgPool2d)(kernel_size=pool_size)
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.dropout = nn.Dropout(p=dropout_p)
+        self.conv1x1 = nn.Conv2d(in_channels, out_channels, 1)
+
+    def forward(self, x):
+        y = x
+        for conv in (self.conv1, self.conv2, self.conv3):
+            y = F.relu(conv(y))
+        y = self.dropout(self.bn(self.pool(y)))
+        # The reference only resamples when shapes differ (M:72) -- they always do,
+        # because the channel count changes in every stage.
+        skip = F.interpolate(x, size=y.shape[-2:], mode="bilinear", align_corners=False)
+        return y + self.conv1x1(skip)
+
+
+# --------------------------------------------------------------------------------------
+# Row B -- spectrogram CNN (M:79-107)
+# --------------------------------------------------------------------------------------
+class Spectrogram_Model(nn.Module):
+    """Five stages -> global average pool -> Linear(256, classes) -> LogSoftmax.
+
+    ``in_channels`` is the build's extension (reference hard-codes 3, M:86); the
+    benchmark's 4-plane spectrogram uses in_channels=4, equal to swapping
+    ``Block(4, 16, 'max')`` into ``block1`` of the reference class.
+    """
+
+    def __init__(self, num_classes=N_CLASSES, in_channels=3):
+        super().__init__()
+        c_prev = in_channels
+        for i, (c, kind) in enumerate(_STAGES, start=1):
+            setattr(self, f"block{i}", Block(c_prev, c, kind, (2, 2)))
+            c_prev = c
+        self.gap = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(c_prev, num_classes)
+        self.log_softmax = nn.LogSoftmax(dim=1)
+
+    def features(self, x):
+        for i in range(1, 6):
+            x = getattr(self, f"block{i}")(x)
+        return x
+
+    def forward(self, x):
+        x = self.features(x)
+        return self.log_softmax(self.fc(self.gap(x).flatten(1)))
+
+
+# --------------------------------------------------------------------------------------
+# Row C -- EEGNet over raw EEG [B,1,Chans,Samples] (M:239-289)
+# --------------------------------------------------------------------------------------
+class EEGNet(nn.Module):
+    """temporal conv(1xK, 'same') -> BN -> depthwise (Chans x 1) -> BN -> ELU -> avgpool4
+    -> dropout -> conv(1x16 'same', dense over F1*D) -> BN -> ELU -> avgpool8 -> dropout
+    -> Linear -> LogSoftmax.  No conv has a bias; one Dropout / one ELU instance (M:253-255).
+    """
+
+    def __init__(self, nb_classes, Chans=37, Samples=3000, dropoutRate=0.5, kernLength=64,
+                 F1=8, D=2, F2=16, norm_rate=0.25, dropoutType="Dropout"):
+        super().__init__()
+        self.nb_classes, self.Chans, self.Samples = nb_classes, Chans, Samples
+        self.conv1 = nn.Conv2d(1, F1, (1, kernLength), padding="same", bias=False)
+        self.batchnorm1 = nn.BatchNorm2d(F1)
+        self.depthwiseConv = nn.Conv2d(F1, F1 * D, (Chans, 1), groups=F1, bias=False)
+        self.batchnorm2 = nn.BatchNorm2d(F1 * D)
+        self.activation = nn.ELU()
+        self.avg_pool1 = nn.AvgPool2d((1, 4))
+        self.dropout = nn.Dropout(dropoutRate) if dropoutType == "Dropout" else nn.Dropout2d(dropoutRate)
+        self.separableConv = nn.Conv2d(F1 * D, F2, (1, 16), padding="same", bias=False)
+        self.batchnorm3 = nn.BatchNorm2d(F2)
+        self.avg_pool2 = nn.AvgPool2d((1, 8))
+        self.flatten = nn.Flatten()
+        self.dense = nn.Linear(F2 * (Samples // 32), nb_classes)
+        self.log_softmax = nn.LogSoftmax(dim=1)
+
+    def stages(self, x):
+        """All intermediates, in order (used by fixtures to pin pad/pool conventions)."""
+        t = {}
+        t["conv1"] = self.conv1(x)
+        t["bn1"] = self.batchnorm1(t["conv1"])
+        t["dw"] = self.depthwiseConv(t["bn1"])
+        t["bn2"] = self.batchnorm2(t["dw"])
+        t["pool1"] = self.dropout(self.avg_pool1(self.activation(t["bn2"])))
+        t["sep"] = self.separableConv(t["pool1"])
+        t["bn3"] = self.batchnorm3(t["sep"])
+        t["pool2"] = self.dropout(self.avg_pool2(self.activation(t["bn3"])))
+        t["out"] = self.log_softmax(self.dense(self.flatten(t["pool2"])))
+        return t
+
+    def forward(self, x):
+        return self.stages(x)["out"]
+
+
+# --------------------------------------------------------------------------------------
+# Row D -- late-fusion head over the two 6-way log-prob vectors (NB:1082-1108)
+# --------------------------------------------------------------------------------------
+class MultimodalModel(nn.Module):
+    def __init__(self, eeg_model, spectrogram_model, num_classes=N_CLASSES):
+        super().__init__()
+        self.eeg_model = eeg_model
+        self.spectrogram_model = spectrogram_model
+        width = eeg_model.dense.out_features + spectrogram_model.fc.out_features
+        self.fc1 = nn.Linear(width, 128)
+        self.fc2 = nn.Linear(128, num_classes)
+        self.log_softmax = nn.LogSoftmax(dim=1)
+
+    def forward(self, eeg_data, spectrogram_data):
+        z = torch.cat((self.eeg_model(eeg_data), self.spectrogram_model(spectrogram_data)), dim=1)
+        return self.log_softmax(self.fc2(F.relu(self.fc1(z))))
+
+    def forward_spectrogram(self, spectrogram_data):
+        return self.spectrogram_model(spectrogram_data)
+
+
+def build_multimodal(chans=19, samples=2000, in_channels=4, num_classes=N_CLASSES, dropout=0.5):
+    """Benchmark model of BASELINE.md section 2: 2 025 074 parameters at the defaults."""
+    eeg = EEGNet(num_classes, Chans=chans, Samples=samples, dropoutRate=dropout)
+    spec = Spectrogram_Model(num_classes, in_channels=in_channels)
+    if dropout != 0.5:
+        for i in range(1, 6):
+            getattr(spec, f"block{i}").dropout.p = dropout
+    return MultimodalModel(eeg, spec, num_classes)
+
+
+def set_dropout(model: nn.Module, p: float) -> None:
+    for m in model.modules():
+        if isinstance(m, (nn.Dropout, nn.Dropout2d)):
+            m.p = p
+
+
+# --------------------------------------------------------------------------------------
+# Row E -- one optimisation step of train_and_validate_combined (NB:1595-1607)
+# --------------------------------------------------------------------------------------
+def kl_div(log_probs, target, reduction="mean"):
+    """nn.KLDivLoss: sum t*(log t - y) with 0*log 0 := 0; 'mean' divides by numel (NB:1989),
+    'batchmean' by batch size (NB:1757)."""
+    pointwise = torch.where(target > 0, target * (torch.log(target.clamp_min(1e-38)) - log_probs),
+                            torch.zeros_like(log_probs))
+    total = pointwise.sum()
+    if reduction == "mean":
+        return total / log_probs.numel()
+    if reduction == "batchmean":
+        return total / log_probs.shape[0]
+    if reduction == "sum":
+        return total
+    raise ValueError(reduction)
+
+
+def train_step(model, optimizer, eeg, spec, labels, criterion=None):
+    """zero_grad -> forward -> KLDiv -> backward -> step; returns (loss, n_correct)."""
+    criterion = criterion or nn.KLDivLoss()
+    optimizer.zero_grad()
+    out = model(eeg, spec)
+    loss = criterion(out, labels)
+    loss.backward()
+    optimizer.step()
+    correct = (out.argmax(1) == labels.argmax(1)).sum()
+    return float(loss.detach()), int(correct)
+
+
+# --------------------------------------------------------------------------------------
+# Row G -- attribution
+# --------------------------------------------------------------------------------------
+def _resolve(model: nn.Module, dotted: str) -> nn.Module:
+    mod = model
+    for part in dotted.split("."):
+        mod = getattr(mod, part)
+    return mod
+
+
+def _class_list(class_idx, out):
+    if class_idx is None:
+        return None
+    if isinstance(class_idx, str):
+        if class_idx != "all":
+            raise ValueError(class_idx)
+        return list(range(out.shape[1]))
+    return [int(class_idx)]
+
+
+def grad_cam(model, eeg, spec, target_layer="spectrogram_model.block5", class_idx=None,
+             upsample=True, relu=True, return_parts=False):
+    """Canonical Grad-CAM (Selvaraju et al.) with a forward hook on ``target_layer``.
+
+    score  y_c = model output (a log-probability, as the reference's saliency uses, NB:3109-3111)
+    w[b,k]   = mean_{h,w} d y_c / d A[b,k,h,w]
+    cam[b]   = ReLU( sum_k w[b,k] * A[b,k] )     -> optional bilinear upsample to the input H x W
+
+    class_idx None -> each sample's argmax class; int -> that class; 'all' -> every class
+    (output gains a class axis: [B, n_classes, H, W]).
+    """
+    was_training = model.training
+    model.eval()
+    grabbed = {}
+    handle = _resolve(model, target_layer).register_forward_hook(
+        lambda _m, _i, o: grabbed.__setitem__("A", o))
+    try:
+        out = model(eeg, spec)
+    finally:
+        handle.remove()
+    A = grabbed["A"]
+    classes = _class_list(class_idx, out)
+    maps, raws, weights = [], [], []
+    for c in ([None] if classes is None else classes):
+        if c is None:
+            score = out.gather(1, out.argmax(1, keepdim=True)).sum()
+        else:
+            score = out[:, c].sum()
+        (G,) = torch.autograd.grad(score, A, retain_graph=True)
+        w = G.mean(dim=(2, 3), keepdim=True)
+        raw = (w * A).sum(dim=1)
+        cam = raw.clamp_min(0) if relu else raw
+        if upsample:
+            cam = F.interpolate(cam[:, None], size=spec.shape[-2:], mode="bilinear",
+                                align_corners=False)[:, 0]
+        maps.append(cam.detach()); raws.append(raw.detach()); weights.append(w.detach()[:, :, 0, 0])
+    model.train(was_training)
+    stack = (lambda xs: xs[0]) if classes is None or not isinstance(class_idx, str) else (lambda xs: torch.stack(xs, 1))
+    if return_parts:
+        return stack(maps), stack(raws), stack(weights), A.detach(), out.detach()
+    return stack(maps)
+
+
+def saliency(model, eeg, spec, reference_quirk=False):
+    """|d max-logprob / d input| maps (NB:3101-3129).
+
+    Returns (eeg_sal [B,Chans,S], spec_sal [B,H,W]) with spec reduced by max over channels.
+    ``reference_quirk=True`` reproduces the reference's double accumulation: its second
+    backward() adds to the un-zeroed input gradient, so its spectrogram map is exactly
+    2x the true one; the reference handles batch size 1 only.
+    """
+    was_training = model.training
+    model.eval()
+    eeg = eeg.detach().clone().requires_grad_(True)
+    spec = spec.detach().clone().requires_grad_(True)
+    out = model(eeg, spec)
+    score = out.gather(1, out.argmax(1, keepdim=True)).sum()
+    g_eeg, g_spec = torch.autograd.grad(score, (eeg, spec))
+    model.train(was_training)
+    factor = 2.0 if reference_quirk else 1.0
+    return g_eeg.abs()[:, 0], factor * g_spec.abs().amax(dim=1)
+
+
+def ig_nodes(n_steps=50):
+    """Captum's default rule ('gausslegendre'): alphas and step sizes on [0,1]."""
+    x, w = np.polynomial.legendre.leggauss(n_steps)
+    return 0.5 * (1.0 + x), 0.5 * w
+
+
+def integrated_gradients(model, inputs, baselines=None, target=None, n_steps=50):
+    """(x - x') * sum_k w_k grad F_target(x' + a_k (x - x')); Captum default semantics.
+
+    inputs = (eeg, spec); target None -> argmax class of the un-interpolated input.
+    """
+    was_training = model.training
+    model.eval()
+    eeg, spec = inputs
+    b_eeg, b_spec = baselines if baselines is not None else (torch.zeros_like(eeg), torch.zeros_like(spec))
+    with torch.no_grad():
+        tgt = model(eeg, spec).argmax(1) if target is None else torch.full((eeg.shape[0],), int(target))
+    alphas, steps = ig_nodes(n_steps)
+    acc_e, acc_s = torch.zeros_like(eeg), torch.zeros_like(spec)
+    for a, s in zip(alphas, steps):
+        xe = (b_eeg + float(a) * (eeg - b_eeg)).requires_grad_(True)
+        xs = (b_spec + float(a) * (spec - b_spec)).requires_grad_(True)
+        out = model(xe, xs)
+        score = out.gather(1, tgt[:, None]).sum()
+        ge, gs = torch.autograd.grad(score, (xe, xs))
+        acc_e += float(s) * ge
+        acc_s += float(s) * gs
+    model.train(was_training)
+    return acc_e * (eeg - b_eeg), acc_s * (spec - b_spec)
+
+
+# --------------------------------------------------------------------------------------
+# Row H -- EEG stacker: raw [L, C] window -> [19, L/5]  (dataset.py:73-104,125-131,213-228)
+# --------------------------------------------------------------------------------------
+def butter_lowpass_coeffs(cutoff_freq=20.0, sampling_rate=200.0, order=4):
+    from scipy.signal import butter
+    return butter(order, cutoff_freq / (0.5 * sampling_rate), btype="low", analog=False)
+
+
+def eeg_transform(x: np.ndarray, channels: Optional[Sequence[int]] = None, downsample=5) -> np.ndarray:
+    """select -> clip(+-1024) -> NaN->0 -> /32 -> 4th-order Butterworth low-pass 20 Hz
+    (scipy lfilter along time, float64) -> every 5th sample.  Returns float32 [L/5, C]."""
+    from scipy.signal import lfilter
+    if channels is not None:
+        x = x[:, list(channels)]
+    y = np.nan_to_num(np.clip(x, -1024, 1024), nan=0) / 32.0
+    b, a = butter_lowpass_coeffs()
+    y = lfilter(b, a, y, axis=0)
+    return y[::downsample, :].astype(np.float32)
+
+
+def stack_eeg_batch(raw: np.ndarray) -> torch.Tensor:
+    """[B, L, C] raw -> EEGNet input [B, 1, C, L/5] (EEGDataset.__getitem__ permute + unsqueeze)."""
+    out = np.stack([eeg_transform(r).T for r in raw])
+    return torch.from_numpy(out)[:, None]
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic inputs of SURVEY.md section 8(d) -- shared by tests, smoke and bench
+# --------------------------------------------------------------------------------------
+def synthetic_batch(batch=64, in_channels=4, height=128, width=256, chans=19, raw_len=10000, seed=42,
+                    stacked=True):
+    g = torch.Generator().manual_seed(seed)
+    spec = torch.rand(batch, in_channels, height, width, generator=g)
+    raw = torch.randn(batch, raw_len, chans, generator=g) * 100.0
+    flat = raw.view(-1)
+    n = flat.numel()
+    k = max(1, n // 1000)
+    idx = torch.randint(0, n, (2 * k,), generator=g)
+    flat[idx[:k]] = float("nan")
+    flat[idx[k:]] *= 50.0
+    labels = torch.softmax(torch.randn(batch, N_CLASSES, generator=g), dim=1)
+    eeg = stack_eeg_batch(raw.numpy()) if stacked else None
+    return {"spec": spec, "raw_eeg": raw, "eeg": eeg, "labels": labels}
+
+
+# --------------------------------------------------------------------------------------
+# Deterministic, construction-order-independent test weights (fixtures carry no weights)
+# --------------------------------------------------------------------------------------
+def fill_params(model: nn.Module, seed: int = 42) -> nn.Module:
+    """Overwrite every parameter/buffer from a generator keyed by (seed, tensor name).
+
+    Conv/linear weights ~ U(+-sqrt(6/fan_in)) (keeps activations O(1) through ReLU chains),
+    biases ~ U(+-0.1), BN gamma ~ U(0.5,1.5), beta/running_mean ~ U(+-0.2),
+    running_var ~ U(0.5,1.5), counters 0.  Works on the reference's classes and on the
+    build's classes alike because the tensor *names* are identical.
+    """
+    import zlib
+    sd = model.state_dict()
+    with torch.no_grad():
+        for name, t in sd.items():
+            g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 31))
+            leaf = name.rsplit(".", 1)[-1]
+            if leaf == "num_batches_tracked":
+                t.zero_()
+            elif leaf == "running_var":
+                t.copy_(torch.rand(t.shape, generator=g) + 0.5)
+            elif leaf == "running_mean":
+                t.copy_(torch.rand(t.shape, generator=g) * 0.4 - 0.2)
+            elif t.dim() == 1 and leaf == "weight":          # BatchNorm gamma
+                t.copy_(torch.rand(t.shape, generator=g) + 0.5)
+            elif t.dim() == 1:                                # any bias / BN beta
+                t.copy_(torch.rand(t.shape, generator=g) * 0.2 - 0.1)
+            else:
+                fan_in = t[0].numel()
+                bound = math.sqrt(6.0 / fan_in)
+                t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * bound)
+    return model
+
+
+def seeded(shape, seed, kind="rand", scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.rand(*shape, generator=g) if kind == "rand" else torch.randn(*shape, generator=g)
+    return t * scale
+
+
+def summarize(t: torch.Tensor) -> np.ndarray:
+    """Order-sensitive 4-number digest of a tensor + used with a head slice in fixtures."""
+    f = t.detach().double().flatten()
+    ramp = torch.linspace(0.5, 1.5, f.numel(), dtype=torch.float64)
+    return np.array([f.sum(), f.abs().sum(), (f * ramp).sum(), (f * f).sum()], dtype=np.float64)

@@ -1,0 +1,155 @@
+"""CPU: the oracle restatement (oracle/ref_torch.py) replayed against fixtures recorded from the
+REFERENCE's own classes (oracle/make_golden.py).  This is what pins the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_torch as O
+from tests.golden_util import GOLDEN, check, load
+
+torch.set_num_threads(min(8, os.cpu_count() or 1))
+BLOCKS = {"b4_16_max": (4, 16, 32, 64, "max"), "b16_32_avg": (16, 32, 16, 32, "avg"),
+          "b3_16_max_odd": (3, 16, 50, 37, "max"), "b64_128_avg_odd": (64, 128, 25, 18, "avg")}
+
+
+def test_pin_report_is_clean():
+    rep = json.load(open(os.path.join(GOLDEN, "PIN_REPORT.json")))
+    worst = max(v for k, v in rep.items() if k != "_meta")
+    assert worst < 2e-5
+
+
+@pytest.mark.parametrize("tag", list(BLOCKS))
+def test_block_fwd_bwd(tag):
+    cin, c, h, w, kind = BLOCKS[tag]
+    fix = load("block_" + tag)
+    net = O.fill_params(O.Block(cin, c, kind, (2, 2), dropout_p=0.0), seed=7)
+    x = O.seeded((2, cin, h, w), 11, "randn")
+    r = O.seeded((2, c, h // 2, w // 2), 12, "randn")
+    check(fix, "x", x, tol=0)
+    for mode in ("eval", "train"):
+        net.train(mode == "train")
+        net.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        y = net(xi)
+        (y * r).sum().backward()
+        check(fix, f"{mode}.out", y)
+        check(fix, f"{mode}.dx", xi.grad)
+        for n, p in net.named_parameters():
+            check(fix, f"{mode}.grad.{n}", p.grad, tol=2e-5)
+    check(fix, "after.running_mean", net.bn.running_mean)
+    check(fix, "after.running_var", net.bn.running_var)
+
+
+@pytest.mark.parametrize("tag,cin", [("spec3_64x96", 3), ("spec4_32x64", 4), ("spec3_100x75", 3)])
+def test_spectrogram_model(tag, cin):
+    fix = load(tag)
+    net = O.fill_params(O.Spectrogram_Model(6, in_channels=cin), seed=21).eval()
+    x = torch.from_numpy(fix["x"]) if "x" in fix else None
+    if x is None:
+        h, w = {"spec3_64x96": (64, 96), "spec3_100x75": (100, 75)}[tag]
+        x = O.seeded((2, cin, h, w), 22, "rand")
+    check(fix, "eval.logits", net(x))
+    check(fix, "eval.block5", net.features(x))
+    O.set_dropout(net, 0.0)
+    net.train()
+    check(fix, "train.logits", net(x))
+
+
+@pytest.mark.parametrize("tag,chans,samples", [("eeg19x2000", 19, 2000), ("eeg37x3000", 37, 3000)])
+def test_eegnet(tag, chans, samples):
+    fix = load(tag)
+    net = O.fill_params(O.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0), seed=31)
+    x = O.seeded((2, 1, chans, samples), 32, "randn")
+    r = torch.from_numpy(fix["r"])
+    for mode in ("eval", "train"):
+        net.train(mode == "train")
+        net.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        st = net.stages(xi)
+        (st["out"] * r).sum().backward()
+        check(fix, f"{mode}.out", st["out"])
+        check(fix, f"{mode}.conv1.head", st["conv1"][..., :80])
+        check(fix, f"{mode}.conv1.tail", st["conv1"][..., -80:])
+        for k in ("dw", "bn2", "sep", "bn3"):
+            check(fix, f"{mode}.{k}", st[k])
+        check(fix, f"{mode}.dx.head", xi.grad[..., :96])
+        check(fix, f"{mode}.dx.tail", xi.grad[..., -96:])
+        for n, p in net.named_parameters():
+            check(fix, f"{mode}.grad.{n}", p.grad, tol=2e-5)
+    for k in ("batchnorm1", "batchnorm2", "batchnorm3"):
+        check(fix, f"after.{k}.running_var", getattr(net, k).running_var)
+
+
+@pytest.mark.parametrize("tag,cfg", [("mm_bench_small", (19, 2000, 4, 32, 64, 4)),
+                                     ("mm_native_small", (37, 3000, 3, 50, 37, 2))])
+def test_multimodal_train3(tag, cfg):
+    chans, samples, cin, h, w, b = cfg
+    fix = load(tag)
+    net = O.fill_params(O.build_multimodal(chans, samples, cin, dropout=0.0), seed=41)
+    eeg = O.seeded((b, 1, chans, samples), 42, "randn")
+    spec = O.seeded((b, cin, h, w), 43, "rand")
+    labels = torch.from_numpy(fix["labels"])
+    net.eval()
+    y = net(eeg, spec)
+    check(fix, "eval.logits", y)
+    check(fix, "eval.loss_mean", O.kl_div(y, labels, "mean"))
+    check(fix, "eval.loss_batchmean", O.kl_div(y, labels, "batchmean"))
+    onehot = torch.nn.functional.one_hot(labels.argmax(1), 6).float()
+    check(fix, "eval.loss_onehot", O.kl_div(y, onehot, "mean"))
+    net.train()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    losses = []
+    for step in range(3):
+        loss, _ = O.train_step(net, opt, eeg, spec, labels)
+        losses.append(loss)
+        if step == 0:
+            for n, p in net.named_parameters():
+                check(fix, "step0.ghead." + n, p.grad.flatten()[:32], tol=2e-5)
+    check(fix, "train.losses", np.array(losses))
+    for n, t in net.state_dict().items():
+        check(fix, "after3.shead." + n, t.float().flatten()[:32], tol=2e-5)
+
+
+def test_gradcam_saliency_ig():
+    net = O.fill_params(O.build_multimodal(19, 2000, 4, dropout=0.0), seed=51).eval()
+    eeg = O.seeded((2, 1, 19, 2000), 52, "randn")
+    spec = O.seeded((2, 4, 64, 128), 53, "rand")
+    fix = load("gradcam_4x64x128")
+    for layer in ("block5", "block5.conv3", "block3"):
+        cam, raw, w, A, out = O.grad_cam(net, eeg, spec, "spectrogram_model." + layer, "all",
+                                         upsample=False, return_parts=True)
+        check(fix, layer + ".raw", raw); check(fix, layer + ".cam", cam); check(fix, layer + ".w", w)
+    check(fix, "up.block5", O.grad_cam(net, eeg, spec, class_idx="all"))
+    check(fix, "argmax.block5", O.grad_cam(net, eeg, spec))
+    sal = load("saliency_4x64x128")
+    se, ss = O.saliency(net, eeg[:1], spec[:1], reference_quirk=True)
+    check(sal, "eeg_ref", se[0]); check(sal, "spec_ref_x2", ss[0])
+    ig = load("ig_4x32x64")
+    ie, is_ = O.integrated_gradients(net, (eeg[:1], spec[:1, :, :32, :64].contiguous()), n_steps=50)
+    check(ig, "eeg_attr", ie, tol=5e-5); check(ig, "spec_attr", is_, tol=5e-5)
+
+
+def test_stacker():
+    fix = load("stacker_2x10000x19")
+    raw = O.synthetic_batch(batch=2, seed=61, stacked=False)["raw_eeg"].numpy()
+    out = np.stack([O.eeg_transform(r) for r in raw])
+    check(fix, "out", out)
+    b, a = O.butter_lowpass_coeffs()
+    np.testing.assert_allclose(b, fix["b"], rtol=1e-12)
+    np.testing.assert_allclose(a, fix["a"], rtol=1e-12)
+    assert O.stack_eeg_batch(raw).shape == (2, 1, 19, 2000)
+
+
+def test_state_dict_manifest():
+    man = json.load(open(os.path.join(GOLDEN, "state_dict_manifest.json")))
+    nets = {"Block(4,16)": O.Block(4, 16), "Spectrogram_Model": O.Spectrogram_Model(6),
+            "EEGNet(6,19,2000)": O.EEGNet(6, Chans=19, Samples=2000), "EEGNet(6,37,3000)": O.EEGNet(6),
+            "MultimodalModel(bench)": O.build_multimodal(19, 2000, 4),
+            "MultimodalModel(native)": O.build_multimodal(37, 3000, 3)}
+    for name, net in nets.items():
+        assert {k: list(v.shape) for k, v in net.state_dict().items()} == man[name], name
+        assert sum(p.numel() for p in net.parameters()) == man[name + "#params"]
+    assert man["MultimodalModel(bench)#params"] == 2025074
