@@ -1,0 +1,216 @@
+/* brainxai.h -- C ABI of libbrainxai.so: hand-written HIP (gfx950 / CDNA4) kernels for the
+ * multimodal brain-pattern training + attribution hot path.
+ *
+ * The reference (KC-decoder/Multimodal-Brain-Pattern-Identification_XAI) has NO native code and no
+ * FFI: its "native boundary" for this path is torch -> ATen -> cuDNN/cuBLAS.  Each entry point
+ * below therefore cites the torch op chain of the reference it replaces
+ * (M  = root/src/models/models.py, NB = root/jupyter_notebooks/XAI_Multimodality.py,
+ *  DS = root/src/data/dataset.py, DDP = root/src/training/training_distributed.py).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the current HIP device unless marked host;
+ *   - the caller owns every buffer including workspaces; the library never allocates, frees
+ *     or retains pointers past a call; no call synchronises the device;
+ *   - all launches go to the hipStream_t passed as `stream` (void* to keep hip headers out);
+ *   - activations are channels-last: [B, H, W, C] (NHWC) for the 2-D CNN, [B, F, Chans, T]
+ *     (NCHW, as the reference) for the EEG branch;
+ *   - `dtype` is the STORAGE type of activations: BX_F32 or BX_BF16; arithmetic accumulates in
+ *     fp32 always; parameters, parameter gradients and statistics are fp32;
+ *   - return 0 on success, a negative BX_E* otherwise; bx_last_error_string() (thread-local)
+ *     says why.  Nothing throws or aborts across this boundary.
+ */
+#ifndef BRAINXAI_H
+#define BRAINXAI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BX_VERSION 100
+
+enum { BX_F32 = 0, BX_BF16 = 1 };
+enum { BX_POOL_MAX = 0, BX_POOL_AVG = 1 };
+enum { BX_OK = 0, BX_EINVAL = -1, BX_EDTYPE = -2, BX_EALIGN = -3, BX_EWORKSPACE = -4, BX_EHIP = -5,
+       BX_EUNSUPPORTED = -6 };
+/* conv algorithm selector: 0 = library default, 1 = direct VALU (any dtype), 2 = MFMA implicit GEMM */
+enum { BX_ALGO_AUTO = 0, BX_ALGO_DIRECT = 1, BX_ALGO_MFMA = 2 };
+/* epilogue flags of bx_conv3x3 */
+enum { BX_EPI_RELU = 1 };
+
+typedef void* bxStream;
+
+int bx_version(void);
+const char* bx_last_error_string(void);
+
+/* ---- layout ------------------------------------------------------------------------------- */
+/* fp32 NCHW [B,C,H,W] -> dtype NHWC [B,H,W,Cp], channels C..Cp-1 zero.  Replaces the implicit
+ * NCHW hand-off of DataLoader batches into Block.forward (M:62-63, NB:1595-1598). */
+int bx_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int Cp, int dtype, bxStream stream);
+/* dtype NHWC [B,H,W,Cs] -> fp32 NCHW [B,C,H,W] (first C channels). */
+int bx_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int Cs, int dtype, bxStream stream);
+
+/* ---- 3x3 convolution, stride 1, pad 1  (nn.Conv2d + F.relu, M:49-51,64-66; autograd bwd) ---- */
+/* Pack fp32 OIHW weights [Cout,Cin,3,3] for bx_conv3x3.
+ *   transpose_flip = 0: forward operand   Wp[tap][cin][cout]            (cin padded to Cin_p)
+ *   transpose_flip = 1: data-gradient operand Wp[tap][cout][cin] = W[cout][cin][8-tap]
+ * `packed_f32` ([9][I_p][O_p] fp32) is always written; `packed_mfma` (may be NULL) receives the
+ * bf16 MFMA-fragment layout (see csrc/conv3x3_mfma.hip). I_p/O_p = channel counts rounded up to 8/16. */
+int bx_conv3x3_pack(const float* w_oihw, float* packed_f32, void* packed_mfma, int Cout, int Cin,
+                    int I_p, int O_p, int transpose_flip, bxStream stream);
+/* bytes of the MFMA operand for padded dims (0 when the MFMA path does not cover them). */
+size_t bx_conv3x3_packed_mfma_bytes(int I_p, int O_p);
+/* y = epi(conv3x3(x, Wp) + bias);  x [B,H,W,Ci] -> y [B,H,W,Co], both `dtype`.
+ *   bias (fp32 [Co]) may be NULL; flags & BX_EPI_RELU applies max(.,0);
+ *   relu_mask_src (dtype [B,H,W,Co], may be NULL): y *= (relu_mask_src > 0)  -- the ReLU backward
+ *     of the layer that produced the tensor whose gradient this call computes;
+ *   addend (dtype [B,H,W,Co], may be NULL) is added last (skip-path gradient).
+ * Forward uses (bias, RELU); data-gradient uses the transpose_flip pack + relu_mask_src/addend. */
+int bx_conv3x3(const void* x, const float* packed_f32, const void* packed_mfma, const float* bias,
+               const void* relu_mask_src, const void* addend, void* y,
+               int B, int H, int W, int Ci, int Co, int dtype, int flags, int algo, bxStream stream);
+/* Weight/bias gradient: dW[Cout,Cin,3,3] = sum_p X[p+tap] (x) dZ[p], db = sum_p dZ[p]  (fp32 out,
+ * overwritten).  x [B,H,W,Ci_p], dz [B,H,W,Co].  Cin = logical input channels (<= Ci_p). */
+size_t bx_conv3x3_wgrad_workspace(int B, int H, int W, int Ci_p, int Co, int dtype, int algo);
+int bx_conv3x3_wgrad(const void* x, const void* dz, float* dw_oihw, float* dbias, int B, int H, int W,
+                     int Cin, int Ci_p, int Co, int dtype, int algo, void* workspace, size_t workspace_bytes,
+                     bxStream stream);
+
+/* ---- Block tail: 2x2 pool -> BatchNorm2d -> Dropout -> + conv1x1(bilinear(x))  (M:67-76) ------ */
+typedef struct {
+  int B, H, W;          /* conv3 output resolution; pooled map is [B, H/2, W/2] (floor) */
+  int Cin_p;            /* channels of the block input x as stored (padded)            */
+  int C;                /* block output channels                                        */
+  int pool;             /* BX_POOL_MAX | BX_POOL_AVG                                    */
+  int training;         /* 1: batch statistics + running-stat update; 0: running stats  */
+  float eps, momentum;  /* 1e-5, 0.1 (nn.BatchNorm2d defaults)                          */
+  float dropout_p;      /* 0 disables; mask = hash(seed[0], salt, element)              */
+  uint32_t salt;
+  int dtype;
+} bxTailDesc;
+size_t bx_block_tail_workspace(const bxTailDesc* d);
+/* y3: conv3 output [B,H,W,C]; x: block input [B,H,W,Cin_p]; w1x1 fp32 [C][Cin] OIHW(1x1), Cin logical;
+ * bn_* fp32 [C]; num_batches_tracked int64[1]; seed uint64[1] (device, may be NULL if dropout_p==0).
+ * Outputs: pooled [B,H/2,W/2,C] (pre-BN, kept for backward), out [B,H/2,W/2,C],
+ * save_mean/save_invstd fp32 [C] (statistics actually used). */
+int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void* x, const float* w1x1, int Cin,
+                      const float* b1x1, const float* bn_weight, const float* bn_bias,
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                      const uint64_t* seed, void* pooled, void* out, float* save_mean, float* save_invstd,
+                      void* workspace, size_t workspace_bytes, bxStream stream);
+/* Backward of the tail.  dout [B,H/2,W/2,C].  Produces
+ *   dz3 [B,H,W,C]: gradient w.r.t. conv3's pre-activation (pool backward AND conv3's ReLU mask applied),
+ *   dx_skip [B,H,W,Cin_p] (may be NULL): gradient reaching the block input through the skip path,
+ *   d_bn_weight, d_bn_bias, d_w1x1 [C][Cin], d_b1x1 (fp32, overwritten). */
+int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const void* y3, const void* x, const void* pooled,
+                      const float* w1x1, int Cin, const float* bn_weight, const float* save_mean,
+                      const float* save_invstd, const uint64_t* seed, void* dz3, void* dx_skip,
+                      float* d_bn_weight, float* d_bn_bias, float* d_w1x1, float* d_b1x1,
+                      void* workspace, size_t workspace_bytes, bxStream stream);
+/* y = max(x,0) elementwise (only used when a pre-ReLU conv output is an attribution target). */
+int bx_relu(const void* x, void* y, size_t n, int dtype, bxStream stream);
+
+/* ---- heads ------------------------------------------------------------------------------------ */
+/* AdaptiveAvgPool2d(1) -> Linear(C,N) -> LogSoftmax (M:92-94,103-106).  feat [B,HW,C] dtype;
+ * gap_out fp32 [B,C] (saved), logp fp32 [B,N].  N <= 32. */
+int bx_gap_fc_lsm_fwd(const void* feat, const float* w, const float* b, float* gap_out, float* logp,
+                      int B, int HW, int C, int N, int dtype, bxStream stream);
+/* dlogp [B,N] -> dfeat [B,HW,C] (dtype), dW [N,C], db [N].  dfeat/dW/db may be NULL individually. */
+int bx_gap_fc_lsm_bwd(const float* dlogp, const float* logp, const float* gap_out, const float* w,
+                      void* dfeat, float* dw, float* db, int B, int HW, int C, int N, int dtype, bxStream stream);
+/* Linear(K,N) -> LogSoftmax on fp32 features [B,K] (EEGNet dense, M:263-269,286-288). */
+int bx_linear_lsm_fwd(const float* x, const float* w, const float* b, float* logp, int B, int K, int N,
+                      bxStream stream);
+int bx_linear_lsm_bwd(const float* dlogp, const float* logp, const float* x, const float* w, float* dx,
+                      float* dw, float* db, int B, int K, int N, bxStream stream);
+/* Fusion head: cat(eeg_logp, spec_logp) -> Linear(2N,Hd) -> ReLU -> Linear(Hd,N) -> LogSoftmax
+ * (NB:1095-1105).  hidden fp32 [B,Hd] is saved for backward. */
+int bx_fusion_head_fwd(const float* eeg_logp, const float* spec_logp, const float* w1, const float* b1,
+                       const float* w2, const float* b2, float* hidden, float* logp, int B, int N, int Hd,
+                       bxStream stream);
+int bx_fusion_head_bwd(const float* dlogp, const float* logp, const float* hidden, const float* eeg_logp,
+                       const float* spec_logp, const float* w1, const float* w2, float* d_eeg_logp,
+                       float* d_spec_logp, float* dw1, float* db1, float* dw2, float* db2, int B, int N, int Hd,
+                       bxStream stream);
+/* nn.KLDivLoss on log-prob input / prob target (NB:1989,1599): loss[1] and dlogp = -t/denom.
+ * reduction: 0 'mean' (denom B*N), 1 'batchmean' (denom B), 2 'sum'.  grad_scale multiplies dlogp. */
+int bx_kldiv_fwd_bwd(const float* logp, const float* target, float* loss, float* dlogp, int B, int N,
+                     int reduction, float grad_scale, bxStream stream);
+
+/* ---- EEGNet branch (M:239-289); activations fp32 or bf16 NCHW ------------------------------------ */
+typedef struct {
+  int B, Chans, T;      /* input [B,1,Chans,T] fp32                                  */
+  int F1, D, F2;        /* 8, 2, 16                                                  */
+  int K1, K2;           /* temporal kernel lengths 64 and 16 ('same': left pad (K-1)/2) */
+  int P1, P2;           /* average-pool widths 4 and 8                               */
+  int training;
+  float eps, momentum, dropout_p;
+  uint32_t salt;
+  int dtype;            /* storage of the big intermediates (conv1 output)           */
+} bxEegDesc;
+/* Parameter block: pointers to the fp32 tensors of the module, reference names in comments. */
+typedef struct {
+  const float* conv1_w;      /* conv1.weight        [F1,1,1,K1]      */
+  const float* bn1_w; const float* bn1_b; float* bn1_rm; float* bn1_rv; int64_t* bn1_nbt;
+  const float* dw_w;         /* depthwiseConv.weight [F1*D,1,Chans,1] */
+  const float* bn2_w; const float* bn2_b; float* bn2_rm; float* bn2_rv; int64_t* bn2_nbt;
+  const float* sep_w;        /* separableConv.weight [F2,F1*D,1,K2]  */
+  const float* bn3_w; const float* bn3_b; float* bn3_rm; float* bn3_rv; int64_t* bn3_nbt;
+} bxEegParams;
+typedef struct {
+  float* conv1_w; float* bn1_w; float* bn1_b; float* dw_w; float* bn2_w; float* bn2_b;
+  float* sep_w; float* bn3_w; float* bn3_b;
+} bxEegGrads;
+/* Saved-for-backward arena layout is private; query its size, pass the same buffer to bwd. */
+size_t bx_eeg_saved_bytes(const bxEegDesc* d);
+size_t bx_eeg_workspace(const bxEegDesc* d);
+/* x fp32 [B,1,Chans,T] -> feat fp32 [B, F2*(T/P1/P2)] (the Flatten() output fed to `dense`). */
+int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, const float* x, const uint64_t* seed,
+                        float* feat, void* saved, void* workspace, size_t workspace_bytes, bxStream stream);
+/* dfeat [B, F2*T2] -> parameter gradients and (optional, may be NULL) dx fp32 [B,1,Chans,T]. */
+int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, const float* x, const float* dfeat,
+                        const uint64_t* seed, const void* saved, const bxEegGrads* g, float* dx,
+                        void* workspace, size_t workspace_bytes, bxStream stream);
+
+/* ---- attribution ----------------------------------------------------------------------------- */
+/* Grad-CAM channel reduce (canonical; the reference has none -- SURVEY.md K18):
+ *   w[m,c] = mean_p G[m,p,c];  raw[m,p] = sum_c w[m,c]*A[m/maps_per_act,p,c];  cam = relu ? max(raw,0) : raw.
+ * G: [n_maps,HW,C], A: [n_maps/maps_per_act,HW,C], `dtype` channels-last (maps_per_act = classes per
+ * sample sharing one activation).  cam fp32 [n_maps,HW]; weights_out fp32 [n_maps,C] may be NULL. */
+int bx_gradcam_reduce(const void* A, const void* G, float* cam, float* weights_out, int n_maps, int maps_per_act,
+                      int HW, int C, int relu, int dtype, bxStream stream);
+/* Bilinear resize (align_corners=False) of fp32 maps [N,h,w] -> [N,H,W]  (F.interpolate). */
+int bx_resize_bilinear(const float* src, float* dst, int N, int h, int w, int H, int W, bxStream stream);
+/* Saliency reduce (NB:3121-3129): out[b,p] = scale * max_c |g[b,p,c]|, g NHWC `dtype` (first C of Cs). */
+int bx_saliency_reduce(const void* g, float* out, int B, int HW, int C, int Cs, float scale, int dtype,
+                       bxStream stream);
+/* y = alpha*x + beta*y over fp32 (integrated-gradients accumulate, baseline interpolation). */
+int bx_axpby(const float* x, float* y, size_t n, float alpha, float beta, bxStream stream);
+int bx_mul(const float* a, const float* b, float* out, size_t n, bxStream stream);
+/* out = |x| over fp32 (EEG saliency, NB:3121-3122). */
+int bx_abs(const float* x, float* out, size_t n, bxStream stream);
+/* out = x * scalar[0] with the scalar on the device (loss.backward()'s upstream gradient; no host sync). */
+int bx_scale_dev(const float* x, const float* scalar, float* out, size_t n, bxStream stream);
+
+/* ---- EEG stacker (DS:73-104,125-131): select/clip/nan->0,/32 -> Butterworth IIR -> decimate ---- */
+/* raw fp32 [B,L,Craw]; channel_index int32[C] (device) selects columns; b,a = host double[order+1];
+ * out fp32 [B,1,C,L/step].  fp64 state per (sample, channel) row. */
+int bx_eeg_stack_iir(const float* raw, const int* channel_index, float* out, int B, int L, int Craw, int C,
+                     const double* b_host, const double* a_host, int order, int step, float clip, float scale,
+                     bxStream stream);
+
+/* ---- optimiser over the flat parameter arena (torch.optim.AdamW, NB:1988) ------------------------ */
+/* p, g, m, v fp32 [n]; step_count device float[1]: incremented by this call, then used as t. */
+int bx_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float grad_scale, float* step_count, bxStream stream);
+/* sum of squares of a flat fp32 arena -> out[1] (DDP loop's manual L2 term, DDP:52-53). */
+int bx_sumsq(const float* x, size_t n, float* out, bxStream stream);
+/* dropout seed stream: out[0] = ++state[0] (a forward call and its backward read the same `out`). */
+int bx_seed_next(uint64_t* state, uint64_t* out, bxStream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRAINXAI_H */

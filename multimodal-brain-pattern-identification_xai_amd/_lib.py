@@ -1,0 +1,107 @@
+"""ctypes binding of libbrainxai.so (the C ABI declared in include/brainxai.h).
+
+The product path has NO fallback: if the shared object is missing or a launcher returns an
+error, a RuntimeError is raised.  The library is built in-tree by ``build.py`` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbrainxai.so")
+
+BX_F32, BX_BF16 = 0, 1
+BX_POOL_MAX, BX_POOL_AVG = 0, 1
+BX_ALGO_AUTO, BX_ALGO_DIRECT, BX_ALGO_MFMA = 0, 1, 2
+BX_EPI_RELU = 1
+
+vp, i32, i64, u32, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_float, C.c_size_t
+
+
+class TailDesc(C.Structure):
+    _fields_ = [("B", i32), ("H", i32), ("W", i32), ("Cin_p", i32), ("C", i32), ("pool", i32), ("training", i32),
+                ("eps", f32), ("momentum", f32), ("dropout_p", f32), ("salt", u32), ("dtype", i32)]
+
+
+class EegDesc(C.Structure):
+    _fields_ = [("B", i32), ("Chans", i32), ("T", i32), ("F1", i32), ("D", i32), ("F2", i32), ("K1", i32), ("K2", i32),
+                ("P1", i32), ("P2", i32), ("training", i32), ("eps", f32), ("momentum", f32), ("dropout_p", f32),
+                ("salt", u32), ("dtype", i32)]
+
+
+class EegParams(C.Structure):
+    _fields_ = [(n, vp) for n in ("conv1_w", "bn1_w", "bn1_b", "bn1_rm", "bn1_rv", "bn1_nbt", "dw_w", "bn2_w", "bn2_b",
+                                  "bn2_rm", "bn2_rv", "bn2_nbt", "sep_w", "bn3_w", "bn3_b", "bn3_rm", "bn3_rv", "bn3_nbt")]
+
+
+class EegGrads(C.Structure):
+    _fields_ = [(n, vp) for n in ("conv1_w", "bn1_w", "bn1_b", "dw_w", "bn2_w", "bn2_b", "sep_w", "bn3_w", "bn3_b")]
+
+
+P = C.POINTER
+# name -> (restype, argtypes); must list every symbol include/brainxai.h declares (tests check this)
+SIGNATURES = {
+    "bx_version": (i32, []),
+    "bx_last_error_string": (C.c_char_p, []),
+    "bx_nchw_to_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "bx_nhwc_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "bx_conv3x3_pack": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "bx_conv3x3_packed_mfma_bytes": (sz, [i32, i32]),
+    "bx_scale_dev": (i32, [vp, vp, vp, sz, vp]),
+    "bx_abs": (i32, [vp, vp, sz, vp]),
+    "bx_conv3x3": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "bx_conv3x3_wgrad_workspace": (sz, [i32, i32, i32, i32, i32, i32, i32]),
+    "bx_conv3x3_wgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "bx_block_tail_workspace": (sz, [P(TailDesc)]),
+    "bx_block_tail_fwd": (i32, [P(TailDesc), vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "bx_block_tail_bwd": (i32, [P(TailDesc), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "bx_relu": (i32, [vp, vp, sz, i32, vp]),
+    "bx_gap_fc_lsm_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "bx_gap_fc_lsm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "bx_linear_lsm_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "bx_linear_lsm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "bx_fusion_head_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "bx_fusion_head_bwd": (i32, [vp] * 13 + [i32, i32, i32, vp]),
+    "bx_kldiv_fwd_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
+    "bx_eeg_saved_bytes": (sz, [P(EegDesc)]),
+    "bx_eeg_workspace": (sz, [P(EegDesc)]),
+    "bx_eeg_features_fwd": (i32, [P(EegDesc), P(EegParams), vp, vp, vp, vp, vp, sz, vp]),
+    "bx_eeg_features_bwd": (i32, [P(EegDesc), P(EegParams), vp, vp, vp, vp, P(EegGrads), vp, vp, sz, vp]),
+    "bx_gradcam_reduce": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "bx_resize_bilinear": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "bx_saliency_reduce": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, vp]),
+    "bx_axpby": (i32, [vp, vp, sz, f32, f32, vp]),
+    "bx_mul": (i32, [vp, vp, vp, sz, vp]),
+    "bx_eeg_stack_iir": (i32, [vp, vp, vp, i32, i32, i32, i32, P(C.c_double), P(C.c_double), i32, i32, f32, f32, vp]),
+    "bx_adamw_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, f32, vp, vp]),
+    "bx_sumsq": (i32, [vp, sz, vp, vp]),
+    "bx_seed_next": (i32, [vp, vp, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raise loudly when the extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"brainxai: HIP extension not built ({LIB_PATH} missing). Run `python __graft_entry__.py` "
+            "or `python multimodal-brain-pattern-identification_xai_amd/build.py`; there is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    if lib.bx_version() != 100:
+        raise RuntimeError(f"brainxai: library version {lib.bx_version()} != 100")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().bx_last_error_string()
+        raise RuntimeError(f"brainxai {what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,164 @@
+// Attribution reduce kernels and the EEG stacker.
+//   bx_gradcam_reduce : canonical Grad-CAM channel reduce (the reference has no Grad-CAM)
+//   bx_resize_bilinear: F.interpolate(mode='bilinear', align_corners=False) of the maps
+//   bx_saliency_reduce: spec.grad.abs().max(dim=1)   reference XAI_Multimodality.py:3128-3129
+//   bx_eeg_stack_iir  : _EEGTransformer.transform     reference root/src/data/dataset.py:73-104,125-131
+#include "bx_common.h"
+
+// One workgroup per map.  Phase 1: w[c] = mean_p G[p][c] -- every thread owns 8 channels of a pixel
+// slice (16-byte loads, coalesced along C), LDS [slots][C] then a fixed-order column sum.
+// Phase 2: raw[p] = sum_c w[c] A[p][c] -- one wave per pixel, 8 channels per lane, DPP/shuffle reduce.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gradcam(const T* __restrict__ A, const T* __restrict__ G, float* __restrict__ cam,
+                                                  float* __restrict__ wout, int HW, int C, int maps_per_act, int relu) {
+  extern __shared__ float sm[];  // part[slots*C] | w[C]
+  const int m = blockIdx.x;
+  const int ncg = C / 8, slots = 256 / ncg;
+  float* part = sm;
+  float* w = sm + (size_t)slots * C;
+  const T* g = G + (size_t)m * HW * C;
+  const T* a = A + (size_t)(m / maps_per_act) * HW * C;
+  const int cg = threadIdx.x % ncg, slot = threadIdx.x / ncg;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int p = slot; p < HW; p += slots) {
+    float v[8];
+    ld8(g, (size_t)p * C + cg * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[slot * C + cg * 8 + j] = acc[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int sl = 0; sl < slots; ++sl) s += part[sl * C + c];
+    s /= (float)HW;
+    w[c] = s;
+    if (wout) wout[(size_t)m * C + c] = s;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int p = wave; p < HW; p += 4) {
+    float s = 0.f;
+    for (int c0 = lane * 8; c0 < C; c0 += 512) {
+      float v[8];
+      ld8(a, (size_t)p * C + c0, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s = fmaf(w[c0 + j], v[j], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) cam[(size_t)m * HW + p] = relu ? fmaxf(s, 0.f) : s;
+  }
+}
+
+extern "C" int bx_gradcam_reduce(const void* A, const void* G, float* cam, float* weights_out, int n_maps, int maps_per_act,
+                                 int HW, int C, int relu, int dtype, bxStream stream) {
+  BX_DTYPE_OK(dtype);
+  BX_REQUIRE(A && G && cam && n_maps > 0 && HW > 0 && maps_per_act > 0 && n_maps % maps_per_act == 0, "bx_gradcam_reduce: bad arguments");
+  BX_REQUIRE(C % 8 == 0 && C >= 8 && C <= 2048 && 256 % (C / 8) == 0, "bx_gradcam_reduce: C=%d must be 8*2^k, <= 2048", C);
+  const size_t lds = ((size_t)(256 / (C / 8)) * C + C) * sizeof(float);
+  BX_DISPATCH_DTYPE(dtype, T,
+    hipLaunchKernelGGL((k_gradcam<T>), dim3(n_maps), dim3(256), lds, (hipStream_t)stream, (const T*)A, (const T*)G, cam, weights_out,
+                       HW, C, maps_per_act, relu));
+  BX_CHECK_LAUNCH("bx_gradcam_reduce");
+  return BX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_resize_bilinear(const float* __restrict__ src, float* __restrict__ dst, long long n, int h, int w, int H, int W,
+                                  float sy, float sx) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % W);
+    const long long r = i / W;
+    const int Y = (int)(r % H);
+    const long long m = r / H;
+    int y0, y1, x0, x1; float ly, lx;
+    bilinear_src(Y, sy, h, y0, y1, ly);
+    bilinear_src(X, sx, w, x0, x1, lx);
+    const float* s = src + m * h * w;
+    dst[i] = (1.f - ly) * ((1.f - lx) * s[y0 * w + x0] + lx * s[y0 * w + x1]) + ly * ((1.f - lx) * s[y1 * w + x0] + lx * s[y1 * w + x1]);
+  }
+}
+extern "C" int bx_resize_bilinear(const float* src, float* dst, int N, int h, int w, int H, int W, bxStream stream) {
+  BX_REQUIRE(src && dst && N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bx_resize_bilinear: bad arguments");
+  const long long n = (long long)N * H * W;
+  const int grid = bx_ceil_div(n, 256) > 4096 ? 4096 : bx_ceil_div(n, 256);
+  hipLaunchKernelGGL(k_resize_bilinear, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, n, h, w, H, W,
+                     (float)h / (float)H, (float)w / (float)W);
+  BX_CHECK_LAUNCH("bx_resize_bilinear");
+  return BX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_saliency(const T* __restrict__ g, float* __restrict__ out, long long npix, int C, int Cs, float scale) {
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+    float m = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      float v[8];
+      ld8(g, (size_t)p * Cs + c0, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (c0 + j < C) m = fmaxf(m, fabsf(v[j]));
+    }
+    out[p] = scale * m;
+  }
+}
+extern "C" int bx_saliency_reduce(const void* g, float* out, int B, int HW, int C, int Cs, float scale, int dtype, bxStream stream) {
+  BX_DTYPE_OK(dtype);
+  BX_REQUIRE(g && out && B > 0 && HW > 0 && C > 0 && C <= Cs && Cs % 8 == 0, "bx_saliency_reduce: bad arguments");
+  const long long npix = (long long)B * HW;
+  const int grid = bx_ceil_div(npix, 256) > 4096 ? 4096 : bx_ceil_div(npix, 256);
+  BX_DISPATCH_DTYPE(dtype, T,
+    hipLaunchKernelGGL((k_saliency<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)g, out, npix, C, Cs, scale));
+  BX_CHECK_LAUNCH("bx_saliency_reduce");
+  return BX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// EEG stacker: one thread per (sample, channel) row runs the direct-form-II-transposed recurrence
+// scipy.signal.lfilter uses, in fp64, over the clipped / NaN-zeroed / scaled fp32 samples, and keeps
+// every `step`-th output.  Lanes of a wave are neighbouring channels of a sample, so the per-step
+// loads of one wave touch a few contiguous 76-byte records.
+#define IIR_MAX_ORDER 8
+struct IirCoef { double b[IIR_MAX_ORDER + 1]; double a[IIR_MAX_ORDER + 1]; };
+__global__ void k_eeg_stack_iir(const float* __restrict__ raw, const int* __restrict__ chan, float* __restrict__ out, int nrows,
+                                int L, int Craw, int C, IirCoef k, int order, int step, float clip, float inv_scale) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nrows) return;
+  const int b = row / C, c = row % C;
+  const int col = chan ? chan[c] : c;
+  const float* src = raw + (size_t)b * L * Craw + col;
+  const int Lout = (L + step - 1) / step;
+  float* dst = out + (size_t)row * Lout;
+  double z[IIR_MAX_ORDER];
+#pragma unroll
+  for (int i = 0; i < IIR_MAX_ORDER; ++i) z[i] = 0.0;
+  for (int n = 0; n < L; ++n) {
+    float xv = src[(size_t)n * Craw];
+    xv = fminf(fmaxf(xv, -clip), clip);            // np.clip keeps NaN; fminf/fmaxf drop it -> handle below
+    if (src[(size_t)n * Craw] != src[(size_t)n * Craw]) xv = 0.f;  // np.nan_to_num(nan=0)
+    const double x = (double)(xv * inv_scale);
+    const double y = z[0] + k.b[0] * x;
+#pragma unroll
+    for (int i = 0; i < IIR_MAX_ORDER - 1; ++i)
+      if (i < order - 1) z[i] = z[i + 1] + k.b[i + 1] * x - k.a[i + 1] * y;
+    z[order - 1] = k.b[order] * x - k.a[order] * y;
+    if (n % step == 0) dst[n / step] = (float)y;
+  }
+}
+extern "C" int bx_eeg_stack_iir(const float* raw, const int* channel_index, float* out, int B, int L, int Craw, int C,
+                                const double* b_host, const double* a_host, int order, int step, float clip, float scale,
+                                bxStream stream) {
+  BX_REQUIRE(raw && out && b_host && a_host && B > 0 && L > 0 && C > 0 && Craw >= 1, "bx_eeg_stack_iir: bad arguments");
+  BX_REQUIRE(order >= 1 && order <= IIR_MAX_ORDER && step >= 1 && scale != 0.f, "bx_eeg_stack_iir: order must be 1..%d", IIR_MAX_ORDER);
+  BX_REQUIRE(channel_index || C <= Craw, "bx_eeg_stack_iir: C > Craw without a channel index");
+  IirCoef k;
+  const double a0 = a_host[0];
+  BX_REQUIRE(a0 != 0.0, "bx_eeg_stack_iir: a[0] == 0");
+  for (int i = 0; i <= IIR_MAX_ORDER; ++i) { k.b[i] = i <= order ? b_host[i] / a0 : 0.0; k.a[i] = i <= order ? a_host[i] / a0 : 0.0; }
+  const int nrows = B * C;
+  hipLaunchKernelGGL(k_eeg_stack_iir, dim3(bx_ceil_div(nrows, 64)), dim3(64), 0, (hipStream_t)stream, raw, channel_index, out,
+                     nrows, L, Craw, C, k, order, step, clip, 1.f / scale);
+  BX_CHECK_LAUNCH("bx_eeg_stack_iir");
+  return BX_OK;
+}

@@ -1,0 +1,131 @@
+// Shared device/host helpers for libbrainxai (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/brainxai.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void bx_set_error(const char* fmt, ...);
+#define BX_FAIL(code, ...) do { bx_set_error(__VA_ARGS__); return (code); } while (0)
+#define BX_REQUIRE(cond, ...) do { if (!(cond)) BX_FAIL(BX_EINVAL, __VA_ARGS__); } while (0)
+#define BX_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
+  if (e_ != hipSuccess) BX_FAIL(BX_EHIP, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)
+#define BX_DTYPE_OK(dt) do { if ((dt) != BX_F32 && (dt) != BX_BF16) BX_FAIL(BX_EDTYPE, "unsupported dtype %d", (dt)); } while (0)
+
+static inline int bx_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline size_t bx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline size_t bx_esize(int dtype) { return dtype == BX_BF16 ? 2 : 4; }
+
+// ---- scalar conversion ---------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // keep NaN a NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                        // round to nearest even
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float ldf(const float* p, size_t i) { return p[i]; }
+__device__ __forceinline__ float ldf(const bf16_t* p, size_t i) { return bf2f(p[i]); }
+__device__ __forceinline__ void stf(float* p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void stf(bf16_t* p, size_t i, float v) { p[i] = f2bf(v); }
+
+// ---- 8-channel vector access (16 B for bf16, 2 x 16 B for fp32); p + i must be 8-element aligned ----
+__device__ __forceinline__ void ld8(const float* p, size_t i, float v[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p + i);
+  const float4 b = *reinterpret_cast<const float4*>(p + i + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const bf16_t* p, size_t i, float v[8]) {
+  const uint4 r = *reinterpret_cast<const uint4*>(p + i);
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[2 * k] = __uint_as_float(w[k] << 16);
+    v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void st8(float* p, size_t i, const float v[8]) {
+  *reinterpret_cast<float4*>(p + i) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void st8(bf16_t* p, size_t i, const float v[8]) {
+  uint32_t w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = (uint32_t)f2bf(v[2 * k]) | ((uint32_t)f2bf(v[2 * k + 1]) << 16);
+  *reinterpret_cast<uint4*>(p + i) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---- counter-based dropout mask: keep iff hash(seed, salt, idx) maps above p --------------------
+__device__ __forceinline__ uint32_t bx_hash(uint64_t seed, uint32_t salt, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + ((uint64_t)salt << 32 | salt);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+// returns the multiplier applied to an element: 0 or 1/(1-p)
+__device__ __forceinline__ float bx_dropout_scale(uint64_t seed, uint32_t salt, uint64_t idx, float p, float inv_keep) {
+  const float u = (float)(bx_hash(seed, salt, idx) >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.0f;
+}
+
+// ---- wave / block reductions (wave = 64 lanes) ----------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// PyTorch's area_pixel_compute_source_index for bilinear, align_corners=False.
+__device__ __forceinline__ void bilinear_src(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
+  float s = scale * ((float)o + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+// forward 2: statistics -> (scale, shift); running-stat update (unbiased variance, momentum)
+static __global__ void k_bn_finalize(const float* __restrict__ partials, int nblk, double count, int C, int training,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+                              float* __restrict__ rvar, int64_t* __restrict__ nbt, float momentum, float eps,
+                              float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
+                              float* __restrict__ save_invstd) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float mean, invstd;
+  if (training) {
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nblk; ++k) { s += partials[((size_t)k * 2 + 0) * C + c]; q += partials[((size_t)k * 2 + 1) * C + c]; }
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    if (c == 0 && nbt) nbt[0] += 1;
+  } else {
+    mean = rmean[c];
+    invstd = 1.0f / sqrtf(rvar[c] + eps);
+  }
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - mean * sc;
+  save_mean[c] = mean;
+  save_invstd[c] = invstd;
+}
+
+
+#define BX_DISPATCH_DTYPE(dtype, T, ...) \
+  do { if ((dtype) == BX_F32) { typedef float T; __VA_ARGS__; } else { typedef bf16_t T; __VA_ARGS__; } } while (0)

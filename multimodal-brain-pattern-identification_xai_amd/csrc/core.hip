@@ -1,0 +1,205 @@
+// libbrainxai core: error plumbing, layout conversion, elementwise helpers, AdamW, seed.
+#include <stdarg.h>
+#include <string.h>
+#include "bx_common.h"
+
+static thread_local char g_err[512] = "";
+void bx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" int bx_version(void) { return BX_VERSION; }
+extern "C" const char* bx_last_error_string(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// NCHW fp32 -> NHWC(Cp) T.  One thread per pixel; reads are coalesced along x per channel plane,
+// each 8-channel group of the pixel is written with 16-byte stores; channels C..Cp-1 are zero.
+template <typename T>
+__global__ void k_nchw_to_nhwc(const float* __restrict__ src, T* __restrict__ dst, int C, int Cp, long long HW, long long npix) {
+  long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const long long b = p / HW, r = p - b * HW;
+  for (int c0 = 0; c0 < Cp; c0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (c0 + j) < C ? src[(b * C + c0 + j) * HW + r] : 0.f;
+    st8(dst, (size_t)p * Cp + c0, v);
+  }
+}
+
+template <typename T>
+__global__ void k_nhwc_to_nchw(const T* __restrict__ src, float* __restrict__ dst, int C, int Cs, long long HW, long long npix) {
+  long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const long long b = p / HW, r = p - b * HW;
+  for (int c0 = 0; c0 < C; c0 += 8) {
+    float v[8];
+    ld8(src, (size_t)p * Cs + c0, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (c0 + j < C) dst[(b * C + c0 + j) * HW + r] = v[j];
+  }
+}
+
+extern "C" int bx_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int Cp, int dtype, bxStream stream) {
+  BX_DTYPE_OK(dtype);
+  BX_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "bx_nchw_to_nhwc: bad arguments");
+  BX_REQUIRE(Cp % 8 == 0 && C <= Cp, "bx_nchw_to_nhwc: Cp must be a multiple of 8 and >= C (C=%d Cp=%d)", C, Cp);
+  const long long HW = (long long)H * W, npix = HW * B;
+  const int grid = bx_ceil_div(npix, 256);
+  hipStream_t s = (hipStream_t)stream;
+  BX_DISPATCH_DTYPE(dtype, T,
+    hipLaunchKernelGGL((k_nchw_to_nhwc<T>), dim3(grid), dim3(256), 0, s, src, (T*)dst, C, Cp, HW, npix));
+  BX_CHECK_LAUNCH("bx_nchw_to_nhwc");
+  return BX_OK;
+}
+
+extern "C" int bx_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int Cs, int dtype, bxStream stream) {
+  BX_DTYPE_OK(dtype);
+  BX_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cs % 8 == 0 && C <= Cs, "bx_nhwc_to_nchw: bad arguments");
+  const long long HW = (long long)H * W, npix = HW * B;
+  hipStream_t s = (hipStream_t)stream;
+  BX_DISPATCH_DTYPE(dtype, T,
+    hipLaunchKernelGGL((k_nhwc_to_nchw<T>), dim3(bx_ceil_div(npix, 256)), dim3(256), 0, s, (const T*)src, dst, C, Cs, HW, npix));
+  BX_CHECK_LAUNCH("bx_nhwc_to_nchw");
+  return BX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_relu(const T* __restrict__ x, T* __restrict__ y, size_t n8) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n8; i += stride) {
+    float v[8];
+    ld8(x, i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    st8(y, i * 8, v);
+  }
+}
+extern "C" int bx_relu(const void* x, void* y, size_t n, int dtype, bxStream stream) {
+  BX_DTYPE_OK(dtype);
+  BX_REQUIRE(x && y && n % 8 == 0, "bx_relu: n must be a multiple of 8");
+  const size_t n8 = n / 8;
+  const int grid = (int)(n8 / 256 + 1 > 2048 ? 2048 : n8 / 256 + 1);
+  BX_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((k_relu<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, n8));
+  BX_CHECK_LAUNCH("bx_relu");
+  return BX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void k_axpby(const float* __restrict__ x, float* __restrict__ y, size_t n, float alpha, float beta) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = beta == 0.f ? alpha * x[i] : alpha * x[i] + beta * y[i];
+}
+__global__ void k_mul(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) o[i] = a[i] * b[i];
+}
+__global__ void k_scale_dev(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ o, size_t n) {
+  const float k = s[0];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) o[i] = x[i] * k;
+}
+__global__ void k_abs(const float* __restrict__ x, float* __restrict__ o, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) o[i] = fabsf(x[i]);
+}
+static inline int ew_grid(size_t n);
+extern "C" int bx_abs(const float* x, float* out, size_t n, bxStream stream) {
+  BX_REQUIRE(x && out, "bx_abs: null pointer");
+  if (n == 0) return BX_OK;
+  hipLaunchKernelGGL(k_abs, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, out, n);
+  BX_CHECK_LAUNCH("bx_abs");
+  return BX_OK;
+}
+extern "C" int bx_scale_dev(const float* x, const float* scalar, float* out, size_t n, bxStream stream) {
+  BX_REQUIRE(x && scalar && out, "bx_scale_dev: null pointer");
+  if (n == 0) return BX_OK;
+  hipLaunchKernelGGL(k_scale_dev, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, scalar, out, n);
+  BX_CHECK_LAUNCH("bx_scale_dev");
+  return BX_OK;
+}
+static inline int ew_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g ? g : 1)); }
+extern "C" int bx_axpby(const float* x, float* y, size_t n, float alpha, float beta, bxStream stream) {
+  BX_REQUIRE(x && y, "bx_axpby: null pointer");
+  if (n == 0) return BX_OK;
+  hipLaunchKernelGGL(k_axpby, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, alpha, beta);
+  BX_CHECK_LAUNCH("bx_axpby");
+  return BX_OK;
+}
+extern "C" int bx_mul(const float* a, const float* b, float* out, size_t n, bxStream stream) {
+  BX_REQUIRE(a && b && out, "bx_mul: null pointer");
+  if (n == 0) return BX_OK;
+  hipLaunchKernelGGL(k_mul, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  BX_CHECK_LAUNCH("bx_mul");
+  return BX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// AdamW (decoupled weight decay), torch.optim.AdamW semantics:
+//   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+//   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                        size_t n, float lr, float b1, float b2, float eps, float wd, float gscale, const float* __restrict__ step) {
+  const float t = step[0];
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float gi = g[i] * gscale;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+__global__ void k_step_inc(float* t) { t[0] += 1.f; }
+extern "C" int bx_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, float grad_scale, float* step_count, bxStream stream) {
+  BX_REQUIRE(p && g && m && v && step_count, "bx_adamw_step: null pointer");
+  if (n == 0) return BX_OK;
+  hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step_count);
+  hipLaunchKernelGGL(k_adamw, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, grad_scale, step_count);
+  BX_CHECK_LAUNCH("bx_adamw_step");
+  return BX_OK;
+}
+
+__global__ void k_sumsq(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+  // single workgroup, fixed order -> deterministic
+  __shared__ float part[16];
+  float acc = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) acc += x[i] * x[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
+    out[0] = t;
+  }
+}
+extern "C" int bx_sumsq(const float* x, size_t n, float* out, bxStream stream) {
+  BX_REQUIRE(x && out, "bx_sumsq: null pointer");
+  hipLaunchKernelGGL(k_sumsq, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);
+  BX_CHECK_LAUNCH("bx_sumsq");
+  return BX_OK;
+}
+
+__global__ void k_seed_next(uint64_t* state, uint64_t* out) { const uint64_t v = state[0] + 1; state[0] = v; out[0] = v; }
+extern "C" int bx_seed_next(uint64_t* state, uint64_t* out, bxStream stream) {
+  BX_REQUIRE(state && out, "bx_seed_next: null pointer");
+  hipLaunchKernelGGL(k_seed_next, dim3(1), dim3(1), 0, (hipStream_t)stream, state, out);
+  BX_CHECK_LAUNCH("bx_seed_next");
+  return BX_OK;
+}

@@ -1,0 +1,591 @@
+// EEGNet feature extractor over raw EEG [B,1,Chans,T], forward and backward.
+// Replaces reference root/src/models/models.py:271-285 (EEGNet.forward up to Flatten) and its autograd
+// backward:  conv(1xK1,'same') -> BN1 -> depthwise(Chans x 1, D per filter) -> BN2 -> ELU -> avgpool(1xP1)
+//            -> dropout -> conv(1xK2,'same', F1*D -> F2) -> BN3 -> ELU -> avgpool(1xP2) -> dropout -> flatten
+// 'same' padding for an even kernel K: left (K-1)/2, right K/2 (31/32 for K=64, 7/8 for K=16).
+//
+// The only large tensor is the temporal-conv output c1 [B,F1,Chans,T] (stored in `dtype`); everything
+// after the depthwise electrode mix is [B,16,T] or smaller and stays fp32.  All batch reductions use
+// per-workgroup partials + a fixed-order finalize (deterministic).
+#include "bx_common.h"
+
+#define EEG_TT 256           // time steps per workgroup in the temporal conv
+#define EEG_MAXK 64
+#define EEG_MAXF 16          // F1*D and F2 upper bound
+#define EEG_MAXCH 64
+
+struct EegGeom {
+  int B, Ch, T, F1, D, FD, F2, K1, K2, P1, P2, T1, T2, padl1, padl2;
+  size_t off_c1, off_d, off_p1, off_s, off_stats, total;   // saved arena (bytes)
+};
+static int eeg_geom(const bxEegDesc* d, EegGeom* g) {
+  g->B = d->B; g->Ch = d->Chans; g->T = d->T; g->F1 = d->F1; g->D = d->D; g->FD = d->F1 * d->D; g->F2 = d->F2;
+  g->K1 = d->K1; g->K2 = d->K2; g->P1 = d->P1; g->P2 = d->P2;
+  if (d->B <= 0 || d->Chans <= 0 || d->T <= 0) return -1;
+  if (d->F1 != 8 || g->FD != 16 || d->F2 != 16) return -2;          // register-tiled for the EEGNet-8,2 family
+  if (d->K1 < 1 || d->K1 > EEG_MAXK || d->K2 != 16) return -3;
+  if (d->Chans > EEG_MAXCH || d->P1 < 1 || d->P2 < 1) return -4;
+  g->T1 = d->T / d->P1; g->T2 = g->T1 / d->P2;
+  if (g->T2 < 1) return -5;
+  g->padl1 = (d->K1 - 1) / 2; g->padl2 = (d->K2 - 1) / 2;
+  size_t o = 0;
+  g->off_c1 = o; o += bx_align_up((size_t)g->B * g->F1 * g->Ch * g->T * bx_esize(d->dtype), 256);
+  g->off_d = o;  o += bx_align_up((size_t)g->B * g->FD * g->T * 4, 256);
+  g->off_p1 = o; o += bx_align_up((size_t)g->B * g->FD * g->T1 * 4, 256);
+  g->off_s = o;  o += bx_align_up((size_t)g->B * g->F2 * g->T1 * 4, 256);
+  g->off_stats = o; o += bx_align_up((size_t)4 * (g->F1 + g->FD + g->F2) * 4, 256);
+  g->total = o;
+  return 0;
+}
+// stats block: [mean1 F1][invstd1 F1][scale1 F1][shift1 F1][mean2 FD]...[mean3 F2]...
+struct EegStats { float *mean1, *inv1, *sc1, *sh1, *mean2, *inv2, *sc2, *sh2, *mean3, *inv3, *sc3, *sh3; };
+static EegStats eeg_stats(const EegGeom& g, void* saved) {
+  float* p = (float*)((char*)saved + g.off_stats);
+  EegStats s;
+  s.mean1 = p; s.inv1 = p + g.F1; s.sc1 = p + 2 * g.F1; s.sh1 = p + 3 * g.F1; p += 4 * g.F1;
+  s.mean2 = p; s.inv2 = p + g.FD; s.sc2 = p + 2 * g.FD; s.sh2 = p + 3 * g.FD; p += 4 * g.FD;
+  s.mean3 = p; s.inv3 = p + g.F2; s.sc3 = p + 2 * g.F2; s.sh3 = p + 3 * g.F2;
+  return s;
+}
+extern "C" size_t bx_eeg_saved_bytes(const bxEegDesc* d) {
+  EegGeom g;
+  return (d && eeg_geom(d, &g) == 0) ? g.total : 0;
+}
+
+// workspace: forward needs BN partials only; backward needs gradient maps + partial buffers
+struct EegWs { size_t off_part, off_du3, off_dp1, off_du2, off_r, off_w1p, off_sepp, off_coef, total; int nblk_rows; };
+static EegWs eeg_ws(const EegGeom& g) {
+  EegWs w; size_t o = 0;
+  const int rows = g.B * g.Ch;
+  w.nblk_rows = rows * ((g.T + EEG_TT - 1) / EEG_TT);
+  size_t npart = (size_t)w.nblk_rows;
+  const size_t n_dw = (size_t)g.B * ((g.T + 255) / 256), n_sep = (size_t)g.B * ((g.T1 + 63) / 64);
+  if (npart < n_dw) npart = n_dw;
+  if (npart < n_sep) npart = n_sep;
+  if (npart < (size_t)g.B) npart = (size_t)g.B;
+  w.off_part = o; o += bx_align_up(npart * 2 * EEG_MAXF * 4, 256);
+  w.off_du3 = o; o += bx_align_up((size_t)g.B * g.F2 * g.T1 * 4, 256);
+  w.off_dp1 = o; o += bx_align_up((size_t)g.B * g.FD * g.T1 * 4, 256);
+  w.off_du2 = o; o += bx_align_up((size_t)g.B * g.FD * g.T * 4, 256);
+  w.off_r = o;   o += bx_align_up((size_t)g.B * (g.FD * g.Ch + g.FD) * 4, 256);
+  w.off_w1p = o; o += bx_align_up((size_t)rows * g.F1 * g.K1 * 4, 256);
+  w.off_sepp = o; o += bx_align_up((size_t)g.B * g.F2 * g.FD * g.K2 * 4, 256);
+  w.off_coef = o; o += bx_align_up((size_t)3 * 3 * EEG_MAXF * 4 + 256, 256);
+  w.total = o;
+  return w;
+}
+extern "C" size_t bx_eeg_workspace(const bxEegDesc* d) {
+  EegGeom g;
+  if (!d || eeg_geom(d, &g)) return 0;
+  return eeg_ws(g).total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// E1: temporal convolution, one workgroup per (row = sample*electrode, 256-step time block).
+template <typename T>
+__global__ __launch_bounds__(EEG_TT) void k_eeg_conv1(const float* __restrict__ x, const float* __restrict__ w1, T* __restrict__ c1,
+                                                      float* __restrict__ partials, EegGeom g, int want_stats) {
+  __shared__ float sx[EEG_TT + EEG_MAXK];
+  __shared__ float sw[8 * EEG_MAXK];
+  __shared__ float red[4][16];
+  const int nblk_t = (g.T + EEG_TT - 1) / EEG_TT;
+  const int row = blockIdx.x / nblk_t, tb = blockIdx.x % nblk_t;
+  const int b = row / g.Ch, ch = row % g.Ch;
+  const int t0 = tb * EEG_TT;
+  const float* xr = x + (size_t)row * g.T;
+  for (int i = threadIdx.x; i < EEG_TT + g.K1 - 1; i += EEG_TT) {
+    const int t = t0 + i - g.padl1;
+    sx[i] = (t >= 0 && t < g.T) ? xr[t] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 8 * g.K1; i += EEG_TT) sw[i] = w1[i];
+  __syncthreads();
+  const int t = t0 + threadIdx.x;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < g.K1; ++k) {
+    const float xv = sx[threadIdx.x + k];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) acc[f] = fmaf(sw[f * g.K1 + k], xv, acc[f]);
+  }
+  float s[8], q[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    float v = 0.f;
+    if (t < g.T) {
+      const size_t o = (((size_t)b * g.F1 + f) * g.Ch + ch) * g.T + t;
+      stf(c1, o, acc[f]);
+      v = ldf(c1, o);                       // statistics of the stored value
+    }
+    s[f] = v; q[f] = v * v;
+  }
+  if (!want_stats) return;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) { s[f] = wave_sum(s[f]); q[f] = wave_sum(q[f]); }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0)
+#pragma unroll
+    for (int f = 0; f < 8; ++f) { red[wave][f] = s[f]; red[wave][8 + f] = q[f]; }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    // layout [blk][2][F1]
+    partials[(size_t)blockIdx.x * 16 + threadIdx.x] = v;
+  }
+}
+
+// E2: BN1 apply + depthwise electrode mix; thread per (b, t) produces all FD maps.  grid (ceil(T/256), B)
+template <typename T>
+__global__ __launch_bounds__(256) void k_eeg_dw(const T* __restrict__ c1, const float* __restrict__ dw, const float* __restrict__ sc1,
+                                                 const float* __restrict__ sh1, float* __restrict__ dmap, float* __restrict__ partials,
+                                                 EegGeom g, int want_stats) {
+  __shared__ float sdw[EEG_MAXF * EEG_MAXCH];
+  __shared__ float red[4][32];
+  for (int i = threadIdx.x; i < g.FD * g.Ch; i += 256) sdw[i] = dw[i];
+  __syncthreads();
+  const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+  float out[EEG_MAXF];
+#pragma unroll
+  for (int i = 0; i < EEG_MAXF; ++i) out[i] = 0.f;
+  if (t < g.T) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      const float a = sc1[f], c = sh1[f];
+      float o0 = 0.f, o1 = 0.f;
+      for (int ch = 0; ch < g.Ch; ++ch) {
+        const float v = ldf(c1, (((size_t)b * g.F1 + f) * g.Ch + ch) * g.T + t) * a + c;
+        o0 = fmaf(sdw[(2 * f) * g.Ch + ch], v, o0);
+        o1 = fmaf(sdw[(2 * f + 1) * g.Ch + ch], v, o1);
+      }
+      out[2 * f] = o0; out[2 * f + 1] = o1;
+      dmap[((size_t)b * g.FD + 2 * f) * g.T + t] = o0;
+      dmap[((size_t)b * g.FD + 2 * f + 1) * g.T + t] = o1;
+    }
+  }
+  if (!want_stats) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < EEG_MAXF; ++i) {
+    const float s = wave_sum(out[i]), q = wave_sum(out[i] * out[i]);
+    if (lane == 0) { red[wave][i] = s; red[wave][16 + i] = q; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + threadIdx.x] = v;   // [blk][2][16]
+  }
+}
+
+__device__ __forceinline__ float elu1(float u) { return u > 0.f ? u : expm1f(u); }
+
+// E3/E5: BN apply + ELU + average pool (1xP, floor) + dropout.  in [B,F,Tin] -> out [B,F,Tout]
+__global__ void k_eeg_bn_elu_pool(const float* __restrict__ in, const float* __restrict__ sc, const float* __restrict__ sh,
+                                  float* __restrict__ out, int B, int F, int Tin, int Tout, int P, const uint64_t* __restrict__ seed,
+                                  float dropout_p, uint32_t salt) {
+  const long long n = (long long)B * F * Tout;
+  const uint64_t sd = (dropout_p > 0.f && seed) ? seed[0] : 0;
+  const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int to = (int)(i % Tout);
+    const long long bf = i / Tout;
+    const int f = (int)(bf % F);
+    const float a = sc[f], c = sh[f];
+    const float* src = in + bf * Tin + (size_t)to * P;
+    float s = 0.f;
+    for (int j = 0; j < P; ++j) s += elu1(src[j] * a + c);
+    s /= (float)P;
+    if (dropout_p > 0.f) s *= bx_dropout_scale(sd, salt, (uint64_t)i, dropout_p, inv_keep);
+    out[i] = s;
+  }
+}
+
+// E4: dense temporal conv FD -> F2 over K2 taps; thread per (b, t) -> 16 outputs. grid (ceil(T1/64), B), 64 threads
+__global__ __launch_bounds__(64) void k_eeg_sep(const float* __restrict__ p1, const float* __restrict__ ws, float* __restrict__ s,
+                                                 float* __restrict__ partials, EegGeom g, int want_stats) {
+  __shared__ float sp[EEG_MAXF][64 + 16];
+  __shared__ float sw[16 * 16 * 16];
+  const int b = blockIdx.y, t0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < g.F2 * g.FD * g.K2; i += 64) sw[i] = ws[i];
+  for (int i = threadIdx.x; i < g.FD * (64 + g.K2 - 1); i += 64) {
+    const int fd = i / (64 + g.K2 - 1), j = i % (64 + g.K2 - 1);
+    const int t = t0 + j - g.padl2;
+    sp[fd][j] = (t >= 0 && t < g.T1) ? p1[((size_t)b * g.FD + fd) * g.T1 + t] : 0.f;
+  }
+  __syncthreads();
+  const int t = t0 + threadIdx.x;
+  float acc[16];
+#pragma unroll
+  for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+  for (int fd = 0; fd < 16; ++fd)
+    for (int k = 0; k < 16; ++k) {
+      const float v = sp[fd][threadIdx.x + k];
+#pragma unroll
+      for (int o = 0; o < 16; ++o) acc[o] = fmaf(sw[(o * 16 + fd) * 16 + k], v, acc[o]);
+    }
+  const bool ok = t < g.T1;
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    if (ok) s[((size_t)b * g.F2 + o) * g.T1 + t] = acc[o];
+    else acc[o] = 0.f;
+  }
+  if (!want_stats) return;
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    const float su = wave_sum(acc[o]), q = wave_sum(acc[o] * acc[o]);
+    if (threadIdx.x == 0) {
+      partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + o] = su;
+      partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 16 + o] = q;
+    }
+  }
+}
+
+extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, const float* x, const uint64_t* seed,
+                                   float* feat, void* saved, void* workspace, size_t workspace_bytes, bxStream stream) {
+  BX_REQUIRE(d && p && x && feat && saved, "bx_eeg_features_fwd: null pointer");
+  BX_DTYPE_OK(d->dtype);
+  EegGeom g;
+  const int ge = eeg_geom(d, &g);
+  BX_REQUIRE(ge == 0, "bx_eeg_features_fwd: unsupported geometry (code %d): need F1=8, D=2, F2=16, K1<=64, K2=16, Chans<=64", ge);
+  const EegWs w = eeg_ws(g);
+  if (!workspace || workspace_bytes < w.total) BX_FAIL(BX_EWORKSPACE, "bx_eeg_features_fwd: workspace %zu < %zu", workspace_bytes, w.total);
+  BX_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "bx_eeg_features_fwd: dropout_p must be in [0,1)");
+  hipStream_t s = (hipStream_t)stream;
+  const EegStats st = eeg_stats(g, saved);
+  float* part = (float*)((char*)workspace + w.off_part);
+  void* c1 = (char*)saved + g.off_c1;
+  float* dmap = (float*)((char*)saved + g.off_d);
+  float* p1 = (float*)((char*)saved + g.off_p1);
+  float* smap = (float*)((char*)saved + g.off_s);
+  const int tr = d->training;
+  const float pdrop = tr ? d->dropout_p : 0.f;
+  BX_REQUIRE(pdrop == 0.f || seed, "bx_eeg_features_fwd: dropout needs a device seed");
+
+  BX_DISPATCH_DTYPE(d->dtype, T,
+    hipLaunchKernelGGL((k_eeg_conv1<T>), dim3(w.nblk_rows), dim3(EEG_TT), 0, s, x, p->conv1_w, (T*)c1, part, g, tr));
+  BX_CHECK_LAUNCH("eeg conv1");
+  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, s, part, w.nblk_rows, (double)g.B * g.Ch * g.T, g.F1, tr, p->bn1_w, p->bn1_b,
+                     p->bn1_rm, p->bn1_rv, p->bn1_nbt, d->momentum, d->eps, st.sc1, st.sh1, st.mean1, st.inv1);
+  BX_CHECK_LAUNCH("eeg bn1");
+  dim3 gdw(bx_ceil_div(g.T, 256), g.B);
+  BX_DISPATCH_DTYPE(d->dtype, T,
+    hipLaunchKernelGGL((k_eeg_dw<T>), gdw, dim3(256), 0, s, (const T*)c1, p->dw_w, st.sc1, st.sh1, dmap, part, g, tr));
+  BX_CHECK_LAUNCH("eeg depthwise");
+  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, s, part, (int)(gdw.x * gdw.y), (double)g.B * g.T, g.FD, tr, p->bn2_w, p->bn2_b,
+                     p->bn2_rm, p->bn2_rv, p->bn2_nbt, d->momentum, d->eps, st.sc2, st.sh2, st.mean2, st.inv2);
+  BX_CHECK_LAUNCH("eeg bn2");
+  {
+    const long long n = (long long)g.B * g.FD * g.T1;
+    hipLaunchKernelGGL(k_eeg_bn_elu_pool, dim3(bx_ceil_div(n, 256)), dim3(256), 0, s, dmap, st.sc2, st.sh2, p1, g.B, g.FD, g.T, g.T1, g.P1,
+                       seed, pdrop, d->salt);
+    BX_CHECK_LAUNCH("eeg pool1");
+  }
+  dim3 gsep(bx_ceil_div(g.T1, 64), g.B);
+  hipLaunchKernelGGL(k_eeg_sep, gsep, dim3(64), 0, s, p1, p->sep_w, smap, part, g, tr);
+  BX_CHECK_LAUNCH("eeg sepconv");
+  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, s, part, (int)(gsep.x * gsep.y), (double)g.B * g.T1, g.F2, tr, p->bn3_w, p->bn3_b,
+                     p->bn3_rm, p->bn3_rv, p->bn3_nbt, d->momentum, d->eps, st.sc3, st.sh3, st.mean3, st.inv3);
+  BX_CHECK_LAUNCH("eeg bn3");
+  {
+    const long long n = (long long)g.B * g.F2 * g.T2;
+    hipLaunchKernelGGL(k_eeg_bn_elu_pool, dim3(bx_ceil_div(n, 256)), dim3(256), 0, s, smap, st.sc3, st.sh3, feat, g.B, g.F2, g.T1, g.T2, g.P2,
+                       seed, pdrop, d->salt + 1);
+    BX_CHECK_LAUNCH("eeg pool2");
+  }
+  return BX_OK;
+}
+
+// ================================================================================================
+// backward
+// B-act: gradient through dropout/avg-pool/ELU up to the BN output, du = dL/d(bn_out); writes du and the
+// BN-backward partial sums  s1 = sum du,  s2 = sum du * xhat.  One workgroup per (b), 256 threads.
+__global__ __launch_bounds__(256) void k_eeg_act_bwd(const float* __restrict__ dpool, const float* __restrict__ pre, const float* __restrict__ mean,
+    const float* __restrict__ inv, const float* __restrict__ sc, const float* __restrict__ sh, float* __restrict__ du,
+    float* __restrict__ partials, int F, int Tin, int Tout, int P, const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt) {
+  __shared__ float red[4][32];
+  const int b = blockIdx.x;
+  const uint64_t sd = (dropout_p > 0.f && seed) ? seed[0] : 0;
+  const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int f = 0; f < F; ++f) {
+    float s1 = 0.f, s2 = 0.f;
+    const float a = sc[f], c = sh[f], mu = mean[f], is = inv[f];
+    for (int t = threadIdx.x; t < Tin; t += 256) {
+      const size_t i = ((size_t)b * F + f) * Tin + t;
+      float g_ = 0.f;
+      const int to = t / P;
+      if (to < Tout) {
+        const size_t io = ((size_t)b * F + f) * Tout + to;
+        float go = dpool[io] / (float)P;
+        if (dropout_p > 0.f) go *= bx_dropout_scale(sd, salt, (uint64_t)io, dropout_p, inv_keep);
+        const float v = pre[i];
+        const float u = v * a + c;
+        g_ = u > 0.f ? go : go * expf(u);
+        s2 += g_ * (v - mu) * is;
+      }
+      du[i] = g_;
+      s1 += g_;
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { red[wave][f] = s1; red[wave][16 + f] = s2; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) partials[(size_t)b * 32 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+// finalize: dgamma, dbeta, coefficients a = gamma*invstd, k1 = s1/N, k2 = s2/N (zero in eval mode)
+__global__ void k_eeg_bn_bwd_finalize(const float* __restrict__ partials, int nblk, double count, int F, int training,
+                                      const float* __restrict__ gamma, const float* __restrict__ inv, float* __restrict__ coef,
+                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int f = threadIdx.x;
+  if (f >= F) return;
+  double s1 = 0, s2 = 0;
+  for (int k = 0; k < nblk; ++k) { s1 += partials[(size_t)k * 32 + f]; s2 += partials[(size_t)k * 32 + 16 + f]; }
+  if (dbeta) dbeta[f] = (float)s1;
+  if (dgamma) dgamma[f] = (float)s2;
+  coef[f] = gamma[f] * inv[f];
+  coef[EEG_MAXF + f] = training ? (float)(s1 / count) : 0.f;
+  coef[2 * EEG_MAXF + f] = training ? (float)(s2 / count) : 0.f;
+}
+// in place: du -> dpre = a * (du - k1 - xhat * k2)
+__global__ void k_eeg_bn_bwd_apply(float* __restrict__ du, const float* __restrict__ pre, const float* __restrict__ mean,
+                                   const float* __restrict__ inv, const float* __restrict__ coef, int F, int Tin, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int f = (int)((i / Tin) % F);
+    du[i] = coef[f] * (du[i] - coef[EEG_MAXF + f] - (pre[i] - mean[f]) * inv[f] * coef[2 * EEG_MAXF + f]);
+  }
+}
+
+// sepconv backward: one workgroup per sample; LDS holds ds[16][T1] and p1[16][T1+15]
+// (a) dp1[fd][t] = sum_{o,k} ws[o][fd][k] ds[o][t-k+padl]   (b) partial dws[o][fd][k] = sum_t ds[o][t] p1[fd][t+k-padl]
+__global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ ds, const float* __restrict__ p1, const float* __restrict__ ws,
+                                                      float* __restrict__ dp1, float* __restrict__ wpart, EegGeom g) {
+  extern __shared__ float sm[];
+  const int T1 = g.T1, TP = T1 + 16;
+  float* sds = sm;                 // [16][TP] with padl2.. zero halo on both sides: index t + 8
+  float* sp1 = sm + 16 * TP;       // [16][TP]
+  float* sw = sp1 + 16 * TP;       // [16*16*16]
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < 16 * TP; i += 256) {
+    const int f = i / TP, j = i % TP, t = j - 8;
+    const bool in = t >= 0 && t < T1;
+    sds[i] = in ? ds[((size_t)b * 16 + f) * T1 + t] : 0.f;
+    sp1[i] = in ? p1[((size_t)b * 16 + f) * T1 + t] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 4096; i += 256) sw[i] = ws[i];
+  __syncthreads();
+  // (a)
+  for (int i = threadIdx.x; i < 16 * T1; i += 256) {
+    const int fd = i / T1, t = i % T1;
+    float acc = 0.f;
+    for (int o = 0; o < 16; ++o)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc = fmaf(sw[(o * 16 + fd) * 16 + k], sds[o * TP + (t - k + g.padl2) + 8], acc);
+    dp1[((size_t)b * 16 + fd) * T1 + t] = acc;
+  }
+  // (b)
+  for (int i = threadIdx.x; i < 4096; i += 256) {
+    const int k = i & 15, fd = (i >> 4) & 15, o = i >> 8;
+    float acc = 0.f;
+    for (int t = 0; t < T1; ++t) acc = fmaf(sds[o * TP + t + 8], sp1[fd * TP + (t + k - g.padl2) + 8], acc);
+    wpart[(size_t)b * 4096 + i] = acc;
+  }
+}
+__global__ void k_sum_partials(const float* __restrict__ part, float* __restrict__ out, int nchunk, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunk; ++k) s += part[(size_t)k * n + i];
+  out[i] = s;
+}
+
+// depthwise backward pass A: per sample  R[fd][ch] = sum_t dd[fd][t] * c1[f][ch][t],  Sd[fd] = sum_t dd[fd][t]
+template <typename T>
+__global__ __launch_bounds__(256) void k_eeg_dw_bwd_a(const T* __restrict__ c1, const float* __restrict__ dd, float* __restrict__ rpart, EegGeom g) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nout = g.FD * g.Ch + g.FD;
+  for (int o = 0; o < nout; ++o) {
+    float acc = 0.f;
+    if (o < g.FD * g.Ch) {
+      const int fd = o / g.Ch, ch = o % g.Ch, f = fd / g.D;
+      const float* dr = dd + ((size_t)b * g.FD + fd) * g.T;
+      const size_t cb = (((size_t)b * g.F1 + f) * g.Ch + ch) * g.T;
+      for (int t = threadIdx.x; t < g.T; t += 256) acc = fmaf(dr[t], ldf(c1, cb + t), acc);
+    } else {
+      const float* dr = dd + ((size_t)b * g.FD + (o - g.FD * g.Ch)) * g.T;
+      for (int t = threadIdx.x; t < g.T; t += 256) acc += dr[t];
+    }
+    acc = wave_sum(acc);
+    __syncthreads();
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) rpart[(size_t)b * nout + o] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+// finalize of pass A: ddw, dgamma1, dbeta1 and the BN1-backward coefficients
+__global__ void k_eeg_dw_bwd_finalize(const float* __restrict__ rpart, int B, EegGeom g, int training, const float* __restrict__ dw,
+                                      const float* __restrict__ gamma1, const float* __restrict__ mean1, const float* __restrict__ inv1,
+                                      const float* __restrict__ sc1, const float* __restrict__ sh1, float* __restrict__ ddw,
+                                      float* __restrict__ dgamma1, float* __restrict__ dbeta1, float* __restrict__ coef) {
+  __shared__ double R[EEG_MAXF * EEG_MAXCH + EEG_MAXF];
+  const int nout = g.FD * g.Ch + g.FD;
+  for (int o = threadIdx.x; o < nout; o += blockDim.x) {
+    double s = 0;
+    for (int b = 0; b < B; ++b) s += rpart[(size_t)b * nout + o];
+    R[o] = s;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < g.FD * g.Ch; o += blockDim.x) {
+    const int fd = o / g.Ch, f = fd / g.D;
+    if (ddw) ddw[o] = (float)(sc1[f] * R[o] + sh1[f] * R[g.FD * g.Ch + fd]);
+  }
+  if ((int)threadIdx.x < g.F1) {
+    const int f = threadIdx.x;
+    double db = 0, dg = 0;
+    for (int dd = 0; dd < g.D; ++dd) {
+      const int fd = f * g.D + dd;
+      for (int ch = 0; ch < g.Ch; ++ch) {
+        const double w = dw[fd * g.Ch + ch];
+        db += w * R[g.FD * g.Ch + fd];
+        dg += w * (R[fd * g.Ch + ch] - (double)mean1[f] * R[g.FD * g.Ch + fd]);
+      }
+    }
+    dg *= inv1[f];
+    if (dbeta1) dbeta1[f] = (float)db;
+    if (dgamma1) dgamma1[f] = (float)dg;
+    const double N = (double)g.B * g.Ch * g.T;
+    coef[f] = gamma1[f] * inv1[f];
+    coef[EEG_MAXF + f] = training ? (float)(db / N) : 0.f;
+    coef[2 * EEG_MAXF + f] = training ? (float)(dg / N) : 0.f;
+  }
+}
+// pass B: per (sample, electrode) row rebuild dc1[f][t] in LDS, then the temporal-conv weight gradient
+// partial dW1[f][k] = sum_t dc1[f][t] x[t+k-padl] and (optionally) dx[t] = sum_{f,k} w1[f][k] dc1[f][t-k+padl].
+template <typename T>
+__global__ __launch_bounds__(256) void k_eeg_conv1_bwd(const T* __restrict__ c1, const float* __restrict__ dd, const float* __restrict__ x,
+    const float* __restrict__ dw, const float* __restrict__ w1, const float* __restrict__ mean1, const float* __restrict__ inv1,
+    const float* __restrict__ coef, float* __restrict__ w1part, float* __restrict__ dx, EegGeom g) {
+  extern __shared__ float sm[];
+  const int Tn = g.T, TX = Tn + 2 * EEG_MAXK;
+  float* sdc = sm;                 // [8][TX]  dc1 with zero halo, index t + 64
+  float* sxr = sm + 8 * TX;        // [TX]     x row with zero halo, index t + 64
+  float* sw = sxr + TX;            // [8*K1]
+  const int row = blockIdx.x, b = row / g.Ch, ch = row % g.Ch;
+  for (int i = threadIdx.x; i < 8 * TX; i += 256) sdc[i] = 0.f;
+  for (int i = threadIdx.x; i < TX; i += 256) { const int t = i - EEG_MAXK; sxr[i] = (t >= 0 && t < Tn) ? x[(size_t)row * Tn + t] : 0.f; }
+  for (int i = threadIdx.x; i < 8 * g.K1; i += 256) sw[i] = w1[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 8 * Tn; i += 256) {
+    const int f = i / Tn, t = i % Tn;
+    float dbn = 0.f;
+    for (int q = 0; q < g.D; ++q) dbn = fmaf(dw[(f * g.D + q) * g.Ch + ch], dd[((size_t)b * g.FD + f * g.D + q) * Tn + t], dbn);
+    const float xh = (ldf(c1, (((size_t)b * g.F1 + f) * g.Ch + ch) * Tn + t) - mean1[f]) * inv1[f];
+    sdc[f * TX + t + EEG_MAXK] = coef[f] * (dbn - coef[EEG_MAXF + f] - xh * coef[2 * EEG_MAXF + f]);
+  }
+  __syncthreads();
+  if (w1part)
+    for (int o = threadIdx.x; o < 8 * g.K1; o += 256) {
+      const int f = o / g.K1, k = o % g.K1;
+      const float* dc = sdc + f * TX + EEG_MAXK;
+      const float* xr = sxr + EEG_MAXK + k - g.padl1;
+      float acc = 0.f;
+      for (int t = 0; t < Tn; ++t) acc = fmaf(dc[t], xr[t], acc);
+      w1part[(size_t)row * 8 * g.K1 + o] = acc;
+    }
+  if (dx)
+    for (int t = threadIdx.x; t < Tn; t += 256) {
+      float acc = 0.f;
+      for (int f = 0; f < 8; ++f)
+        for (int k = 0; k < g.K1; ++k) acc = fmaf(sw[f * g.K1 + k], sdc[f * TX + EEG_MAXK + t - k + g.padl1], acc);
+      dx[(size_t)row * Tn + t] = acc;
+    }
+}
+
+extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, const float* x, const float* dfeat,
+                                   const uint64_t* seed, const void* saved, const bxEegGrads* gr, float* dx,
+                                   void* workspace, size_t workspace_bytes, bxStream stream) {
+  BX_REQUIRE(d && p && x && dfeat && saved, "bx_eeg_features_bwd: null pointer");
+  BX_DTYPE_OK(d->dtype);
+  EegGeom g;
+  const int ge = eeg_geom(d, &g);
+  BX_REQUIRE(ge == 0, "bx_eeg_features_bwd: unsupported geometry (code %d)", ge);
+  const EegWs w = eeg_ws(g);
+  if (!workspace || workspace_bytes < w.total) BX_FAIL(BX_EWORKSPACE, "bx_eeg_features_bwd: workspace %zu < %zu", workspace_bytes, w.total);
+  hipStream_t s = (hipStream_t)stream;
+  const EegStats st = eeg_stats(g, (void*)saved);
+  const void* c1 = (const char*)saved + g.off_c1;
+  const float* dmap = (const float*)((const char*)saved + g.off_d);
+  const float* p1 = (const float*)((const char*)saved + g.off_p1);
+  const float* smap = (const float*)((const char*)saved + g.off_s);
+  char* W = (char*)workspace;
+  float* part = (float*)(W + w.off_part);
+  float* du3 = (float*)(W + w.off_du3);
+  float* dp1 = (float*)(W + w.off_dp1);
+  float* du2 = (float*)(W + w.off_du2);
+  float* rpart = (float*)(W + w.off_r);
+  float* w1part = (float*)(W + w.off_w1p);
+  float* sepp = (float*)(W + w.off_sepp);
+  float* coef3 = (float*)(W + w.off_coef);
+  float* coef2 = coef3 + 3 * EEG_MAXF;
+  float* coef1 = coef2 + 3 * EEG_MAXF;
+  const int tr = d->training;
+  const float pdrop = tr ? d->dropout_p : 0.f;
+  bxEegGrads none = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (!gr) gr = &none;
+
+  // pool2/dropout/ELU/BN3
+  hipLaunchKernelGGL(k_eeg_act_bwd, dim3(g.B), dim3(256), 0, s, dfeat, smap, st.mean3, st.inv3, st.sc3, st.sh3, du3, part, g.F2, g.T1, g.T2, g.P2,
+                     seed, pdrop, d->salt + 1);
+  BX_CHECK_LAUNCH("eeg act3 bwd");
+  hipLaunchKernelGGL(k_eeg_bn_bwd_finalize, dim3(1), dim3(64), 0, s, part, g.B, (double)g.B * g.T1, g.F2, tr, p->bn3_w, st.inv3, coef3, gr->bn3_w, gr->bn3_b);
+  BX_CHECK_LAUNCH("eeg bn3 bwd finalize");
+  {
+    const long long n = (long long)g.B * g.F2 * g.T1;
+    hipLaunchKernelGGL(k_eeg_bn_bwd_apply, dim3(bx_ceil_div(n, 256)), dim3(256), 0, s, du3, smap, st.mean3, st.inv3, coef3, g.F2, g.T1, n);
+    BX_CHECK_LAUNCH("eeg bn3 bwd apply");
+  }
+  // separable conv
+  {
+    const size_t lds = ((size_t)2 * 16 * (g.T1 + 16) + 4096) * sizeof(float);
+    BX_REQUIRE(lds <= 160 * 1024, "bx_eeg_features_bwd: T/P1 too long for the LDS tile (%zu bytes)", lds);
+    if (hipFuncSetAttribute((const void*)k_eeg_sep_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      BX_FAIL(BX_EHIP, "bx_eeg_features_bwd: cannot reserve %zu bytes of LDS", lds);
+    hipLaunchKernelGGL(k_eeg_sep_bwd, dim3(g.B), dim3(256), lds, s, du3, p1, p->sep_w, dp1, sepp, g);
+    BX_CHECK_LAUNCH("eeg sep bwd");
+    if (gr->sep_w) {
+      hipLaunchKernelGGL(k_sum_partials, dim3(16), dim3(256), 0, s, sepp, gr->sep_w, g.B, 4096);
+      BX_CHECK_LAUNCH("eeg sep wgrad reduce");
+    }
+  }
+  // pool1/dropout/ELU/BN2
+  hipLaunchKernelGGL(k_eeg_act_bwd, dim3(g.B), dim3(256), 0, s, dp1, dmap, st.mean2, st.inv2, st.sc2, st.sh2, du2, part, g.FD, g.T, g.T1, g.P1,
+                     seed, pdrop, d->salt);
+  BX_CHECK_LAUNCH("eeg act2 bwd");
+  hipLaunchKernelGGL(k_eeg_bn_bwd_finalize, dim3(1), dim3(64), 0, s, part, g.B, (double)g.B * g.T, g.FD, tr, p->bn2_w, st.inv2, coef2, gr->bn2_w, gr->bn2_b);
+  BX_CHECK_LAUNCH("eeg bn2 bwd finalize");
+  {
+    const long long n = (long long)g.B * g.FD * g.T;
+    hipLaunchKernelGGL(k_eeg_bn_bwd_apply, dim3(bx_ceil_div(n, 256) > 4096 ? 4096 : bx_ceil_div(n, 256)), dim3(256), 0, s, du2, dmap, st.mean2, st.inv2,
+                       coef2, g.FD, g.T, n);
+    BX_CHECK_LAUNCH("eeg bn2 bwd apply");
+  }
+  // depthwise + BN1
+  BX_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((k_eeg_dw_bwd_a<T>), dim3(g.B), dim3(256), 0, s, (const T*)c1, du2, rpart, g));
+  BX_CHECK_LAUNCH("eeg dw bwd A");
+  hipLaunchKernelGGL(k_eeg_dw_bwd_finalize, dim3(1), dim3(256), 0, s, rpart, g.B, g, tr, p->dw_w, p->bn1_w, st.mean1, st.inv1, st.sc1, st.sh1,
+                     gr->dw_w, gr->bn1_w, gr->bn1_b, coef1);
+  BX_CHECK_LAUNCH("eeg dw bwd finalize");
+  if (gr->conv1_w || dx) {
+    const size_t lds = ((size_t)9 * (g.T + 2 * EEG_MAXK) + 8 * g.K1) * sizeof(float);
+    BX_REQUIRE(lds <= 160 * 1024, "bx_eeg_features_bwd: T too long for the LDS tile (%zu bytes)", lds);
+    BX_DISPATCH_DTYPE(d->dtype, T,
+      if (hipFuncSetAttribute((const void*)k_eeg_conv1_bwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        BX_FAIL(BX_EHIP, "bx_eeg_features_bwd: cannot reserve %zu bytes of LDS", lds);
+      hipLaunchKernelGGL((k_eeg_conv1_bwd<T>), dim3(g.B * g.Ch), dim3(256), lds, s, (const T*)c1, du2, x, p->dw_w, p->conv1_w, st.mean1, st.inv1,
+                         coef1, gr->conv1_w ? w1part : (float*)nullptr, dx, g));
+    BX_CHECK_LAUNCH("eeg conv1 bwd");
+    if (gr->conv1_w) {
+      hipLaunchKernelGGL(k_sum_partials, dim3(bx_ceil_div(8 * g.K1, 256)), dim3(256), 0, s, w1part, gr->conv1_w, g.B * g.Ch, 8 * g.K1);
+      BX_CHECK_LAUNCH("eeg conv1 wgrad reduce");
+    }
+  }
+  return BX_OK;
+}

@@ -1,0 +1,270 @@
+// Classifier heads, fusion head and KL-divergence loss, forward and backward.  All fp32 except the
+// channels-last feature map fed to / produced by the global-average-pool.
+//   GAP -> Linear(256,6) -> LogSoftmax   reference root/src/models/models.py:92-94,103-106
+//   Linear(F2*T/32, 6) -> LogSoftmax     reference root/src/models/models.py:263-269,286-288
+//   cat -> Linear(12,128) -> ReLU -> Linear(128,6) -> LogSoftmax   XAI_Multimodality.py:1095-1105
+//   nn.KLDivLoss()                        XAI_Multimodality.py:1989,1599
+// Parameter gradients are summed over the batch in a fixed order (deterministic).
+#include "bx_common.h"
+
+#define HEAD_MAX_N 32
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gap(const T* __restrict__ feat, float* __restrict__ gap, int HW, int C) {
+  const int b = blockIdx.x;
+  const float inv = 1.f / (float)HW;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += ldf(feat, ((size_t)b * HW + p) * C + c);
+    gap[(size_t)b * C + c] = s * inv;
+  }
+}
+
+// one workgroup (256 threads = 4 waves) per sample
+__global__ __launch_bounds__(256) void k_linear_lsm_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ logp, int K, int N) {
+  __shared__ float logit[HEAD_MAX_N];
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int n = wave; n < N; n += 4) {
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s = fmaf(w[(size_t)n * K + k], x[(size_t)b * K + k], s);
+    s = wave_sum(s);
+    if (lane == 0) logit[n] = s + bias[n];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = -INFINITY;
+    for (int n = 0; n < N; ++n) m = fmaxf(m, logit[n]);
+    float se = 0.f;
+    for (int n = 0; n < N; ++n) se += expf(logit[n] - m);
+    const float lse = m + logf(se);
+    for (int n = 0; n < N; ++n) logp[(size_t)b * N + n] = logit[n] - lse;
+  }
+}
+
+// dlogit = dlogp - softmax * sum(dlogp)
+__device__ __forceinline__ void lsm_bwd_row(const float* dlogp, const float* logp, int N, float* dlogit) {
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += dlogp[n];
+  for (int n = 0; n < N; ++n) dlogit[n] = dlogp[n] - expf(logp[n]) * s;
+}
+
+// input gradient: dx[b][k] = sum_n dlogit[b][n] W[n][k]; GAP variant broadcasts dx/HW over the pixels
+template <typename T, bool GAP>
+__global__ __launch_bounds__(256) void k_linear_lsm_bwd_dx(const float* __restrict__ dlogp, const float* __restrict__ logp,
+    const float* __restrict__ w, float* __restrict__ dx, T* __restrict__ dfeat, int K, int N, int HW) {
+  const int b = blockIdx.x;
+  float dl[HEAD_MAX_N];
+  lsm_bwd_row(dlogp + (size_t)b * N, logp + (size_t)b * N, N, dl);
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s = fmaf(dl[n], w[(size_t)n * K + k], s);
+    if (GAP) {
+      s /= (float)HW;
+      for (int p = 0; p < HW; ++p) stf(dfeat, ((size_t)b * HW + p) * K + k, s);
+    } else {
+      dx[(size_t)b * K + k] = s;
+    }
+  }
+}
+// parameter gradients: thread per (n,k); loops the batch in order
+__global__ __launch_bounds__(256) void k_linear_lsm_bwd_w(const float* __restrict__ dlogp, const float* __restrict__ logp,
+    const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int B, int K, int N) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * K + N) return;
+  const bool is_bias = idx >= N * K;
+  const int n = is_bias ? idx - N * K : idx / K, k = is_bias ? 0 : idx % K;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float s = 0.f;
+    for (int j = 0; j < N; ++j) s += dlogp[(size_t)b * N + j];
+    const float dl = dlogp[(size_t)b * N + n] - expf(logp[(size_t)b * N + n]) * s;
+    acc += is_bias ? dl : dl * x[(size_t)b * K + k];
+  }
+  if (is_bias) { if (db) db[n] = acc; }
+  else if (dw) dw[idx] = acc;
+}
+
+extern "C" int bx_linear_lsm_fwd(const float* x, const float* w, const float* b, float* logp, int B, int K, int N, bxStream stream) {
+  BX_REQUIRE(x && w && b && logp && B > 0 && K > 0 && N > 0 && N <= HEAD_MAX_N, "bx_linear_lsm_fwd: bad arguments (N<=%d)", HEAD_MAX_N);
+  hipLaunchKernelGGL(k_linear_lsm_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, x, w, b, logp, K, N);
+  BX_CHECK_LAUNCH("bx_linear_lsm_fwd");
+  return BX_OK;
+}
+extern "C" int bx_linear_lsm_bwd(const float* dlogp, const float* logp, const float* x, const float* w, float* dx,
+                                 float* dw, float* db, int B, int K, int N, bxStream stream) {
+  BX_REQUIRE(dlogp && logp && x && w && B > 0 && K > 0 && N > 0 && N <= HEAD_MAX_N, "bx_linear_lsm_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (dx) {
+    hipLaunchKernelGGL((k_linear_lsm_bwd_dx<float, false>), dim3(B), dim3(256), 0, s, dlogp, logp, w, dx, (float*)nullptr, K, N, 1);
+    BX_CHECK_LAUNCH("bx_linear_lsm_bwd(dx)");
+  }
+  if (dw || db) {
+    hipLaunchKernelGGL(k_linear_lsm_bwd_w, dim3(bx_ceil_div(N * K + N, 256)), dim3(256), 0, s, dlogp, logp, x, dw, db, B, K, N);
+    BX_CHECK_LAUNCH("bx_linear_lsm_bwd(w)");
+  }
+  return BX_OK;
+}
+
+extern "C" int bx_gap_fc_lsm_fwd(const void* feat, const float* w, const float* b, float* gap_out, float* logp,
+                                 int B, int HW, int C, int N, int dtype, bxStream stream) {
+  BX_DTYPE_OK(dtype);
+  BX_REQUIRE(feat && w && b && gap_out && logp && B > 0 && HW > 0 && C > 0 && N > 0 && N <= HEAD_MAX_N, "bx_gap_fc_lsm_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  BX_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((k_gap<T>), dim3(B), dim3(256), 0, s, (const T*)feat, gap_out, HW, C));
+  BX_CHECK_LAUNCH("bx_gap_fc_lsm_fwd(gap)");
+  hipLaunchKernelGGL(k_linear_lsm_fwd, dim3(B), dim3(256), 0, s, gap_out, w, b, logp, C, N);
+  BX_CHECK_LAUNCH("bx_gap_fc_lsm_fwd(fc)");
+  return BX_OK;
+}
+extern "C" int bx_gap_fc_lsm_bwd(const float* dlogp, const float* logp, const float* gap_out, const float* w,
+                                 void* dfeat, float* dw, float* db, int B, int HW, int C, int N, int dtype, bxStream stream) {
+  BX_DTYPE_OK(dtype);
+  BX_REQUIRE(dlogp && logp && gap_out && w && B > 0 && HW > 0 && C > 0 && N > 0 && N <= HEAD_MAX_N, "bx_gap_fc_lsm_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (dfeat) {
+    BX_DISPATCH_DTYPE(dtype, T,
+      hipLaunchKernelGGL((k_linear_lsm_bwd_dx<T, true>), dim3(B), dim3(256), 0, s, dlogp, logp, w, (float*)nullptr, (T*)dfeat, C, N, HW));
+    BX_CHECK_LAUNCH("bx_gap_fc_lsm_bwd(dfeat)");
+  }
+  if (dw || db) {
+    hipLaunchKernelGGL(k_linear_lsm_bwd_w, dim3(bx_ceil_div(N * C + N, 256)), dim3(256), 0, s, dlogp, logp, gap_out, dw, db, B, C, N);
+    BX_CHECK_LAUNCH("bx_gap_fc_lsm_bwd(w)");
+  }
+  return BX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fusion head: one workgroup per sample, one thread per hidden unit
+__global__ void k_fusion_fwd(const float* __restrict__ e, const float* __restrict__ sp, const float* __restrict__ w1,
+                             const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                             float* __restrict__ hidden, float* __restrict__ logp, int N, int Hd) {
+  extern __shared__ float sm[];  // z[2N] | h[Hd] | logit[N]
+  float* z = sm; float* h = sm + 2 * N; float* logit = h + Hd;
+  const int b = blockIdx.x, j = threadIdx.x;
+  if (j < N) { z[j] = e[(size_t)b * N + j]; z[N + j] = sp[(size_t)b * N + j]; }
+  __syncthreads();
+  if (j < Hd) {
+    float s = b1[j];
+    for (int i = 0; i < 2 * N; ++i) s = fmaf(w1[(size_t)j * 2 * N + i], z[i], s);
+    s = fmaxf(s, 0.f);
+    h[j] = s;
+    hidden[(size_t)b * Hd + j] = s;
+  }
+  __syncthreads();
+  if (j < N) {
+    float s = b2[j];
+    for (int k = 0; k < Hd; ++k) s = fmaf(w2[(size_t)j * Hd + k], h[k], s);
+    logit[j] = s;
+  }
+  __syncthreads();
+  if (j == 0) {
+    float m = -INFINITY;
+    for (int n = 0; n < N; ++n) m = fmaxf(m, logit[n]);
+    float se = 0.f;
+    for (int n = 0; n < N; ++n) se += expf(logit[n] - m);
+    const float lse = m + logf(se);
+    for (int n = 0; n < N; ++n) logp[(size_t)b * N + n] = logit[n] - lse;
+  }
+}
+// gradient w.r.t. the two branch outputs
+__global__ void k_fusion_bwd_in(const float* __restrict__ dlogp, const float* __restrict__ logp, const float* __restrict__ hidden,
+                                const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ de,
+                                float* __restrict__ dsp, int N, int Hd) {
+  extern __shared__ float sm[];  // dh[Hd]
+  const int b = blockIdx.x, j = threadIdx.x;
+  float dl[HEAD_MAX_N];
+  lsm_bwd_row(dlogp + (size_t)b * N, logp + (size_t)b * N, N, dl);
+  if (j < Hd) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s = fmaf(dl[n], w2[(size_t)n * Hd + j], s);
+    sm[j] = hidden[(size_t)b * Hd + j] > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  if (j < 2 * N) {
+    float s = 0.f;
+    for (int k = 0; k < Hd; ++k) s = fmaf(sm[k], w1[(size_t)k * 2 * N + j], s);
+    if (j < N) { if (de) de[(size_t)b * N + j] = s; }
+    else if (dsp) dsp[(size_t)b * N + (j - N)] = s;
+  }
+}
+// parameter gradients: one thread per hidden unit, batch looped in order
+__global__ void k_fusion_bwd_w(const float* __restrict__ dlogp, const float* __restrict__ logp, const float* __restrict__ hidden,
+                               const float* __restrict__ e, const float* __restrict__ sp, const float* __restrict__ w2,
+                               float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
+                               int B, int N, int Hd) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Hd) return;
+  float a1[2 * HEAD_MAX_N], a2[HEAD_MAX_N], ab2[HEAD_MAX_N], ab1 = 0.f;
+  for (int i = 0; i < 2 * N; ++i) a1[i] = 0.f;
+  for (int n = 0; n < N; ++n) a2[n] = ab2[n] = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float dl[HEAD_MAX_N];
+    lsm_bwd_row(dlogp + (size_t)b * N, logp + (size_t)b * N, N, dl);
+    const float hj = hidden[(size_t)b * Hd + j];
+    float dh = 0.f;
+    for (int n = 0; n < N; ++n) { dh = fmaf(dl[n], w2[(size_t)n * Hd + j], dh); a2[n] = fmaf(dl[n], hj, a2[n]); ab2[n] += dl[n]; }
+    dh = hj > 0.f ? dh : 0.f;
+    ab1 += dh;
+    for (int i = 0; i < N; ++i) { a1[i] = fmaf(dh, e[(size_t)b * N + i], a1[i]); a1[N + i] = fmaf(dh, sp[(size_t)b * N + i], a1[N + i]); }
+  }
+  if (dw1) for (int i = 0; i < 2 * N; ++i) dw1[(size_t)j * 2 * N + i] = a1[i];
+  if (db1) db1[j] = ab1;
+  if (dw2) for (int n = 0; n < N; ++n) dw2[(size_t)n * Hd + j] = a2[n];
+  if (db2 && j == 0) for (int n = 0; n < N; ++n) db2[n] = ab2[n];
+}
+
+extern "C" int bx_fusion_head_fwd(const float* eeg_logp, const float* spec_logp, const float* w1, const float* b1,
+                                  const float* w2, const float* b2, float* hidden, float* logp, int B, int N, int Hd, bxStream stream) {
+  BX_REQUIRE(eeg_logp && spec_logp && w1 && b1 && w2 && b2 && hidden && logp, "bx_fusion_head_fwd: null pointer");
+  BX_REQUIRE(B > 0 && N > 0 && N <= HEAD_MAX_N && Hd >= 2 * N && Hd <= 1024, "bx_fusion_head_fwd: need N<=%d, 2N<=Hd<=1024", HEAD_MAX_N);
+  const int threads = (Hd + 63) / 64 * 64;
+  hipLaunchKernelGGL(k_fusion_fwd, dim3(B), dim3(threads), (3 * N + Hd) * sizeof(float), (hipStream_t)stream,
+                     eeg_logp, spec_logp, w1, b1, w2, b2, hidden, logp, N, Hd);
+  BX_CHECK_LAUNCH("bx_fusion_head_fwd");
+  return BX_OK;
+}
+extern "C" int bx_fusion_head_bwd(const float* dlogp, const float* logp, const float* hidden, const float* eeg_logp,
+                                  const float* spec_logp, const float* w1, const float* w2, float* d_eeg_logp,
+                                  float* d_spec_logp, float* dw1, float* db1, float* dw2, float* db2, int B, int N, int Hd,
+                                  bxStream stream) {
+  BX_REQUIRE(dlogp && logp && hidden && eeg_logp && spec_logp && w1 && w2, "bx_fusion_head_bwd: null pointer");
+  BX_REQUIRE(B > 0 && N > 0 && N <= HEAD_MAX_N && Hd >= 2 * N && Hd <= 1024, "bx_fusion_head_bwd: bad dims");
+  hipStream_t s = (hipStream_t)stream;
+  const int threads = (Hd + 63) / 64 * 64;
+  if (d_eeg_logp || d_spec_logp) {
+    hipLaunchKernelGGL(k_fusion_bwd_in, dim3(B), dim3(threads), Hd * sizeof(float), s, dlogp, logp, hidden, w1, w2, d_eeg_logp, d_spec_logp, N, Hd);
+    BX_CHECK_LAUNCH("bx_fusion_head_bwd(in)");
+  }
+  if (dw1 || db1 || dw2 || db2) {
+    hipLaunchKernelGGL(k_fusion_bwd_w, dim3(bx_ceil_div(Hd, 64)), dim3(64), 0, s, dlogp, logp, hidden, eeg_logp, spec_logp, w2,
+                       dw1, db1, dw2, db2, B, N, Hd);
+    BX_CHECK_LAUNCH("bx_fusion_head_bwd(w)");
+  }
+  return BX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_kldiv(const float* __restrict__ logp, const float* __restrict__ target, float* __restrict__ loss,
+                                                float* __restrict__ dlogp, int n, float inv_denom, float gscale) {
+  __shared__ float part[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float t = target[i];
+    acc += t > 0.f ? t * (logf(t) - logp[i]) : 0.f;
+    if (dlogp) dlogp[i] = -t * inv_denom * gscale;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss) loss[0] = (part[0] + part[1] + part[2] + part[3]) * inv_denom;
+}
+extern "C" int bx_kldiv_fwd_bwd(const float* logp, const float* target, float* loss, float* dlogp, int B, int N,
+                                int reduction, float grad_scale, bxStream stream) {
+  BX_REQUIRE(logp && target && B > 0 && N > 0, "bx_kldiv_fwd_bwd: bad arguments");
+  BX_REQUIRE(reduction >= 0 && reduction <= 2, "bx_kldiv_fwd_bwd: reduction must be 0 (mean), 1 (batchmean) or 2 (sum)");
+  const float denom = reduction == 0 ? (float)B * N : reduction == 1 ? (float)B : 1.f;
+  hipLaunchKernelGGL(k_kldiv, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, target, loss, dlogp, B * N, 1.f / denom, grad_scale);
+  BX_CHECK_LAUNCH("bx_kldiv_fwd_bwd");
+  return BX_OK;
+}

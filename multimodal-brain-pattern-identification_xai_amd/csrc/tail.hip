@@ -1,0 +1,482 @@
+// Block tail: 2x2 pool -> BatchNorm2d -> Dropout -> + conv1x1(bilinear_half(x)), forward and backward,
+// over channels-last activations.  Replaces reference root/src/models/models.py:67-76 (Block.forward after
+// the three convolutions) and its autograd backward.
+//
+// Thread layout shared by the pixel-wise kernels: a thread owns 8 consecutive channels of one pooled
+// pixel; a 256-thread workgroup covers `slots = 256 / (C/8)` pixels at a time and grid-strides.
+// Per-channel reductions (BN statistics, BN/bias gradients) go thread -> LDS[slot][C] -> fixed-order
+// column sums -> per-workgroup partials in the workspace -> a one-workgroup finalize kernel that sums
+// the partials in double precision.  No atomics: results are run-to-run deterministic.
+#include "bx_common.h"
+
+#define TAIL_MAX_BLOCKS 1024
+
+struct TailGeom {
+  int B, H, W, Ho, Wo, C, Cin_p, ncg, slots;
+  long long npool;
+  float sy, sx;  // bilinear scales H/Ho, W/Wo (float, as ATen computes them)
+};
+
+static int make_geom(const bxTailDesc* d, TailGeom* g) {
+  g->B = d->B; g->H = d->H; g->W = d->W; g->Ho = d->H / 2; g->Wo = d->W / 2; g->C = d->C; g->Cin_p = d->Cin_p;
+  if (d->B <= 0 || g->Ho <= 0 || g->Wo <= 0) return -1;
+  if (d->C % 8 || d->C > 256 || 256 % (d->C / 8)) return -2;
+  if (d->Cin_p % 8 || d->Cin_p <= 0) return -3;
+  g->ncg = d->C / 8; g->slots = 256 / g->ncg;
+  g->npool = (long long)d->B * g->Ho * g->Wo;
+  g->sy = (float)d->H / (float)g->Ho; g->sx = (float)d->W / (float)g->Wo;
+  return 0;
+}
+static int tail_blocks(const TailGeom& g) {
+  long long nb = (g.npool + g.slots - 1) / g.slots;
+  return (int)(nb > TAIL_MAX_BLOCKS ? TAIL_MAX_BLOCKS : nb);
+}
+
+// fixed-order column reduction of NV per-thread 8-vectors through LDS; result for channel c in thread c (< C)
+template <int NV>
+__device__ __forceinline__ void block_channel_reduce(float (*vals)[8], float* lds, int C, int ncg, int slots, float out[NV]) {
+  const int cg = threadIdx.x % ncg, slot = threadIdx.x / ncg;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lds[slot * C + cg * 8 + j] = vals[k][j];
+    __syncthreads();
+    float s = 0.f;
+    if ((int)threadIdx.x < C)
+      for (int sl = 0; sl < slots; ++sl) s += lds[sl * C + threadIdx.x];
+    out[k] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward 1: pooled = pool2x2(y3) (stored, needed again by backward) + per-workgroup (sum, sumsq)
+template <typename T>
+__global__ __launch_bounds__(256) void k_pool_stats(const T* __restrict__ y3, T* __restrict__ pooled, float* __restrict__ partials,
+                                                     TailGeom g, int pool, int want_stats) {
+  __shared__ float lds[2048];
+  const int cg = threadIdx.x % g.ncg, slot = threadIdx.x / g.ncg;
+  float acc[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.f;
+  for (long long pp = (long long)blockIdx.x * g.slots + slot; pp < g.npool; pp += (long long)gridDim.x * g.slots) {
+    const int ox = (int)(pp % g.Wo);
+    const long long r = pp / g.Wo;
+    const int oy = (int)(r % g.Ho), b = (int)(r / g.Ho);
+    const size_t base = (((size_t)b * g.H + 2 * oy) * g.W + 2 * ox) * g.C + cg * 8;
+    float a[8], bq[8], c[8], dq[8], v[8];
+    ld8(y3, base, a); ld8(y3, base + g.C, bq);
+    ld8(y3, base + (size_t)g.W * g.C, c); ld8(y3, base + (size_t)g.W * g.C + g.C, dq);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v[j] = pool == BX_POOL_MAX ? fmaxf(fmaxf(a[j], bq[j]), fmaxf(c[j], dq[j])) : 0.25f * (a[j] + bq[j] + c[j] + dq[j]);
+    st8(pooled, (size_t)pp * g.C + cg * 8, v);
+    if (want_stats) {
+      float q[8];
+      ld8(pooled, (size_t)pp * g.C + cg * 8, q);  // statistics of the values as stored (bf16-rounded if bf16)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { acc[0][j] += q[j]; acc[1][j] += q[j] * q[j]; }
+    }
+  }
+  if (!want_stats) return;
+  float red[2];
+  block_channel_reduce<2>(acc, lds, g.C, g.ncg, g.slots, red);
+  if ((int)threadIdx.x < g.C) {
+    partials[((size_t)blockIdx.x * 2 + 0) * g.C + threadIdx.x] = red[0];
+    partials[((size_t)blockIdx.x * 2 + 1) * g.C + threadIdx.x] = red[1];
+  }
+}
+
+// bilinear sample of the block input at pooled pixel (oy, ox): 8 channels starting at c0
+template <typename T>
+__device__ __forceinline__ void skip_sample(const T* __restrict__ x, const TailGeom& g, int b, int oy, int ox, int c0, float out[8]) {
+  int y0, y1, x0, x1; float ly, lx;
+  bilinear_src(oy, g.sy, g.H, y0, y1, ly);
+  bilinear_src(ox, g.sx, g.W, x0, x1, lx);
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  float p00[8], p01[8], p10[8], p11[8];
+  const size_t rb = (size_t)b * g.H;
+  ld8(x, ((rb + y0) * g.W + x0) * g.Cin_p + c0, p00); ld8(x, ((rb + y0) * g.W + x1) * g.Cin_p + c0, p01);
+  ld8(x, ((rb + y1) * g.W + x0) * g.Cin_p + c0, p10); ld8(x, ((rb + y1) * g.W + x1) * g.Cin_p + c0, p11);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[j] = hy * (hx * p00[j] + lx * p01[j]) + ly * (hx * p10[j] + lx * p11[j]);
+}
+
+// forward 3: out = dropout(pooled*scale + shift) + b1x1 + W1x1 . bilinear(x)
+template <typename T>
+__global__ __launch_bounds__(256) void k_tail_apply(const T* __restrict__ pooled, const T* __restrict__ x, const float* __restrict__ w1x1,
+    int Cin, const float* __restrict__ b1x1, const float* __restrict__ scale, const float* __restrict__ shift,
+    const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, T* __restrict__ out, TailGeom g) {
+  extern __shared__ float xs[];  // [slots][Cin_p + 1]
+  const int cg = threadIdx.x % g.ncg, slot = threadIdx.x / g.ncg;
+  const int xstride = g.Cin_p + 1, nci8 = g.Cin_p / 8;
+  const uint64_t sd = (dropout_p > 0.f && seed) ? seed[0] : 0;
+  const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+  float sc[8], sh[8], bb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = scale[cg * 8 + j]; sh[j] = shift[cg * 8 + j]; bb[j] = b1x1[cg * 8 + j]; }
+  const long long nsteps = (g.npool + (long long)gridDim.x * g.slots - 1) / ((long long)gridDim.x * g.slots);
+  for (long long st = 0; st < nsteps; ++st) {
+    const long long p0 = (st * gridDim.x + blockIdx.x) * g.slots;
+    __syncthreads();
+    for (int u = threadIdx.x; u < g.slots * nci8; u += 256) {
+      const int sl = u / nci8, c8 = u % nci8;
+      const long long pp = p0 + sl;
+      if (pp < g.npool) {
+        const int ox = (int)(pp % g.Wo);
+        const long long r = pp / g.Wo;
+        float v[8];
+        skip_sample(x, g, (int)(r / g.Ho), (int)(r % g.Ho), ox, c8 * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xs[sl * xstride + c8 * 8 + j] = v[j];
+      }
+    }
+    __syncthreads();
+    const long long pp = p0 + slot;
+    if (pp >= g.npool) continue;
+    float pv[8], acc[8];
+    ld8(pooled, (size_t)pp * g.C + cg * 8, pv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = pv[j] * sc[j] + sh[j];
+      if (dropout_p > 0.f) v *= bx_dropout_scale(sd, salt, (uint64_t)pp * g.C + cg * 8 + j, dropout_p, inv_keep);
+      acc[j] = v + bb[j];
+    }
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float xv = xs[slot * xstride + ci];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(w1x1[(size_t)(cg * 8 + j) * Cin + ci], xv, acc[j]);
+    }
+    st8(out, (size_t)pp * g.C + cg * 8, acc);
+  }
+}
+
+extern "C" size_t bx_block_tail_workspace(const bxTailDesc* d) {
+  TailGeom g;
+  if (!d || make_geom(d, &g)) return 0;
+  const size_t Ho = d->H / 2, Wo = d->W / 2;
+  size_t fwd = ((size_t)TAIL_MAX_BLOCKS * 2 + 2) * d->C * sizeof(float);
+  size_t bwd = ((size_t)TAIL_MAX_BLOCKS * 3 + 3) * d->C * sizeof(float)                 // partials + coefficients
+             + bx_align_up((size_t)d->B * Ho * Wo * d->Cin_p * sizeof(float), 256)       // dXs (half-res, fp32)
+             + (size_t)256 * d->C * d->Cin_p * sizeof(float);                            // conv1x1 weight-grad partials
+  return bx_align_up(fwd > bwd ? fwd : bwd, 256);
+}
+
+extern "C" int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void* x, const float* w1x1, int Cin,
+                                 const float* b1x1, const float* bn_weight, const float* bn_bias,
+                                 float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                 const uint64_t* seed, void* pooled, void* out, float* save_mean, float* save_invstd,
+                                 void* workspace, size_t workspace_bytes, bxStream stream) {
+  BX_REQUIRE(d && y3 && x && w1x1 && b1x1 && bn_weight && bn_bias && running_mean && running_var && pooled && out && save_mean && save_invstd,
+             "bx_block_tail_fwd: null pointer");
+  BX_DTYPE_OK(d->dtype);
+  TailGeom g;
+  const int ge = make_geom(d, &g);
+  BX_REQUIRE(ge == 0, "bx_block_tail_fwd: unsupported geometry (code %d): need C%%8==0, C<=256, 256%%(C/8)==0, Cin_p%%8==0, H,W>=2", ge);
+  BX_REQUIRE(Cin > 0 && Cin <= d->Cin_p, "bx_block_tail_fwd: Cin=%d exceeds Cin_p=%d", Cin, d->Cin_p);
+  BX_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "bx_block_tail_fwd: dropout_p must be in [0,1)");
+  BX_REQUIRE(d->dropout_p == 0.f || !d->training || seed, "bx_block_tail_fwd: dropout needs a device seed");
+  const size_t need = bx_block_tail_workspace(d);
+  if (!workspace || workspace_bytes < need) BX_FAIL(BX_EWORKSPACE, "bx_block_tail_fwd: workspace %zu < %zu", workspace_bytes, need);
+  const size_t xs_bytes = (size_t)g.slots * (g.Cin_p + 1) * sizeof(float);
+  BX_REQUIRE(xs_bytes <= 60 * 1024, "bx_block_tail_fwd: Cin_p too large for the LDS tile");
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = tail_blocks(g);
+  float* partials = (float*)workspace;
+  float* scale = partials + (size_t)TAIL_MAX_BLOCKS * 2 * g.C;
+  float* shift = scale + g.C;
+  const float p = d->training ? d->dropout_p : 0.f;
+  BX_DISPATCH_DTYPE(d->dtype, T,
+    hipLaunchKernelGGL((k_pool_stats<T>), dim3(nblk), dim3(256), 0, s, (const T*)y3, (T*)pooled, partials, g, d->pool, d->training));
+  BX_CHECK_LAUNCH("bx_block_tail_fwd(pool)");
+  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(256), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight, bn_bias,
+                     running_mean, running_var, num_batches_tracked, d->momentum, d->eps, scale, shift, save_mean, save_invstd);
+  BX_CHECK_LAUNCH("bx_block_tail_fwd(finalize)");
+  BX_DISPATCH_DTYPE(d->dtype, T,
+    hipLaunchKernelGGL((k_tail_apply<T>), dim3(nblk), dim3(256), xs_bytes, s, (const T*)pooled, (const T*)x, w1x1, Cin, b1x1,
+                       scale, shift, seed, p, d->salt, (T*)out, g));
+  BX_CHECK_LAUNCH("bx_block_tail_fwd(apply)");
+  return BX_OK;
+}
+
+// ================================================================================================
+// backward
+// reduce: per channel  s1 = sum dD,  s2 = sum dD * xhat,  s3 = sum dOut   (dD = dOut * dropout multiplier)
+template <typename T>
+__global__ __launch_bounds__(256) void k_tail_bwd_reduce(const T* __restrict__ dout, const T* __restrict__ pooled,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const uint64_t* __restrict__ seed, float dropout_p,
+    uint32_t salt, float* __restrict__ partials, TailGeom g) {
+  __shared__ float lds[2048];
+  const int cg = threadIdx.x % g.ncg, slot = threadIdx.x / g.ncg;
+  const uint64_t sd = (dropout_p > 0.f && seed) ? seed[0] : 0;
+  const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+  float mu[8], is[8], acc[3][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { mu[j] = mean[cg * 8 + j]; is[j] = invstd[cg * 8 + j]; acc[0][j] = acc[1][j] = acc[2][j] = 0.f; }
+  for (long long pp = (long long)blockIdx.x * g.slots + slot; pp < g.npool; pp += (long long)gridDim.x * g.slots) {
+    float go[8], pv[8];
+    ld8(dout, (size_t)pp * g.C + cg * 8, go);
+    ld8(pooled, (size_t)pp * g.C + cg * 8, pv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float dd = go[j];
+      if (dropout_p > 0.f) dd *= bx_dropout_scale(sd, salt, (uint64_t)pp * g.C + cg * 8 + j, dropout_p, inv_keep);
+      acc[0][j] += dd;
+      acc[1][j] += dd * (pv[j] - mu[j]) * is[j];
+      acc[2][j] += go[j];
+    }
+  }
+  float red[3];
+  block_channel_reduce<3>(acc, lds, g.C, g.ncg, g.slots, red);
+  if ((int)threadIdx.x < g.C)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) partials[((size_t)blockIdx.x * 3 + k) * g.C + threadIdx.x] = red[k];
+}
+
+__global__ void k_tail_bwd_finalize(const float* __restrict__ partials, int nblk, double count, int C, int training,
+                                    const float* __restrict__ gamma, const float* __restrict__ invstd, float* __restrict__ coef,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db1x1) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0, s3 = 0;
+  for (int k = 0; k < nblk; ++k) {
+    s1 += partials[((size_t)k * 3 + 0) * C + c]; s2 += partials[((size_t)k * 3 + 1) * C + c]; s3 += partials[((size_t)k * 3 + 2) * C + c];
+  }
+  if (dbeta) dbeta[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s2;
+  if (db1x1) db1x1[c] = (float)s3;
+  coef[c] = gamma[c] * invstd[c];
+  coef[C + c] = training ? (float)(s1 / count) : 0.f;
+  coef[2 * C + c] = training ? (float)(s2 / count) : 0.f;
+}
+
+// apply: dP = a*(dD - k1 - xhat*k2); route through the 2x2 pool and conv3's ReLU to full resolution
+template <typename T>
+__global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ dout, const T* __restrict__ pooled, const T* __restrict__ y3,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
+    const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, int pool, T* __restrict__ dz3, TailGeom g) {
+  const int cg = threadIdx.x % g.ncg, slot = threadIdx.x / g.ncg;
+  const uint64_t sd = (dropout_p > 0.f && seed) ? seed[0] : 0;
+  const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+  float mu[8], is[8], a[8], k1[8], k2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    mu[j] = mean[c]; is[j] = invstd[c]; a[j] = coef[c]; k1[j] = coef[g.C + c]; k2[j] = coef[2 * g.C + c];
+  }
+  const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long long pp = (long long)blockIdx.x * g.slots + slot; pp < g.npool; pp += (long long)gridDim.x * g.slots) {
+    const int ox = (int)(pp % g.Wo);
+    const long long r = pp / g.Wo;
+    const int oy = (int)(r % g.Ho), b = (int)(r / g.Ho);
+    float go[8], pv[8], dp[8];
+    ld8(dout, (size_t)pp * g.C + cg * 8, go);
+    ld8(pooled, (size_t)pp * g.C + cg * 8, pv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float dd = go[j];
+      if (dropout_p > 0.f) dd *= bx_dropout_scale(sd, salt, (uint64_t)pp * g.C + cg * 8 + j, dropout_p, inv_keep);
+      dp[j] = a[j] * (dd - k1[j] - (pv[j] - mu[j]) * is[j] * k2[j]);
+    }
+    const size_t base = (((size_t)b * g.H + 2 * oy) * g.W + 2 * ox) * g.C + cg * 8;
+    const size_t off[4] = {0, (size_t)g.C, (size_t)g.W * g.C, (size_t)g.W * g.C + g.C};
+    float v[4][8], o[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ld8(y3, base + off[q], v[q]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (pool == BX_POOL_MAX) {
+        int arg = 0; float m = v[0][j];                       // first maximum in row-major window order (ATen)
+#pragma unroll
+        for (int q = 1; q < 4; ++q) if (v[q][j] > m) { m = v[q][j]; arg = q; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q][j] = (q == arg && m > 0.f) ? dp[j] : 0.f;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q][j] = v[q][j] > 0.f ? 0.25f * dp[j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st8(dz3, base + off[q], o[q]);
+    // rows / columns the floor-pool never covers get zero gradient
+    const bool last_x = (ox == g.Wo - 1) && (g.W & 1), last_y = (oy == g.Ho - 1) && (g.H & 1);
+    if (last_x) { st8(dz3, base + 2 * (size_t)g.C, zero8); st8(dz3, base + (size_t)g.W * g.C + 2 * (size_t)g.C, zero8); }
+    if (last_y) { st8(dz3, base + 2 * (size_t)g.W * g.C, zero8); st8(dz3, base + 2 * (size_t)g.W * g.C + g.C, zero8); }
+    if (last_x && last_y) st8(dz3, base + 2 * (size_t)g.W * g.C + 2 * (size_t)g.C, zero8);
+  }
+}
+
+// dXs[p][ci] = sum_c W1x1[c][ci] * dOut[p][c]   (half resolution, fp32)
+template <typename T>
+__global__ __launch_bounds__(256) void k_skip_dxs(const T* __restrict__ dout, const float* __restrict__ w1x1, int Cin,
+                                                   float* __restrict__ dxs, TailGeom g) {
+  const int nci8 = g.Cin_p / 8;
+  const long long n = g.npool * nci8;
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < n; u += (long long)gridDim.x * 256) {
+    const long long pp = u / nci8;
+    const int c8 = (int)(u % nci8);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < g.C; c0 += 8) {
+      float go[8];
+      ld8(dout, (size_t)pp * g.C + c0, go);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ci = c8 * 8 + j;
+          if (ci < Cin) acc[j] = fmaf(w1x1[(size_t)(c0 + k) * Cin + ci], go[k], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dxs[(size_t)pp * g.Cin_p + c8 * 8 + j] = acc[j];
+  }
+}
+
+// transposed bilinear: full-resolution gradient of the skip path gathered from dXs
+__device__ __forceinline__ int bilinear_T_taps(int i, float scale, int in_size, int out_size, int idx[4], float wt[4]) {
+  int n = 0;
+  int lo = (int)floorf(((float)i - 0.5f) / scale - 0.5f) - 1;
+  for (int o = lo; o <= lo + 4; ++o) {
+    if (o < 0 || o >= out_size) continue;
+    int i0, i1; float l1;
+    bilinear_src(o, scale, in_size, i0, i1, l1);
+    float w = 0.f;
+    if (i0 == i) w += 1.f - l1;
+    if (i1 == i) w += l1;
+    if (w != 0.f && n < 4) { idx[n] = o; wt[n] = w; ++n; }
+  }
+  return n;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_skip_scatter(const float* __restrict__ dxs, T* __restrict__ dx, TailGeom g) {
+  const int nci8 = g.Cin_p / 8;
+  const long long n = (long long)g.B * g.H * g.W * nci8;
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < n; u += (long long)gridDim.x * 256) {
+    const int c8 = (int)(u % nci8);
+    const long long p = u / nci8;
+    const int xx = (int)(p % g.W);
+    const long long r = p / g.W;
+    const int yy = (int)(r % g.H), b = (int)(r / g.H);
+    int iy[4], ix[4]; float wy[4], wx[4];
+    const int ny = bilinear_T_taps(yy, g.sy, g.H, g.Ho, iy, wy), nx = bilinear_T_taps(xx, g.sx, g.W, g.Wo, ix, wx);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < ny; ++a)
+      for (int c = 0; c < nx; ++c) {
+        const float w = wy[a] * wx[c];
+        const float* src = dxs + (((size_t)b * g.Ho + iy[a]) * g.Wo + ix[c]) * g.Cin_p + c8 * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(w, src[j], acc[j]);
+      }
+    st8(dx, (size_t)p * g.Cin_p + c8 * 8, acc);
+  }
+}
+
+// conv1x1 weight gradient: dW[c][ci] = sum_p dOut[p][c] * xs[p][ci]; 16x16 output tile per workgroup,
+// pixel chunks over blockIdx.x, partials reduced in fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void k_w1x1_grad(const T* __restrict__ dout, const T* __restrict__ x, float* __restrict__ partial,
+                                                    int pix_per_chunk, TailGeom g) {
+  __shared__ float sd[64][17], sxs[64][17];
+  const int c = threadIdx.x >> 4, ci = threadIdx.x & 15;
+  const int c0 = blockIdx.y * 16, ci0 = blockIdx.z * 16;
+  float acc = 0.f;
+  const long long p_begin = (long long)blockIdx.x * pix_per_chunk;
+  long long p_end = p_begin + pix_per_chunk;
+  if (p_end > g.npool) p_end = g.npool;
+  for (long long p0 = p_begin; p0 < p_end; p0 += 64) {
+    __syncthreads();
+    if (threadIdx.x < 128) {            // 64 pixels x 2 halves of dOut
+      const int px = threadIdx.x >> 1, half = threadIdx.x & 1;
+      const long long pp = p0 + px;
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (pp < p_end) ld8(dout, (size_t)pp * g.C + c0 + half * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sd[px][half * 8 + j] = v[j];
+    } else {                            // 64 pixels x 2 halves of the bilinear-sampled input
+      const int t = threadIdx.x - 128, px = t >> 1, half = t & 1;
+      const long long pp = p0 + px;
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (pp < p_end && ci0 + half * 8 < g.Cin_p) {
+        const int ox = (int)(pp % g.Wo);
+        const long long r = pp / g.Wo;
+        skip_sample(x, g, (int)(r / g.Ho), (int)(r % g.Ho), ox, ci0 + half * 8, v);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sxs[px][half * 8 + j] = v[j];
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int px = 0; px < 64; ++px) acc = fmaf(sd[px][c], sxs[px][ci], acc);
+  }
+  if (ci0 + ci < g.Cin_p) partial[((size_t)blockIdx.x * g.C + c0 + c) * g.Cin_p + ci0 + ci] = acc;
+}
+__global__ void k_w1x1_reduce(const float* __restrict__ partial, float* __restrict__ dw, int nchunk, int C, int Cin, int Cin_p) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= C * Cin_p) return;
+  const int c = idx / Cin_p, ci = idx % Cin_p;
+  if (ci >= Cin) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunk; ++k) s += partial[(size_t)k * C * Cin_p + idx];
+  dw[(size_t)c * Cin + ci] = s;
+}
+
+extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const void* y3, const void* x, const void* pooled,
+                                 const float* w1x1, int Cin, const float* bn_weight, const float* save_mean,
+                                 const float* save_invstd, const uint64_t* seed, void* dz3, void* dx_skip,
+                                 float* d_bn_weight, float* d_bn_bias, float* d_w1x1, float* d_b1x1,
+                                 void* workspace, size_t workspace_bytes, bxStream stream) {
+  BX_REQUIRE(d && dout && y3 && x && pooled && w1x1 && bn_weight && save_mean && save_invstd && dz3, "bx_block_tail_bwd: null pointer");
+  BX_DTYPE_OK(d->dtype);
+  TailGeom g;
+  const int ge = make_geom(d, &g);
+  BX_REQUIRE(ge == 0, "bx_block_tail_bwd: unsupported geometry (code %d)", ge);
+  BX_REQUIRE(Cin > 0 && Cin <= d->Cin_p, "bx_block_tail_bwd: Cin=%d exceeds Cin_p=%d", Cin, d->Cin_p);
+  BX_REQUIRE(d->C % 16 == 0, "bx_block_tail_bwd: C must be a multiple of 16");
+  const size_t need = bx_block_tail_workspace(d);
+  if (!workspace || workspace_bytes < need) BX_FAIL(BX_EWORKSPACE, "bx_block_tail_bwd: workspace %zu < %zu", workspace_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = tail_blocks(g);
+  const float p = d->training ? d->dropout_p : 0.f;
+  float* partials = (float*)workspace;
+  float* coef = partials + (size_t)TAIL_MAX_BLOCKS * 3 * g.C;
+  float* dxs = coef + 3 * g.C;
+  float* wpart = (float*)((char*)dxs + bx_align_up((size_t)g.npool * g.Cin_p * sizeof(float), 256));
+
+  BX_DISPATCH_DTYPE(d->dtype, T,
+    hipLaunchKernelGGL((k_tail_bwd_reduce<T>), dim3(nblk), dim3(256), 0, s, (const T*)dout, (const T*)pooled, save_mean, save_invstd,
+                       seed, p, d->salt, partials, g));
+  BX_CHECK_LAUNCH("bx_block_tail_bwd(reduce)");
+  hipLaunchKernelGGL(k_tail_bwd_finalize, dim3(1), dim3(256), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight,
+                     save_invstd, coef, d_bn_weight, d_bn_bias, d_b1x1);
+  BX_CHECK_LAUNCH("bx_block_tail_bwd(finalize)");
+  BX_DISPATCH_DTYPE(d->dtype, T,
+    hipLaunchKernelGGL((k_tail_bwd_apply<T>), dim3(nblk), dim3(256), 0, s, (const T*)dout, (const T*)pooled, (const T*)y3, save_mean,
+                       save_invstd, coef, seed, p, d->salt, d->pool, (T*)dz3, g));
+  BX_CHECK_LAUNCH("bx_block_tail_bwd(apply)");
+  if (d_w1x1) {
+    int nchunk = (int)((g.npool + 63) / 64);
+    if (nchunk > 256) nchunk = 256;
+    int ppc = (int)((g.npool + nchunk - 1) / nchunk);
+    ppc = (ppc + 63) / 64 * 64;
+    nchunk = (int)((g.npool + ppc - 1) / ppc);
+    dim3 grid(nchunk, g.C / 16, (g.Cin_p + 15) / 16);
+    BX_DISPATCH_DTYPE(d->dtype, T,
+      hipLaunchKernelGGL((k_w1x1_grad<T>), grid, dim3(256), 0, s, (const T*)dout, (const T*)x, wpart, ppc, g));
+    BX_CHECK_LAUNCH("bx_block_tail_bwd(w1x1)");
+    hipLaunchKernelGGL(k_w1x1_reduce, dim3(bx_ceil_div(g.C * g.Cin_p, 256)), dim3(256), 0, s, wpart, d_w1x1, nchunk, g.C, Cin, g.Cin_p);
+    BX_CHECK_LAUNCH("bx_block_tail_bwd(w1x1 reduce)");
+  }
+  if (dx_skip) {
+    const long long n1 = g.npool * (g.Cin_p / 8);
+    BX_DISPATCH_DTYPE(d->dtype, T,
+      hipLaunchKernelGGL((k_skip_dxs<T>), dim3(bx_ceil_div(n1, 256) > 2048 ? 2048 : bx_ceil_div(n1, 256)), dim3(256), 0, s,
+                         (const T*)dout, w1x1, Cin, dxs, g));
+    BX_CHECK_LAUNCH("bx_block_tail_bwd(dxs)");
+    const long long n2 = (long long)g.B * g.H * g.W * (g.Cin_p / 8);
+    BX_DISPATCH_DTYPE(d->dtype, T,
+      hipLaunchKernelGGL((k_skip_scatter<T>), dim3(bx_ceil_div(n2, 256) > 4096 ? 4096 : bx_ceil_div(n2, 256)), dim3(256), 0, s,
+                         dxs, (T*)dx_skip, g));
+    BX_CHECK_LAUNCH("bx_block_tail_bwd(scatter)");
+  }
+  return BX_OK;
+}

@@ -1,0 +1,232 @@
+"""Attribution over the multimodal model on the HIP path.
+
+* ``grad_cam``                -- canonical Grad-CAM (the reference ships none): forward,
+                                 backward from the class score to the target layer only, then the fused
+                                 activation x gradient channel-reduce kernel (bx_gradcam_reduce).
+* ``saliency`` / ``generate_saliency_maps`` -- reference XAI_Multimodality.py:3101-3133.
+* ``integrated_gradients``    -- Captum-default semantics (imported but never called by the reference, NB:51).
+"""
+from __future__ import annotations
+
+import contextlib
+import re
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+from .ops import _p, _stream
+
+
+@contextlib.contextmanager
+def _eval_frozen(model):
+    """eval() mode with parameters detached from autograd (so backward passes skip every weight-gradient
+    kernel); both restored on exit."""
+    was_training = model.training
+    flags = [(p, p.requires_grad) for p in model.parameters()]
+    model.eval()
+    for p, _ in flags:
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p, f in flags:
+            p.requires_grad_(f)
+        model.train(was_training)
+
+
+def _resolve(model, dotted):
+    mod = model
+    for part in dotted.split("."):
+        mod = getattr(mod, part)
+    return mod
+
+
+def _one_hot_rows(idx: torch.Tensor, n: int) -> torch.Tensor:
+    seed = torch.zeros(idx.shape[0], n, dtype=torch.float32, device=idx.device)
+    seed.scatter_(1, idx[:, None], 1.0)
+    return seed
+
+
+def _reduce(A_nhwc, G_nhwc, maps_per_act, relu):
+    lib = L.load()
+    n_maps, h, w, c = G_nhwc.shape
+    cam = torch.empty(n_maps, h, w, dtype=torch.float32, device=G_nhwc.device)
+    wts = torch.empty(n_maps, c, dtype=torch.float32, device=G_nhwc.device)
+    L.check(lib.bx_gradcam_reduce(_p(A_nhwc), _p(G_nhwc), _p(cam), _p(wts), n_maps, maps_per_act, h * w, c, 1 if relu else 0,
+                                  ops.bx_dtype(A_nhwc.dtype), _stream()), "bx_gradcam_reduce")
+    return cam, wts
+
+
+def resize_bilinear(maps: torch.Tensor, size) -> torch.Tensor:
+    """F.interpolate(maps[:,None], size, mode='bilinear', align_corners=False)[:,0] on fp32 [N,h,w]."""
+    n, h, w = maps.shape
+    H, W = size
+    out = torch.empty(n, H, W, dtype=torch.float32, device=maps.device)
+    L.check(L.load().bx_resize_bilinear(_p(maps.contiguous()), _p(out), n, h, w, H, W, _stream()), "bx_resize_bilinear")
+    return out
+
+
+_TARGET = re.compile(r"^(?:spectrogram_model\.)?block([1-5])(?:\.conv([1-3]))?$")
+
+
+def grad_cam(model, eeg, spec, target_layer="spectrogram_model.block5", class_idx=None, upsample=True, relu=True,
+             return_parts=False):
+    """Grad-CAM heat-maps of ``model(eeg, spec)``.
+
+    score y_c = the model's output log-probability of class c;  w[b,k] = mean_hw dy_c/dA[b,k];
+    cam[b] = ReLU(sum_k w[b,k] A[b,k]); optionally bilinear-upsampled to the spectrogram's H x W.
+
+    target_layer: 'spectrogram_model.blockN' (stage output) or 'spectrogram_model.blockN.convK'
+                  (that convolution's pre-ReLU output, i.e. what a hook on the reference's nn.Conv2d sees).
+    class_idx:    None -> each sample's arg-max class; int -> that class; 'all' -> every class, output
+                  gains a class axis [B, n_classes, H, W].
+    """
+    m = _TARGET.match(target_layer)
+    if not m:
+        raise ValueError(f"unsupported Grad-CAM target {target_layer!r}; use 'spectrogram_model.blockN[.convK]'")
+    spec_model = model.spectrogram_model if hasattr(model, "spectrogram_model") else model
+    blk = getattr(spec_model, f"block{m.group(1)}")
+    conv_k = int(m.group(2)) if m.group(2) else 0
+    with _eval_frozen(model):
+        spec_in = spec.detach().clone().requires_grad_(True)
+        grabbed = {}
+        hooks = []
+        if conv_k:
+            blk._preact, blk._capture = conv_k, {}
+            hooks.append(blk.register_forward_pre_hook(lambda _m, args: grabbed.__setitem__("x", args[0])))
+        else:
+            hooks.append(blk.register_forward_hook(lambda _m, _i, o: grabbed.__setitem__("A", o)))
+        try:
+            out = model(eeg, spec_in) if hasattr(model, "spectrogram_model") else model(spec_in)
+        finally:
+            for h in hooks:
+                h.remove()
+        n_cls = out.shape[1]
+        B = out.shape[0]
+        if class_idx is None:
+            seeds = [_one_hot_rows(out.detach().argmax(1), n_cls)]
+        elif isinstance(class_idx, str):
+            if class_idx != "all":
+                raise ValueError(class_idx)
+            seeds = [_one_hot_rows(torch.full((B,), c, dtype=torch.int64, device=out.device), n_cls) for c in range(n_cls)]
+        else:
+            seeds = [_one_hot_rows(torch.full((B,), int(class_idx), dtype=torch.int64, device=out.device), n_cls)]
+        try:
+            grads = []
+            for sd in seeds:
+                if conv_k:
+                    torch.autograd.grad(out, grabbed["x"], grad_outputs=sd, retain_graph=True)
+                    grads.append(blk._capture["grad"])
+                else:
+                    (g,) = torch.autograd.grad(out, grabbed["A"], grad_outputs=sd, retain_graph=True)
+                    grads.append(g.permute(0, 2, 3, 1).contiguous())
+            A = blk._capture["act"] if conv_k else grabbed["A"].detach().permute(0, 2, 3, 1).contiguous()
+        finally:
+            blk._preact, blk._capture = 0, None
+        nm = len(grads)
+        # map index = sample * nm + class
+        G = torch.stack(grads, dim=1).reshape(B * nm, *grads[0].shape[1:]) if nm > 1 else grads[0]
+        cam, wts = _reduce(A, G, nm, relu=relu)
+        raw = _reduce(A, G, nm, relu=False)[0] if (return_parts and relu) else cam
+        if upsample:
+            cam = resize_bilinear(cam, spec.shape[-2:])
+    stacked = isinstance(class_idx, str)
+    def shape(t):
+        return t.reshape(B, nm, *t.shape[1:]) if stacked else t
+    if return_parts:
+        return shape(cam), shape(raw), shape(wts), A, out.detach()
+    return shape(cam)
+
+
+def _abs(t: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(t)
+    L.check(L.load().bx_abs(_p(t), _p(out), t.numel(), _stream()), "bx_abs")
+    return out
+
+
+def saliency(model, eeg, spec, reference_quirk=False):
+    """|d max-logprob / d input| (reference XAI_Multimodality.py:3109-3129): returns
+    (eeg_sal [B,Chans,T], spec_sal [B,H,W]); the spectrogram map is the max over channels.
+    ``reference_quirk=True`` doubles the spectrogram map as the reference's second backward() does."""
+    with _eval_frozen(model):
+        e = eeg.detach().clone().float().requires_grad_(True)
+        s = spec.detach().clone().float().requires_grad_(True)
+        out = model(e, s)
+        seed = _one_hot_rows(out.detach().argmax(1), out.shape[1])
+        ge, gs = torch.autograd.grad(out, (e, s), grad_outputs=seed)
+    B, Cc, H, W = gs.shape
+    g_nhwc = ops.to_nhwc(gs, torch.float32)
+    smap = torch.empty(B, H, W, dtype=torch.float32, device=gs.device)
+    L.check(L.load().bx_saliency_reduce(_p(g_nhwc), _p(smap), B, H * W, Cc, g_nhwc.shape[3], 2.0 if reference_quirk else 1.0,
+                                        L.BX_F32, _stream()), "bx_saliency_reduce")
+    return _abs(ge.contiguous())[:, 0], smap
+
+
+def generate_saliency_maps(model, dataloader, plot_eeg=None, plot_spectrogram=None, device=None):
+    """Reference signature (XAI_Multimodality.py:3101).  Iterates ``((eeg, spec), label)`` batches, computes the
+    reference's maps (batch element 0 of each batch, spectrogram map with its 2x accumulation quirk) and hands
+    them to the optional plot callbacks; also returns them as a list of (eeg_map, spec_map) numpy pairs."""
+    device = device or next(model.parameters()).device
+    results = []
+    for (eeg_data, spectrogram_data), _label in dataloader:
+        e, s = eeg_data.to(device)[:1], spectrogram_data.to(device)[:1]
+        es, ss = saliency(model, e, s, reference_quirk=True)
+        pair = (es[0].cpu().numpy(), ss[0].cpu().numpy())
+        results.append(pair)
+        if plot_eeg is not None:
+            plot_eeg(pair[0])
+        if plot_spectrogram is not None:
+            plot_spectrogram(pair[1])
+    return results
+
+
+def ig_nodes(n_steps=50):
+    x, w = np.polynomial.legendre.leggauss(n_steps)
+    return 0.5 * (1.0 + x), 0.5 * w
+
+
+def _axpby(x, y, alpha, beta):
+    L.check(L.load().bx_axpby(_p(x), _p(y), x.numel(), float(alpha), float(beta), _stream()), "bx_axpby")
+
+
+def integrated_gradients(model, inputs, baselines=None, target=None, n_steps=50, max_batch=256):
+    """(x - x') * sum_k w_k grad F_target(x' + a_k (x - x')) with Gauss-Legendre nodes (Captum's default rule).
+    inputs = (eeg [B,1,Ch,T], spec [B,C,H,W]); the k-loop is batched: up to ``max_batch`` interpolants per pass."""
+    eeg, spec = (t.detach().float().contiguous() for t in inputs)
+    be, bs = baselines if baselines is not None else (torch.zeros_like(eeg), torch.zeros_like(spec))
+    be, bs = be.float().contiguous(), bs.float().contiguous()
+    B = eeg.shape[0]
+    alphas, steps = ig_nodes(n_steps)
+    acc_e, acc_s = torch.zeros_like(eeg), torch.zeros_like(spec)
+    per_pass = max(1, max_batch // B)
+    with _eval_frozen(model):
+        if target is None:
+            with torch.no_grad():
+                tgt = model(eeg, spec).argmax(1)
+        else:
+            tgt = torch.full((B,), int(target), dtype=torch.int64, device=eeg.device)
+        for k0 in range(0, n_steps, per_pass):
+            ks = range(k0, min(n_steps, k0 + per_pass))
+            xe = torch.empty(len(ks), *eeg.shape, dtype=torch.float32, device=eeg.device)
+            xs = torch.empty(len(ks), *spec.shape, dtype=torch.float32, device=spec.device)
+            for j, k in enumerate(ks):
+                _axpby(be, xe[j], 1.0 - alphas[k], 0.0); _axpby(eeg, xe[j], alphas[k], 1.0)
+                _axpby(bs, xs[j], 1.0 - alphas[k], 0.0); _axpby(spec, xs[j], alphas[k], 1.0)
+            xe = xe.flatten(0, 1).requires_grad_(True)
+            xs = xs.flatten(0, 1).requires_grad_(True)
+            out = model(xe, xs)
+            seed = _one_hot_rows(tgt.repeat(len(ks)), out.shape[1])
+            ge, gs = torch.autograd.grad(out, (xe, xs), grad_outputs=seed)
+            ge, gs = ge.reshape(len(ks), *eeg.shape), gs.reshape(len(ks), *spec.shape)
+            for j, k in enumerate(ks):
+                _axpby(ge[j], acc_e, steps[k], 1.0)
+                _axpby(gs[j], acc_s, steps[k], 1.0)
+    de, ds = eeg.clone(), spec.clone()
+    _axpby(be, de, -1.0, 1.0)
+    _axpby(bs, ds, -1.0, 1.0)
+    lib = L.load()
+    L.check(lib.bx_mul(_p(acc_e), _p(de), _p(acc_e), acc_e.numel(), _stream()), "bx_mul")
+    L.check(lib.bx_mul(_p(acc_s), _p(ds), _p(acc_s), acc_s.numel(), _stream()), "bx_mul")
+    return acc_e, acc_s

@@ -1,0 +1,196 @@
+"""Drop-in model classes: same names, constructor arguments, sub-module names and state_dict keys as
+the reference (root/src/models/models.py:42-107,239-289; MultimodalModel = XAI_Multimodality.py:1082-1108),
+with forward/backward running on the HIP kernels of libbrainxai.so.
+
+Sub-modules such as ``conv1`` or ``bn`` are ordinary torch modules used as PARAMETER CONTAINERS (so
+checkpoints interchange with the reference and ``model.block3.conv2.weight`` means what it says);
+their own ``forward`` is never called -- each stage runs as one fused autograd Function.
+
+Inputs must be CUDA tensors; there is no CPU path.  ``compute_dtype`` (float32 | bfloat16) selects the
+activation storage type; parameters, statistics and gradients stay float32.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_STAGES = ((16, "max"), (32, "avg"), (64, "max"), (128, "avg"), (256, "max"))
+
+
+def _is_internal(x: torch.Tensor, dtype: torch.dtype) -> bool:
+    """True for a logical-NCHW view of one of our channels-last activations."""
+    return (x.is_cuda and x.dim() == 4 and x.dtype == dtype and x.shape[1] % 8 == 0
+            and x.permute(0, 2, 3, 1).is_contiguous())
+
+
+class Block(nn.Module):
+    """relu(conv3x3) x3 -> 2x2 pool -> BatchNorm -> Dropout -> + conv1x1(bilinear(x))  (reference models.py:42-77)."""
+
+    def __init__(self, in_channels, out_channels, pool_type="max", pool_size=(2, 2), dropout_p=0.5):
+        super().__init__()
+        if tuple(pool_size) != (2, 2) if not isinstance(pool_size, int) else pool_size != 2:
+            raise ValueError("brainxai Block: only the reference's 2x2 pooling is implemented")
+        if pool_type not in ("max", "avg"):
+            raise ValueError(f"pool_type must be 'max' or 'avg', got {pool_type!r}")
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.conv3 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.pool = nn.MaxPool2d(kernel_size=pool_size) if pool_type == "max" else nn.AvgPool2d(kernel_size=pool_size)
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.dropout = nn.Dropout(p=dropout_p)
+        self.conv1x1 = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+        self.in_channels, self.out_channels, self.pool_type = in_channels, out_channels, pool_type
+        self.compute_dtype = torch.float32
+        self.salt = 0
+        self._preact = 0          # set by explain.grad_cam for targets "blockN.convK"
+        self._capture = None
+
+    def forward(self, x):
+        dt = self.compute_dtype
+        if _is_internal(x, dt) and x.shape[1] == ops.pad8(self.in_channels):
+            xi = x.permute(0, 2, 3, 1)
+        else:
+            if x.dim() != 4 or x.shape[1] != self.in_channels:
+                raise RuntimeError(f"Block expected [B,{self.in_channels},H,W], got {tuple(x.shape)}")
+            xi = ops.InputLayout.apply(x, dt)
+        if xi.shape[1] < 2 or xi.shape[2] < 2:
+            raise RuntimeError("Block needs H, W >= 2")
+        bn = self.bn
+        cfg = ops.block_cfg(pool=self.pool_type, training=self.training, dropout_p=self.dropout.p if self.training else 0.0,
+                            eps=bn.eps, momentum=0.1 if bn.momentum is None else bn.momentum, salt=self.salt,
+                            preact=self._preact, capture=self._capture)
+        out = ops.BlockFn.apply(xi, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.conv3.weight,
+                                self.conv3.bias, bn.weight, bn.bias, self.conv1x1.weight, self.conv1x1.bias,
+                                bn.running_mean, bn.running_var, bn.num_batches_tracked, cfg)
+        return out.permute(0, 3, 1, 2)     # logical NCHW view (channels-last strides), as hooks expect
+
+
+class Spectrogram_Model(nn.Module):
+    """Five stages -> GAP -> Linear(256, classes) -> LogSoftmax (reference models.py:79-107).
+    ``in_channels`` (default 3, the reference's value) is the build's extension for the 4-plane benchmark input."""
+
+    def __init__(self, num_classes=6, in_channels=3):
+        super().__init__()
+        prev = in_channels
+        for i, (c, kind) in enumerate(_STAGES, start=1):
+            blk = Block(in_channels=prev, out_channels=c, pool_type=kind, pool_size=(2, 2))
+            blk.salt = i
+            setattr(self, f"block{i}", blk)
+            prev = c
+        self.gap = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(256, num_classes)
+        self.log_softmax = nn.LogSoftmax(dim=1)
+        self.compute_dtype = torch.float32
+
+    def features(self, x):
+        for i in range(1, 6):
+            x = getattr(self, f"block{i}")(x)
+        return x
+
+    def forward(self, x):
+        f = self.features(x)
+        return ops.GapFcLsmFn.apply(f.permute(0, 2, 3, 1), self.fc.weight, self.fc.bias)
+
+
+class EEGNet(nn.Module):
+    """EEGNet over [B,1,Chans,Samples] (reference models.py:239-289)."""
+
+    def __init__(self, nb_classes, Chans=37, Samples=3000, dropoutRate=0.5, kernLength=64, F1=8, D=2, F2=16,
+                 norm_rate=0.25, dropoutType="Dropout"):
+        super().__init__()
+        if dropoutType != "Dropout":
+            raise NotImplementedError("brainxai EEGNet: only dropoutType='Dropout' (the reference's default) is implemented")
+        self.nb_classes, self.Chans, self.Samples = nb_classes, Chans, Samples
+        self.conv1 = nn.Conv2d(1, F1, (1, kernLength), padding="same", bias=False)
+        self.batchnorm1 = nn.BatchNorm2d(F1)
+        self.depthwiseConv = nn.Conv2d(F1, F1 * D, (Chans, 1), groups=F1, bias=False)
+        self.batchnorm2 = nn.BatchNorm2d(F1 * D)
+        self.activation = nn.ELU()
+        self.avg_pool1 = nn.AvgPool2d((1, 4))
+        self.dropout = nn.Dropout(dropoutRate)
+        self.separableConv = nn.Conv2d(F1 * D, F2, (1, 16), padding="same", bias=False)
+        self.batchnorm3 = nn.BatchNorm2d(F2)
+        self.avg_pool2 = nn.AvgPool2d((1, 8))
+        self.flatten = nn.Flatten()
+        self.dense = nn.Linear(F2 * (Samples // 32), nb_classes)
+        self.log_softmax = nn.LogSoftmax(dim=1)
+        self._geom = SimpleNamespace(F1=F1, D=D, F2=F2, K1=kernLength, K2=16, P1=4, P2=8)
+        self.compute_dtype = torch.float32
+        self.salt = 100
+
+    def features(self, x):
+        if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != self.Chans:
+            raise RuntimeError(f"EEGNet expected [B,1,{self.Chans},T], got {tuple(x.shape)}")
+        g = self._geom
+        bn1, bn2, bn3 = self.batchnorm1, self.batchnorm2, self.batchnorm3
+        cfg = SimpleNamespace(F1=g.F1, D=g.D, F2=g.F2, K1=g.K1, K2=g.K2, P1=g.P1, P2=g.P2, training=self.training,
+                              eps=bn1.eps, momentum=0.1 if bn1.momentum is None else bn1.momentum,
+                              dropout_p=self.dropout.p if self.training else 0.0, salt=self.salt, dtype=self.compute_dtype)
+        bufs = (bn1.running_mean, bn1.running_var, bn1.num_batches_tracked, bn2.running_mean, bn2.running_var,
+                bn2.num_batches_tracked, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked)
+        return ops.EegFeaturesFn.apply(x, self.conv1.weight, bn1.weight, bn1.bias, self.depthwiseConv.weight, bn2.weight, bn2.bias,
+                                       self.separableConv.weight, bn3.weight, bn3.bias, bufs, cfg)
+
+    def forward(self, x):
+        feat = self.features(x)
+        if feat.shape[1] != self.dense.in_features:
+            raise RuntimeError(f"EEGNet: {feat.shape[1]} features but dense expects {self.dense.in_features} (Samples mismatch)")
+        return ops.LinearLsmFn.apply(feat, self.dense.weight, self.dense.bias)
+
+
+class MultimodalModel(nn.Module):
+    """Late fusion over the two branches' log-probabilities (reference XAI_Multimodality.py:1082-1108)."""
+
+    def __init__(self, eeg_model, spectrogram_model, num_classes=6):
+        super().__init__()
+        self.eeg_model = eeg_model
+        self.spectrogram_model = spectrogram_model
+        combined_output_size = eeg_model.dense.out_features + spectrogram_model.fc.out_features
+        self.fc1 = nn.Linear(combined_output_size, 128)
+        self.fc2 = nn.Linear(128, num_classes)
+        self.log_softmax = nn.LogSoftmax(dim=1)
+
+    def forward(self, eeg_data, spectrogram_data):
+        e = self.eeg_model(eeg_data)
+        s = self.spectrogram_model(spectrogram_data)
+        if e.shape[1] != s.shape[1]:
+            raise RuntimeError("MultimodalModel: both branches must emit the same number of classes")
+        return ops.FusionHeadFn.apply(e, s, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+
+    def forward_spectrogram(self, spectrogram_data):
+        return self.spectrogram_model(spectrogram_data)
+
+
+class KLDivLoss(nn.Module):
+    """nn.KLDivLoss(reduction) on log-prob input / prob target, fused with its gradient seed."""
+
+    def __init__(self, reduction="mean"):
+        super().__init__()
+        if reduction not in ("mean", "batchmean", "sum"):
+            raise ValueError(reduction)
+        self.reduction = reduction
+
+    def forward(self, log_probs, target):
+        return ops.KLDivFn.apply(log_probs, target, self.reduction, 1.0)
+
+
+def set_compute_dtype(model: nn.Module, dtype: torch.dtype) -> nn.Module:
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    for m in model.modules():
+        if hasattr(m, "compute_dtype"):
+            m.compute_dtype = dtype
+    return model
+
+
+def build_multimodal(chans=19, samples=2000, in_channels=4, num_classes=6, dropout=0.5, compute_dtype=torch.float32):
+    """The benchmark model of BASELINE.md section 2 (2 025 074 parameters at the defaults)."""
+    eeg = EEGNet(num_classes, Chans=chans, Samples=samples, dropoutRate=dropout)
+    spec = Spectrogram_Model(num_classes, in_channels=in_channels)
+    for i in range(1, 6):
+        getattr(spec, f"block{i}").dropout.p = dropout
+    return set_compute_dtype(MultimodalModel(eeg, spec, num_classes), compute_dtype)

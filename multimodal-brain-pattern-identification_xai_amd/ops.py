@@ -1,0 +1,415 @@
+"""torch.autograd glue over the C ABI: one Function per fused stage of the hot path.
+
+PyTorch is used here for device memory (caching allocator), the current HIP stream and autograd
+bookkeeping only; every arithmetic step is a launch into libbrainxai.so.  Activations of the 2-D CNN
+are channels-last tensors [B, H, W, C] in the compute dtype (float32 or bfloat16); parameters and
+their gradients are float32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+
+import torch
+
+from . import _lib as L
+
+CONV_ALGO = L.BX_ALGO_AUTO        # module-level switch used by tests to force the direct / MFMA kernels
+WGRAD_ALGO = L.BX_ALGO_AUTO
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"brainxai: {what} must live on the GPU (got {t.device}); this package has no CPU path")
+
+
+def bx_dtype(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return L.BX_F32
+    if dt == torch.bfloat16:
+        return L.BX_BF16
+    raise RuntimeError(f"brainxai: unsupported compute dtype {dt}")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_WS = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per device (all uses are ordered on the current stream)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+_SEED = {}
+
+
+def seed_state(device) -> torch.Tensor:
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SEED.get(key)
+    if st is None:
+        st = torch.full((1,), torch.initial_seed() & 0x7FFFFFFFFFFF, dtype=torch.int64, device=device)
+        _SEED[key] = st
+    return st
+
+
+def manual_seed(seed: int, device=None):
+    """Reset the dropout counter stream of ``device`` (default: current device)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    seed_state(device).fill_(int(seed))
+
+
+def next_seed(device) -> torch.Tensor:
+    out = torch.empty(1, dtype=torch.int64, device=device)
+    L.check(L.load().bx_seed_next(_p(seed_state(device)), _p(out), _stream()), "bx_seed_next")
+    return out
+
+
+# Gradient arena hook: the trainer / DDP wrapper registers, per parameter, a callable returning a fresh
+# view into its flat fp32 gradient buffer, so weight-gradient kernels write there directly.
+_GRAD_VIEW = {}
+
+
+def register_grad_views(params, flat: torch.Tensor):
+    off = 0
+    for p_ in params:
+        n = p_.numel()
+        _GRAD_VIEW[p_.data_ptr()] = (flat, off, tuple(p_.shape))
+        off += n
+    return off
+
+
+def clear_grad_views():
+    _GRAD_VIEW.clear()
+
+
+def new_grad(param: torch.Tensor) -> torch.Tensor:
+    ent = _GRAD_VIEW.get(param.data_ptr())   # saved tensors are new objects; storage identifies the parameter
+    if ent is None:
+        return torch.empty_like(param, dtype=torch.float32)
+    flat, off, shape = ent
+    return flat.narrow(0, off, param.numel()).view(shape)
+
+
+def pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+# ------------------------------------------------------------------------------------------------
+def to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 NCHW [B,C,H,W] (any strides) -> compute-dtype NHWC [B,H,W,pad8(C)] with zero padding."""
+    _require_gpu(x, "input")
+    B, Cc, H, W = x.shape
+    src = x.detach().to(torch.float32).contiguous()
+    out = torch.empty(B, H, W, pad8(Cc), dtype=dtype, device=x.device)
+    L.check(L.load().bx_nchw_to_nhwc(_p(src), _p(out), B, Cc, H, W, pad8(Cc), bx_dtype(dtype), _stream()), "bx_nchw_to_nhwc")
+    return out
+
+
+def to_nchw_f32(x_nhwc: torch.Tensor, channels: int) -> torch.Tensor:
+    B, H, W, Cs = x_nhwc.shape
+    out = torch.empty(B, channels, H, W, dtype=torch.float32, device=x_nhwc.device)
+    L.check(L.load().bx_nhwc_to_nchw(_p(x_nhwc), _p(out), B, channels, H, W, Cs, bx_dtype(x_nhwc.dtype), _stream()), "bx_nhwc_to_nchw")
+    return out
+
+
+class InputLayout(torch.autograd.Function):
+    """Differentiable NCHW fp32 -> NHWC(pad 8) compute-dtype conversion (gradient flows back for saliency / IG)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.channels = x.shape[1]
+        return to_nhwc(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return to_nchw_f32(g.contiguous(), ctx.channels), None
+
+
+def _pack(w: torch.Tensor, flip: bool):
+    """fp32 OIHW -> library operand(s). Returns (packed_f32, packed_mfma|None, I_p, O_p)."""
+    lib = L.load()
+    co, ci = w.shape[0], w.shape[1]
+    i_log, o_log = (co, ci) if flip else (ci, co)
+    ip, op = pad8(i_log), pad8(o_log)
+    pf = torch.empty(9 * ip * op, dtype=torch.float32, device=w.device)
+    pm = None
+    nb = lib.bx_conv3x3_packed_mfma_bytes(ip, op) if hasattr(lib, "bx_conv3x3_packed_mfma_bytes") else 0
+    if nb:
+        pm = torch.empty(nb, dtype=torch.uint8, device=w.device)
+    L.check(lib.bx_conv3x3_pack(_p(w), _p(pf), _p(pm), co, ci, ip, op, 1 if flip else 0, _stream()), "bx_conv3x3_pack")
+    return pf, pm, ip, op
+
+
+def _conv(x, packed, bias, mask_src, addend, relu: bool, dtype):
+    pf, pm, ip, op = packed
+    B, H, W, Ci = x.shape
+    if Ci != ip:
+        raise RuntimeError(f"brainxai: conv input has {Ci} channels, packed weights expect {ip}")
+    y = torch.empty(B, H, W, op, dtype=dtype, device=x.device)
+    algo = CONV_ALGO if x.dtype == torch.bfloat16 else L.BX_ALGO_DIRECT
+    L.check(L.load().bx_conv3x3(_p(x), _p(pf), _p(pm), _p(bias), _p(mask_src), _p(addend), _p(y), B, H, W, Ci, op,
+                                bx_dtype(dtype), L.BX_EPI_RELU if relu else 0, algo, _stream()), "bx_conv3x3")
+    return y
+
+
+def _wgrad(x, dz, w: torch.Tensor, b: torch.Tensor):
+    lib = L.load()
+    B, H, W, Cip = x.shape
+    Co = dz.shape[3]
+    dt = bx_dtype(x.dtype)
+    algo = WGRAD_ALGO if x.dtype == torch.bfloat16 else L.BX_ALGO_DIRECT
+    need = lib.bx_conv3x3_wgrad_workspace(B, H, W, Cip, Co, dt, algo)
+    ws = workspace(need, x.device)
+    dw, db = new_grad(w), new_grad(b)
+    L.check(lib.bx_conv3x3_wgrad(_p(x), _p(dz), _p(dw), _p(db), B, H, W, w.shape[1], Cip, Co, dt, algo, _p(ws), ws.numel(), _stream()),
+            "bx_conv3x3_wgrad")
+    return dw, db
+
+
+def _tail_desc(x, y3, cfg) -> L.TailDesc:
+    B, H, W, Cc = y3.shape
+    return L.TailDesc(B, H, W, x.shape[3], Cc, L.BX_POOL_MAX if cfg.pool == "max" else L.BX_POOL_AVG, 1 if cfg.training else 0,
+                      cfg.eps, cfg.momentum, float(cfg.dropout_p), cfg.salt, bx_dtype(y3.dtype))
+
+
+class BlockFn(torch.autograd.Function):
+    """relu(conv3x3) x3 -> pool -> BN -> dropout -> + conv1x1(bilinear(x))   (reference models.py:62-77).
+
+    x: NHWC [B,H,W,Cin_p].  Returns NHWC [B,H/2,W/2,C].  With cfg.preact = k in {1,2,3} the k-th conv's
+    PRE-ReLU output (what a hook on ``blockN.convK`` would see) is kept in cfg.capture["act"] and the
+    gradient reaching it during backward in cfg.capture["grad"] (attribution targets inside a stage).
+    """
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, bnw, bnb, w11, b11, rm, rv, nbt, cfg):
+        lib = L.load()
+        dt = x.dtype
+        ws_, bs_ = (w1, w2, w3), (b1, b2, b3)
+        acts, pre = [x], None
+        for k in range(3):
+            packed = _pack(ws_[k], flip=False)
+            if cfg.preact == k + 1:
+                pre = _conv(acts[-1], packed, bs_[k], None, None, False, dt)
+                y = torch.empty_like(pre)
+                L.check(lib.bx_relu(_p(pre), _p(y), pre.numel(), bx_dtype(dt), _stream()), "bx_relu")
+            else:
+                y = _conv(acts[-1], packed, bs_[k], None, None, True, dt)
+            acts.append(y)
+        y3 = acts[3]
+        B, H, W, Cc = y3.shape
+        desc = _tail_desc(x, y3, cfg)
+        seed = next_seed(x.device) if (cfg.training and cfg.dropout_p > 0) else None
+        pooled = torch.empty(B, H // 2, W // 2, Cc, dtype=dt, device=x.device)
+        out = torch.empty_like(pooled)
+        mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        ws = workspace(lib.bx_block_tail_workspace(C.byref(desc)), x.device)
+        L.check(lib.bx_block_tail_fwd(C.byref(desc), _p(y3), _p(x), _p(w11), w11.shape[1], _p(b11), _p(bnw), _p(bnb), _p(rm), _p(rv), _p(nbt),
+                                      _p(seed), _p(pooled), _p(out), _p(mean), _p(invstd), _p(ws), ws.numel(), _stream()), "bx_block_tail_fwd")
+        ctx.cfg, ctx.desc, ctx.seed = cfg, desc, seed
+        ctx.save_for_backward(x, acts[1], acts[2], y3, pooled, mean, invstd, w1, b1, w2, b2, w3, b3, bnw, bnb, w11, b11)
+        if pre is not None:
+            cfg.capture["act"] = pre
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.load()
+        x, y1, y2, y3, pooled, mean, invstd, w1, b1, w2, b2, w3, b3, bnw, bnb, w11, b11 = ctx.saved_tensors
+        cfg, desc, seed = ctx.cfg, ctx.desc, ctx.seed
+        dt = x.dtype
+        need_dx = ctx.needs_input_grad[0]
+        need_w = any(ctx.needs_input_grad[1:11])
+        dout = dout.contiguous()
+        dz3 = torch.empty_like(y3)
+        dx_skip = torch.empty_like(x) if need_dx else None
+        d_bnw, d_bnb = new_grad(bnw), new_grad(bnb)
+        d_w11, d_b11 = (new_grad(w11), new_grad(b11)) if need_w else (None, None)
+        ws = workspace(lib.bx_block_tail_workspace(C.byref(desc)), x.device)
+        L.check(lib.bx_block_tail_bwd(C.byref(desc), _p(dout), _p(y3), _p(x), _p(pooled), _p(w11), w11.shape[1], _p(bnw), _p(mean), _p(invstd),
+                                      _p(seed), _p(dz3), _p(dx_skip), _p(d_bnw), _p(d_bnb), _p(d_w11), _p(d_b11), _p(ws), ws.numel(), _stream()),
+                "bx_block_tail_bwd")
+        if cfg.preact == 3:
+            cfg.capture["grad"] = dz3
+        acts = (x, y1, y2)
+        wts = (w1, w2, w3)
+        bss = (b1, b2, b3)
+        grads_w, grads_b = [None] * 3, [None] * 3
+        dz = dz3
+        for k in (2, 1, 0):
+            if need_w:
+                grads_w[k], grads_b[k] = _wgrad(acts[k], dz, wts[k], bss[k])
+            if k > 0:
+                dz = _conv(dz, _pack(wts[k], flip=True), None, acts[k], None, False, dt)
+                if cfg.preact == k:
+                    cfg.capture["grad"] = dz
+            elif need_dx:
+                dz = _conv(dz, _pack(wts[0], flip=True), None, None, dx_skip, False, dt)
+        dx = dz if need_dx else None
+        return (dx, grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2], d_bnw, d_bnb, d_w11, d_b11,
+                None, None, None, None)
+
+
+class GapFcLsmFn(torch.autograd.Function):
+    """AdaptiveAvgPool2d(1) -> Linear -> LogSoftmax over an NHWC feature map (reference models.py:103-106)."""
+
+    @staticmethod
+    def forward(ctx, feat, w, b):
+        B, H, W, Cc = feat.shape
+        N = w.shape[0]
+        gap = torch.empty(B, Cc, dtype=torch.float32, device=feat.device)
+        logp = torch.empty(B, N, dtype=torch.float32, device=feat.device)
+        L.check(L.load().bx_gap_fc_lsm_fwd(_p(feat), _p(w), _p(b), _p(gap), _p(logp), B, H * W, Cc, N, bx_dtype(feat.dtype), _stream()),
+                "bx_gap_fc_lsm_fwd")
+        ctx.shape, ctx.dt = (B, H, W, Cc), feat.dtype
+        ctx.save_for_backward(gap, logp, w, b)
+        return logp
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        gap, logp, w, b = ctx.saved_tensors
+        B, H, W, Cc = ctx.shape
+        N = w.shape[0]
+        dfeat = torch.empty(B, H, W, Cc, dtype=ctx.dt, device=gap.device) if ctx.needs_input_grad[0] else None
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dw, db = (new_grad(w), new_grad(b)) if need_w else (None, None)
+        L.check(L.load().bx_gap_fc_lsm_bwd(_p(dlogp.contiguous()), _p(logp), _p(gap), _p(w), _p(dfeat), _p(dw), _p(db), B, H * W, Cc, N,
+                                           bx_dtype(ctx.dt), _stream()), "bx_gap_fc_lsm_bwd")
+        return dfeat, dw, db
+
+
+class LinearLsmFn(torch.autograd.Function):
+    """Flatten -> Linear -> LogSoftmax on fp32 features (reference models.py:286-288)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        B, K = x.shape
+        N = w.shape[0]
+        logp = torch.empty(B, N, dtype=torch.float32, device=x.device)
+        L.check(L.load().bx_linear_lsm_fwd(_p(x), _p(w), _p(b), _p(logp), B, K, N, _stream()), "bx_linear_lsm_fwd")
+        ctx.save_for_backward(x, logp, w, b)
+        return logp
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        x, logp, w, b = ctx.saved_tensors
+        B, K = x.shape
+        N = w.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dw, db = (new_grad(w), new_grad(b)) if need_w else (None, None)
+        L.check(L.load().bx_linear_lsm_bwd(_p(dlogp.contiguous()), _p(logp), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, K, N, _stream()),
+                "bx_linear_lsm_bwd")
+        return dx, dw, db
+
+
+class FusionHeadFn(torch.autograd.Function):
+    """cat -> Linear(2N,Hd) -> ReLU -> Linear(Hd,N) -> LogSoftmax (reference XAI_Multimodality.py:1095-1105)."""
+
+    @staticmethod
+    def forward(ctx, e, s, w1, b1, w2, b2):
+        B, N = e.shape
+        Hd = w1.shape[0]
+        hidden = torch.empty(B, Hd, dtype=torch.float32, device=e.device)
+        logp = torch.empty(B, N, dtype=torch.float32, device=e.device)
+        e, s = e.contiguous(), s.contiguous()
+        L.check(L.load().bx_fusion_head_fwd(_p(e), _p(s), _p(w1), _p(b1), _p(w2), _p(b2), _p(hidden), _p(logp), B, N, Hd, _stream()),
+                "bx_fusion_head_fwd")
+        ctx.save_for_backward(e, s, hidden, logp, w1, b1, w2, b2)
+        return logp
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        e, s, hidden, logp, w1, b1, w2, b2 = ctx.saved_tensors
+        B, N = e.shape
+        Hd = w1.shape[0]
+        de = torch.empty_like(e) if ctx.needs_input_grad[0] else None
+        ds = torch.empty_like(s) if ctx.needs_input_grad[1] else None
+        need_w = any(ctx.needs_input_grad[2:])
+        dw1, db1, dw2, db2 = (new_grad(w1), new_grad(b1), new_grad(w2), new_grad(b2)) if need_w else (None,) * 4
+        L.check(L.load().bx_fusion_head_bwd(_p(dlogp.contiguous()), _p(logp), _p(hidden), _p(e), _p(s), _p(w1), _p(w2), _p(de), _p(ds),
+                                            _p(dw1), _p(db1), _p(dw2), _p(db2), B, N, Hd, _stream()), "bx_fusion_head_bwd")
+        return de, ds, dw1, db1, dw2, db2
+
+
+_REDUCTIONS = {"mean": 0, "batchmean": 1, "sum": 2}
+
+
+class KLDivFn(torch.autograd.Function):
+    """nn.KLDivLoss(reduction)(log_probs, target)  (reference XAI_Multimodality.py:1989,1599)."""
+
+    @staticmethod
+    def forward(ctx, logp, target, reduction, grad_scale):
+        B, N = logp.shape
+        loss = torch.empty((), dtype=torch.float32, device=logp.device)
+        dlogp = torch.empty_like(logp)
+        L.check(L.load().bx_kldiv_fwd_bwd(_p(logp.contiguous()), _p(target.contiguous().float()), _p(loss), _p(dlogp), B, N,
+                                          _REDUCTIONS[reduction], float(grad_scale), _stream()), "bx_kldiv_fwd_bwd")
+        ctx.save_for_backward(dlogp)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogp,) = ctx.saved_tensors
+        out = torch.empty_like(dlogp)
+        L.check(L.load().bx_scale_dev(_p(dlogp), _p(g.contiguous()), _p(out), dlogp.numel(), _stream()), "bx_scale_dev")
+        return out, None, None, None
+
+
+class EegFeaturesFn(torch.autograd.Function):
+    """EEGNet up to Flatten (reference models.py:271-285). x fp32 [B,1,Chans,T] -> feat fp32 [B, F2*(T//32)]."""
+
+    @staticmethod
+    def forward(ctx, x, c1w, bn1w, bn1b, dww, bn2w, bn2b, sepw, bn3w, bn3b, bufs, cfg):
+        lib = L.load()
+        _require_gpu(x, "eeg input")
+        B, _, Ch, T = x.shape
+        x = x.contiguous().float()
+        desc = L.EegDesc(B, Ch, T, cfg.F1, cfg.D, cfg.F2, cfg.K1, cfg.K2, cfg.P1, cfg.P2, 1 if cfg.training else 0, cfg.eps, cfg.momentum,
+                         float(cfg.dropout_p), cfg.salt, bx_dtype(cfg.dtype))
+        nsaved = lib.bx_eeg_saved_bytes(C.byref(desc))
+        if nsaved == 0:
+            raise RuntimeError("brainxai: unsupported EEGNet geometry (needs F1=8, D=2, F2=16, kernLength<=64, Chans<=64)")
+        saved = torch.empty(nsaved, dtype=torch.uint8, device=x.device)
+        ws = workspace(lib.bx_eeg_workspace(C.byref(desc)), x.device)
+        params = L.EegParams(_p(c1w), _p(bn1w), _p(bn1b), _p(bufs[0]), _p(bufs[1]), _p(bufs[2]), _p(dww), _p(bn2w), _p(bn2b), _p(bufs[3]),
+                             _p(bufs[4]), _p(bufs[5]), _p(sepw), _p(bn3w), _p(bn3b), _p(bufs[6]), _p(bufs[7]), _p(bufs[8]))
+        T2 = (T // cfg.P1) // cfg.P2
+        feat = torch.empty(B, cfg.F2 * T2, dtype=torch.float32, device=x.device)
+        seed = next_seed(x.device) if (cfg.training and cfg.dropout_p > 0) else None
+        L.check(lib.bx_eeg_features_fwd(C.byref(desc), C.byref(params), _p(x), _p(seed), _p(feat), _p(saved), _p(ws), ws.numel(), _stream()),
+                "bx_eeg_features_fwd")
+        ctx.desc, ctx.params, ctx.seed, ctx.bufs = desc, params, seed, bufs
+        ctx.save_for_backward(x, saved, c1w, bn1w, bn1b, dww, bn2w, bn2b, sepw, bn3w, bn3b)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        lib = L.load()
+        x, saved, c1w, bn1w, bn1b, dww, bn2w, bn2b, sepw, bn3w, bn3b = ctx.saved_tensors
+        need_w = any(ctx.needs_input_grad[1:10])
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gl = [new_grad(t) for t in (c1w, bn1w, bn1b, dww, bn2w, bn2b, sepw, bn3w, bn3b)] if need_w else [None] * 9
+        grads = L.EegGrads(*[_p(t) for t in gl])
+        ws = workspace(lib.bx_eeg_workspace(C.byref(ctx.desc)), x.device)
+        L.check(lib.bx_eeg_features_bwd(C.byref(ctx.desc), C.byref(ctx.params), _p(x), _p(dfeat.contiguous()), _p(ctx.seed), _p(saved),
+                                        C.byref(grads), _p(dx), _p(ws), ws.numel(), _stream()), "bx_eeg_features_bwd")
+        return (dx, *gl, None, None)
+
+
+def block_cfg(**kw) -> SimpleNamespace:
+    base = dict(pool="max", training=False, dropout_p=0.0, eps=1e-5, momentum=0.1, salt=0, preact=0, capture=None)
+    base.update(kw)
+    return SimpleNamespace(**base)

