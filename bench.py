@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: multimodal (SpectrogramCNN + EEGNet + fusion) TRAINING samples/sec on synthetic
+[64,4,128,256] spectrograms + [64,10000,19] raw EEG per GPU (BASELINE.json configs[1]; configs[2] under
+--gpus 8), with Grad-CAM maps/sec, the dominant kernel's roofline and the CPU oracle timed beside it.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = zero_grad -> forward -> KLDiv -> backward -> (RCCL all-reduce of the flat gradient arena) -> fused
+AdamW over one B=64 batch per rank, inputs resident in HBM.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+B, CIN, H, W, CHANS, RAW_LEN, T = 64, 4, 128, 256, 19, 10000, 2000
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gradcam", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def conv_work(bx, dtype_bytes):
+    """Algorithmic FLOPs / bytes of every conv3x3 launch of one training step:
+    forward 15 launches, data-gradient 10 (block1.conv1's is skipped: the input needs no gradient... but
+    conv1 of blocks 2-5 do), weight-gradient 15.  Returns dict kind -> (flops, bytes, launches)."""
+    stages = [(8, 16, 128, 256), (16, 32, 64, 128), (32, 64, 32, 64), (64, 128, 16, 32), (128, 256, 8, 16)]
+    out = {"fwd": [0.0, 0.0, 0], "dgrad": [0.0, 0.0, 0], "wgrad": [0.0, 0.0, 0]}
+    for si, (cin_p, c, h, w) in enumerate(stages):
+        px = bx * h * w
+        for k, ci in enumerate((cin_p, c, c)):
+            fl = 2.0 * 9 * ci * c * px
+            by = px * (ci + c) * dtype_bytes
+            out["fwd"][0] += fl; out["fwd"][1] += by; out["fwd"][2] += 1
+            out["wgrad"][0] += fl; out["wgrad"][1] += by; out["wgrad"][2] += 1
+            if not (si == 0 and k == 0):
+                extra = px * (ci if k else 0) * dtype_bytes      # ReLU-mask read (conv2/3) or skip addend (conv1)
+                out["dgrad"][0] += fl; out["dgrad"][1] += by + px * ci * dtype_bytes; out["dgrad"][2] += 1
+                del extra
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import brainxai
+    from brainxai import ops
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    # ---- synthetic inputs, seed 42 + rank, generated on the host like a DataLoader would
+    g = torch.Generator().manual_seed(42 + rank)
+    spec = torch.rand(B, CIN, H, W, generator=g).to(dev)
+    raw = (torch.randn(B, RAW_LEN, CHANS, generator=g) * 100.0)
+    flat = raw.view(-1)
+    k = flat.numel() // 1000
+    idx = torch.randint(0, flat.numel(), (2 * k,), generator=g)
+    flat[idx[:k]] = float("nan"); flat[idx[k:]] *= 50.0
+    raw = raw.to(dev)
+    labels = torch.softmax(torch.randn(B, 6, generator=g), 1).to(dev)
+    eeg = brainxai.stack_eeg(raw)                      # [B,1,19,2000], resident
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        brainxai.stack_eeg(raw)
+    torch.cuda.synchronize()
+    stacker_sps = 3 * B / (time.perf_counter() - t0)
+
+    torch.manual_seed(42)
+    model = brainxai.build_multimodal(CHANS, T, CIN, dropout=0.5, compute_dtype=cdt).to(dev).train()
+    ddp = brainxai.DataParallel(model) if world > 1 else None
+    opt = brainxai.FlatAdamW(model.parameters(), lr=1e-3)
+    crit = brainxai.KLDivLoss()
+
+    def step():
+        return brainxai.train_step(model, opt, eeg, spec, labels, crit, ddp=ddp)
+
+    for _ in range(args.warmup):
+        step()
+    # ---- timed region: exactly K steps between barrier + synchronize on both sides
+    prof = []
+    ops.CONV_PROFILE = prof
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.CONV_PROFILE = None
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    loss_val = float(loss)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    # ---- dominant kernel (conv3x3 family): HIP-event durations recorded around each launch in the timed region
+    kinds = {}
+    for kind, ev0, ev1 in prof:
+        kinds.setdefault(kind, []).append(ev0.elapsed_time(ev1) * 1e-3)
+    work = conv_work(B, 2 if args.dtype == "bf16" else 4)
+    conv_time = sum(sum(v) for v in kinds.values()) / args.steps            # seconds per step in conv kernels
+    conv_flops = sum(w[0] for w in work.values())
+    conv_bytes = sum(w[1] for w in work.values())
+    n_launch = sum(len(v) for v in kinds.values())
+    roofline = None
+    extra = {}
+    if conv_time > 0:
+        ach_gbs = conv_bytes / conv_time / 1e9
+        ach_tf = conv_flops / conv_time / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv3x3 fwd+dgrad+wgrad (%d launches/step)" % (n_launch // max(args.steps, 1)),
+                    "achieved": round(ach_tf, 3), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                    "frac": round(ach_tf / MFMA_PEAK_TFLOPS[args.dtype], 5), "traffic": None,
+                    "avg_launch_us": round(conv_time / max(n_launch / args.steps, 1) * 1e6, 2),
+                    "share_of_step": round(conv_time / (elapsed / args.steps), 3)}
+        extra["roofline_hbm"] = {"bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(ach_gbs / HBM_PEAK_GBS, 5)}
+        extra["conv_ms_per_step"] = {k_: round(sum(v) / args.steps * 1e3, 3) for k_, v in kinds.items()}
+    # whole-step algorithmic roofline (5.71 GFLOP and 52.2 MB bf16 / 104.5 MB fp32 per sample)
+    per_sample_bytes = 52.2e6 if args.dtype == "bf16" else 104.5e6
+    extra["step_roofline"] = {"hbm_frac": round(per_sample_bytes * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
+                              "mfma_frac": round(5.71e9 * B / (elapsed / args.steps) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 5)}
+
+    # ---- Grad-CAM maps/sec (configs[3] shape: eval, target block5, all 6 classes, upsampled to 128x256)
+    gradcam = None
+    if not args.no_gradcam:
+        model.eval()
+        for _ in range(2):
+            brainxai.grad_cam(model, eeg, spec, class_idx="all")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            maps = brainxai.grad_cam(model, eeg, spec, class_idx="all")
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt)
+        gradcam = {"maps_per_sec": round(world * reps * maps.shape[0] * maps.shape[1] / dt, 1),
+                   "samples_per_sec": round(world * reps * B / dt, 1), "classes": int(maps.shape[1]), "target": "spectrogram_model.block5"}
+        model.train()
+
+    # ---- CPU baseline: the oracle (a port of the reference's PyTorch path) on this box's host cores, rank 0, N=1 only
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ref_torch as O
+        # the GPU box shows every host CPU (os.cpu_count() = 256) but grants one GPU a 16-CPU share:
+        # more threads than that only oversubscribes (measured 0.99 samples/s at 256 threads)
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        torch.set_num_threads(max(1, min(avail, 16)))
+        ref = O.build_multimodal(CHANS, T, CIN, dropout=0.5).train()
+        ropt = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+        ce, cs, cl = eeg.cpu(), spec.cpu(), labels.cpu()
+        O.train_step(ref, ropt, ce, cs, cl)
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_steps):
+            O.train_step(ref, ropt, ce, cs, cl)
+        cdt_s = time.perf_counter() - t0
+        cpu = {"value": round(args.cpu_steps * B / cdt_s, 2), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{args.cpu_steps} training steps of the same B={B} batch (oracle/ref_torch.py, fp32, "
+                         f"{torch.get_num_threads()} torch threads; host shows {os.cpu_count()} CPUs, share is 16)"}
+        if gradcam is not None:
+            ref.eval()
+            t0 = time.perf_counter()
+            O.grad_cam(ref, ce[:16], cs[:16], class_idx="all")
+            cpu["gradcam_maps_per_sec"] = round(16 * 6 / (time.perf_counter() - t0), 2)
+
+    if rank == 0:
+        line = {"metric": "samples/sec train (multimodal SpectrogramCNN+EEGNet fusion, B=64/GPU, 4x128x256 spectro + 10000x19 EEG)",
+                "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": "configs[1]: multimodal train step, B=64 per GPU, spec [64,4,128,256] + EEG [64,1,19,2000] (stacked from [64,10000,19])",
+                           "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": "AdamW(1e-3) fused flat arena",
+                           "loss": "KLDivLoss(mean)", "dropout": 0.5, "params": sum(p.numel() for p in model.parameters())},
+                "final_loss": round(loss_val, 6), "gradcam": gradcam, "stacker_samples_per_sec": round(stacker_sps, 1),
+                "roofline": roofline, "cpu_baseline": cpu}
+        line.update(extra)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,25 @@ from . import _lib as L
 
 CONV_ALGO = L.BX_ALGO_AUTO        # module-level switch used by tests to force the direct / MFMA kernels
 WGRAD_ALGO = L.BX_ALGO_AUTO
+CONV_PROFILE = None               # bench.py sets a list: every conv launch appends (kind, start_event, end_event)
+
+
+class _Timed:
+    """HIP-event bracket around one launch on the current stream (only active while CONV_PROFILE is a list)."""
+
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __enter__(self):
+        if CONV_PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if CONV_PROFILE is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            CONV_PROFILE.append((self.kind, self.e0, e1))
 
 
 def _require_gpu(t: torch.Tensor, what: str):
@@ -159,8 +178,9 @@ def _conv(x, packed, bias, mask_src, addend, relu: bool, dtype):
         raise RuntimeError(f"brainxai: conv input has {Ci} channels, packed weights expect {ip}")
     y = torch.empty(B, H, W, op, dtype=dtype, device=x.device)
     algo = CONV_ALGO if x.dtype == torch.bfloat16 else L.BX_ALGO_DIRECT
-    L.check(L.load().bx_conv3x3(_p(x), _p(pf), _p(pm), _p(bias), _p(mask_src), _p(addend), _p(y), B, H, W, Ci, op,
-                                bx_dtype(dtype), L.BX_EPI_RELU if relu else 0, algo, _stream()), "bx_conv3x3")
+    with _Timed("fwd" if bias is not None else "dgrad"):
+        L.check(L.load().bx_conv3x3(_p(x), _p(pf), _p(pm), _p(bias), _p(mask_src), _p(addend), _p(y), B, H, W, Ci, op,
+                                    bx_dtype(dtype), L.BX_EPI_RELU if relu else 0, algo, _stream()), "bx_conv3x3")
     return y
 
 
@@ -173,8 +193,9 @@ def _wgrad(x, dz, w: torch.Tensor, b: torch.Tensor):
     need = lib.bx_conv3x3_wgrad_workspace(B, H, W, Cip, Co, dt, algo)
     ws = workspace(need, x.device)
     dw, db = new_grad(w), new_grad(b)
-    L.check(lib.bx_conv3x3_wgrad(_p(x), _p(dz), _p(dw), _p(db), B, H, W, w.shape[1], Cip, Co, dt, algo, _p(ws), ws.numel(), _stream()),
-            "bx_conv3x3_wgrad")
+    with _Timed("wgrad"):
+        L.check(lib.bx_conv3x3_wgrad(_p(x), _p(dz), _p(dw), _p(db), B, H, W, w.shape[1], Cip, Co, dt, algo, _p(ws), ws.numel(), _stream()),
+                "bx_conv3x3_wgrad")
     return dw, db
 
 
