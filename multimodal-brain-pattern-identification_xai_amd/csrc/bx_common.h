@@ -94,20 +94,48 @@ __device__ __forceinline__ void bilinear_src(int o, float scale, int in_size, in
   l1 = s - (float)i0;
 }
 
-// forward 2: statistics -> (scale, shift); running-stat update (unbiased variance, momentum)
+// Sum NV per-workgroup partial vectors in double, fixed order: partial k, vector v, channel c lives at
+// partials[(k*NV + v)*C + c].  256 threads: thread = (slice, channel); slices are combined through LDS in
+// slice order, so the result is deterministic.  Returns the totals in out[] for threads < C.
+template <int NV>
+__device__ __forceinline__ void sum_partials_256(const float* __restrict__ partials, int nblk, int C, double out[NV]) {
+  __shared__ double sp[NV][1024];
+  const int nslice = (int)blockDim.x / C;  // C in {8,16,...,256}; blockDim 256..1024
+  const int c = threadIdx.x % C, slice = threadIdx.x / C;
+  double acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+  if (slice < nslice)
+    for (int k = slice; k < nblk; k += nslice)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[v] += (double)partials[((size_t)k * NV + v) * C + c];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) sp[v][threadIdx.x] = acc[v];
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      double s = 0.0;
+      for (int sl = 0; sl < nslice; ++sl) s += sp[v][sl * C + threadIdx.x];
+      out[v] = s;
+    }
+  }
+}
+
+// forward 2: statistics -> (scale, shift); running-stat update (unbiased variance, momentum).  Launch with 256 threads.
 static __global__ void k_bn_finalize(const float* __restrict__ partials, int nblk, double count, int C, int training,
                               const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
                               float* __restrict__ rvar, int64_t* __restrict__ nbt, float momentum, float eps,
                               float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
                               float* __restrict__ save_invstd) {
+  double tot[2] = {0.0, 0.0};
+  if (training) sum_partials_256<2>(partials, nblk, C, tot);
   const int c = threadIdx.x;
   if (c >= C) return;
   float mean, invstd;
   if (training) {
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < nblk; ++k) { s += partials[((size_t)k * 2 + 0) * C + c]; q += partials[((size_t)k * 2 + 1) * C + c]; }
-    const double m = s / count;
-    double var = q / count - m * m;
+    const double m = tot[0] / count;
+    double var = tot[1] / count - m * m;
     if (var < 0.0) var = 0.0;
     mean = (float)m;
     invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -125,7 +153,6 @@ static __global__ void k_bn_finalize(const float* __restrict__ partials, int nbl
   save_mean[c] = mean;
   save_invstd[c] = invstd;
 }
-
 
 #define BX_DISPATCH_DTYPE(dtype, T, ...) \
   do { if ((dtype) == BX_F32) { typedef float T; __VA_ARGS__; } else { typedef bf16_t T; __VA_ARGS__; } } while (0)

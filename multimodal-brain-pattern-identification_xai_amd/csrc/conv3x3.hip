@@ -32,15 +32,18 @@ __global__ void k_pack3x3(const float* __restrict__ w, float* __restrict__ wp, i
 
 extern "C" int bx_conv3x3_pack(const float* w_oihw, float* packed_f32, void* packed_mfma, int Cout, int Cin,
                                int I_p, int O_p, int transpose_flip, bxStream stream) {
-  BX_REQUIRE(w_oihw && packed_f32 && Cout > 0 && Cin > 0, "bx_conv3x3_pack: bad arguments");
+  BX_REQUIRE(w_oihw && (packed_f32 || packed_mfma) && Cout > 0 && Cin > 0, "bx_conv3x3_pack: bad arguments");
   const int I = transpose_flip ? Cout : Cin, O = transpose_flip ? Cin : Cout;
   BX_REQUIRE(I_p >= I && O_p >= O && I_p % 8 == 0 && O_p % 8 == 0, "bx_conv3x3_pack: padded dims I_p=%d O_p=%d must cover %d/%d and be multiples of 8", I_p, O_p, I, O);
   hipStream_t s = (hipStream_t)stream;
   const int n = 9 * I_p * O_p;
-  hipLaunchKernelGGL(k_pack3x3, dim3(bx_ceil_div(n, 256) > 1024 ? 1024 : bx_ceil_div(n, 256)), dim3(256), 0, s,
-                     w_oihw, packed_f32, Cout, Cin, I_p, O_p, transpose_flip);
-  BX_CHECK_LAUNCH("bx_conv3x3_pack");
+  if (packed_f32) {
+    hipLaunchKernelGGL(k_pack3x3, dim3(bx_ceil_div(n, 256) > 1024 ? 1024 : bx_ceil_div(n, 256)), dim3(256), 0, s,
+                       w_oihw, packed_f32, Cout, Cin, I_p, O_p, transpose_flip);
+    BX_CHECK_LAUNCH("bx_conv3x3_pack");
+  }
   if (packed_mfma) {
+    if (!bx_conv3x3_packed_mfma_bytes(I_p, O_p)) BX_FAIL(BX_EUNSUPPORTED, "bx_conv3x3_pack: no MFMA operand layout for I_p=%d O_p=%d", I_p, O_p);
     bx_conv3x3_mfma_pack_launch(w_oihw, packed_mfma, Cout, Cin, I_p, O_p, transpose_flip, s);
     BX_CHECK_LAUNCH("bx_conv3x3_pack(mfma)");
   }

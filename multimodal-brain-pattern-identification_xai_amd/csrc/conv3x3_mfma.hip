@@ -1,15 +1,411 @@
-// MFMA implicit-GEMM 3x3 convolution (bf16 operands, fp32 accumulate) -- forward / data-gradient and
-// weight-gradient.  (placeholder: the entry points report "unsupported" until the kernels land)
+// MFMA implicit-GEMM 3x3 convolution for gfx950: bf16 operands, fp32 accumulate.
+//
+// Forward / data-gradient (k_conv_mfma):  D[cout][pixel] = sum_{tap,cin} Wm[cout][(tap,cin)] * X[(tap,cin)][pixel]
+//   v_mfma_f32_16x16x32_bf16:  A = weights  (row = cout = lane&15, k = 8*(lane>>4)+j)
+//                              B = input    (k = 8*(lane>>4)+j,    col = pixel = lane&15)
+//                              D            (col = pixel = lane&15, row = cout = 4*(lane>>4)+reg)
+//   A workgroup (4 waves) owns an 8 x TW pixel tile and 16*NC output channels.  Input channels are walked
+//   in chunks of CK = min(Ci,64): the (8+2) x (TW+2) halo tile of the chunk is staged once in LDS
+//   ([pixel][CK] bf16, 16-byte chunks XOR-swizzled so that every ds_read_b128 of a B fragment is
+//   conflict-free) and re-read by all 9 taps -- the 9x input reuse never touches L2.  The K dimension of a
+//   chunk is (tap, cin) flattened, 32 per MFMA; for CK < 32 one MFMA spans 2 or 4 taps (each lane group
+//   reads its own tap's pixel).  Weights are pre-packed by k_pack_mfma in exactly the A-fragment order
+//   [chunk][kstep][cout][32] and come straight from L2 (1 KiB contiguous per wave load).
+//   Each lane ends up with 4 consecutive output channels of one pixel -> 8-byte NHWC stores after the fused
+//   epilogue (bias, ReLU | ReLU-mask of the producing layer, skip-gradient addend).
 #include "bx_common.h"
 
-extern "C" size_t bx_conv3x3_packed_mfma_bytes(int I_p, int O_p) { (void)I_p; (void)O_p; return 0; }
-int bx_conv3x3_mfma_supported(int Ci, int Co, int dtype) { (void)Ci; (void)Co; (void)dtype; return 0; }
-void bx_conv3x3_mfma_pack_launch(const float*, void*, int, int, int, int, int, hipStream_t) {}
-int bx_conv3x3_mfma_launch(const void*, const void*, const float*, const void*, const void*, void*, int, int, int, int, int, int, hipStream_t) {
-  BX_FAIL(BX_EUNSUPPORTED, "MFMA conv path not built");
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+static inline int mfma_ck(int Ci) { return Ci < 64 ? Ci : 64; }
+static inline int mfma_ks(int ck) { return (9 * ck + 31) / 32; }
+
+int bx_conv3x3_mfma_supported(int Ci, int Co, int dtype) {
+  if (dtype != BX_BF16) return 0;
+  if (!(Ci == 8 || Ci == 16 || Ci == 32 || (Ci >= 64 && Ci % 64 == 0))) return 0;
+  return Co >= 16 && Co % 16 == 0;
 }
-size_t bx_wgrad_mfma_workspace(int, int, int, int, int) { return 0; }
-int bx_wgrad_mfma_supported(int, int, int) { return 0; }
-int bx_wgrad_mfma_launch(const void*, const void*, float*, float*, int, int, int, int, int, int, void*, size_t, hipStream_t) {
-  BX_FAIL(BX_EUNSUPPORTED, "MFMA wgrad path not built");
+extern "C" size_t bx_conv3x3_packed_mfma_bytes(int I_p, int O_p) {
+  if (!bx_conv3x3_mfma_supported(I_p, O_p, BX_BF16)) return 0;
+  const int ck = mfma_ck(I_p);
+  return (size_t)(I_p / ck) * mfma_ks(ck) * O_p * 32 * sizeof(bf16_t);
+}
+
+// Wp[chunk][s][o][kk]:  q = s*32+kk, tap = q / CK, i = chunk*CK + q % CK
+//   forward (tf=0): W[o][i][tap];  data-gradient (tf=1): W[i][o][8-tap]   (zero outside the logical ranges)
+__global__ void k_pack_mfma(const float* __restrict__ w, bf16_t* __restrict__ wp, int Cout, int Cin, int I_p, int O_p, int tf,
+                            int ck, int ks, size_t n) {
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(idx & 31);
+    const int o = (int)((idx >> 5) % O_p);
+    const int s = (int)((idx / ((size_t)32 * O_p)) % ks);
+    const int chunk = (int)(idx / ((size_t)32 * O_p * ks));
+    const int q = s * 32 + kk, tap = q / ck, i = chunk * ck + q % ck;
+    float v = 0.f;
+    if (tap < 9) {
+      if (!tf) { if (i < Cin && o < Cout) v = w[((size_t)o * Cin + i) * 9 + tap]; }
+      else     { if (i < Cout && o < Cin) v = w[((size_t)i * Cin + o) * 9 + (8 - tap)]; }
+    }
+    wp[idx] = f2bf(v);
+  }
+}
+void bx_conv3x3_mfma_pack_launch(const float* w_oihw, void* packed, int Cout, int Cin, int I_p, int O_p, int tf, hipStream_t s) {
+  const size_t bytes = bx_conv3x3_packed_mfma_bytes(I_p, O_p);
+  if (!bytes) return;
+  const size_t n = bytes / sizeof(bf16_t);
+  const int ck = mfma_ck(I_p);
+  const int grid = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  hipLaunchKernelGGL(k_pack_mfma, dim3(grid), dim3(256), 0, s, w_oihw, (bf16_t*)packed, Cout, Cin, I_p, O_p, tf, ck, mfma_ks(ck), n);
+}
+
+template <int CK>
+__device__ __forceinline__ int lds_chunk(int c, int p) {
+  if (CK == 32) return c ^ ((p >> 1) & 3);
+  if (CK == 64) return c ^ (p & 7);
+  return c;
+}
+
+template <int CK, int NC, int TW>
+__global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+    const bf16_t* __restrict__ mask_src, const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
+    int H, int W, int Ci, int Co, int relu, int tiles_x, int tiles_y) {
+  constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CKB = CK * 2, NCH = CK / 8, KS = (9 * CK + 31) / 32;
+  constexpr int MP = TH * TW / 64;          // 16-pixel tiles per wave
+  constexpr int TPR = TW / 16;              // 16-pixel tiles per tile row
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int bid = blockIdx.x;
+  const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, b = bid / (tiles_x * tiles_y);
+  const int y0 = ty * TH, x0 = tx * TW, co_base = blockIdx.y * (NC * 16);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+
+  f32x4 acc[MP][NC];
+#pragma unroll
+  for (int i = 0; i < MP; ++i)
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nchunk = Ci / CK;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    __syncthreads();
+    for (int u = threadIdx.x; u < HH * HWID * NCH; u += 256) {
+      const int p = u / NCH, c = u % NCH;
+      const int hy = p / HWID, hx = p % HWID;
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+        v = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * Ci + chunk * CK + c * 8);
+      *reinterpret_cast<uint4*>(lds + p * CKB + 16 * lds_chunk<CK>(c, p)) = v;
+    }
+    __syncthreads();
+    const bf16_t* wchunk = wp + (size_t)chunk * KS * Co * 32;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int q0 = s * 32 + 8 * g;
+      int tap = q0 / CK;
+      const int c = (q0 % CK) / 8;
+      const bool valid = tap < 9;
+      if (!valid) tap = 0;
+      const int dy = tap / 3, dx = tap - 3 * dy;
+      bf16x8 a[NC];
+#pragma unroll
+      for (int n = 0; n < NC; ++n)
+        a[n] = *reinterpret_cast<const bf16x8*>(wchunk + ((size_t)s * Co + co_base + n * 16 + li) * 32 + 8 * g);
+#pragma unroll
+      for (int i = 0; i < MP; ++i) {
+        const int t = wave * MP + i;
+        const int p = (t / TPR + dy) * HWID + (t % TPR) * 16 + li + dx;
+        bf16x8 bv = *reinterpret_cast<const bf16x8*>(lds + p * CKB + 16 * lds_chunk<CK>(c, p));
+        if (!valid) bv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int n = 0; n < NC; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], bv, acc[i][n], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: lane = (pixel li of tile t, output channels co_base + n*16 + 4g .. +3)
+#pragma unroll
+  for (int i = 0; i < MP; ++i) {
+    const int t = wave * MP + i;
+    const int oy = y0 + t / TPR, ox = x0 + (t % TPR) * 16 + li;
+    if (oy >= H || ox >= W) continue;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      const int co = co_base + n * 16 + 4 * g;
+      const size_t o = (((size_t)b * H + oy) * W + ox) * Co + co;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[i][n][r] + (bias ? bias[co + r] : 0.f);
+        if (relu) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (mask_src) {
+        const uint2 m = *reinterpret_cast<const uint2*>(mask_src + o);
+        // bf16 > 0  <=>  sign bit clear and magnitude non-zero
+        const uint32_t mm[4] = {m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (mm[r] != 0u && mm[r] < 0x8000u) ? v[r] : 0.f;
+      }
+      if (addend) {
+        const uint2 a2 = *reinterpret_cast<const uint2*>(addend + o);
+        v[0] += __uint_as_float(a2.x << 16); v[1] += __uint_as_float(a2.x & 0xffff0000u);
+        v[2] += __uint_as_float(a2.y << 16); v[3] += __uint_as_float(a2.y & 0xffff0000u);
+      }
+      uint2 out;
+      out.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+      out.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      *reinterpret_cast<uint2*>(y + o) = out;
+    }
+  }
+}
+
+template <int CK, int NC, int TW>
+static int launch_conv(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
+                       int B, int H, int W, int Ci, int Co, int relu, hipStream_t s) {
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + 7) / 8;
+  const size_t lds = (size_t)10 * (TW + 2) * CK * 2;
+  dim3 grid((unsigned)(tiles_x * tiles_y * B), (unsigned)(Co / (16 * NC)));
+  hipLaunchKernelGGL((k_conv_mfma<CK, NC, TW>), grid, dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)wp, bias,
+                     (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y);
+  BX_CHECK_LAUNCH("bx_conv3x3(mfma)");
+  return BX_OK;
+}
+template <int CK, int NC>
+static int launch_conv_tw(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
+                          int B, int H, int W, int Ci, int Co, int relu, hipStream_t s) {
+  if (W <= 16) return launch_conv<CK, NC, 16>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
+  return launch_conv<CK, NC, 32>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
+}
+template <int CK>
+static int launch_conv_nc(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
+                          int B, int H, int W, int Ci, int Co, int relu, hipStream_t s) {
+  if (Co % 64 == 0) return launch_conv_tw<CK, 4>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
+  if (Co % 32 == 0) return launch_conv_tw<CK, 2>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
+  return launch_conv_tw<CK, 1>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
+}
+int bx_conv3x3_mfma_launch(const void* x, const void* packed_mfma, const float* bias, const void* relu_mask_src,
+                           const void* addend, void* y, int B, int H, int W, int Ci, int Co, int flags, hipStream_t s) {
+  const int relu = (flags & BX_EPI_RELU) ? 1 : 0;
+  switch (mfma_ck(Ci)) {
+    case 8:  return launch_conv_nc<8>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s);
+    case 16: return launch_conv_nc<16>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s);
+    case 32: return launch_conv_nc<32>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s);
+    default: return launch_conv_nc<64>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s);
+  }
+}
+
+// ================================================================================================
+// Weight gradient (k_wgrad_mfma):  dW[tap][cin][cout] = sum_pixels X[pixel+tap][cin] * dZ[pixel][cout]
+//   v_mfma_f32_16x16x32_bf16 with the PIXEL index as K:  A = X^T (row = cin, k = 32 pixels), B = dZ (k = pixels,
+//   col = cout), D[cin][cout] per tap.  Both operands need "8 consecutive pixels of one channel" per lane while
+//   the tiles sit in LDS pixel-major ([pixel][channel], as they stream in from NHWC) -- exactly what
+//   ds_read_b64_tr_b16 delivers (4 pixel rows x 16 channels per 16-lane group, transposed on the way to the
+//   registers); every lane supplies its own row address, so the 9 tap shifts cost nothing.
+//   A workgroup owns a (16*MA cin) x (16*NB cout) slice of dW for all 9 taps and walks a contiguous range of
+//   8 x TW pixel tiles; its 4 waves split each tile's K-steps (rows) and keep 9*MA*NB accumulator tiles in
+//   registers across the whole range.  At the end the waves are summed through LDS in a fixed order and the
+//   slice goes to the workspace as one partial; k_wgrad_reduce2 sums the partials in a fixed order
+//   (deterministic, no atomics) and writes OIHW.  The bias gradient rides along on the dZ fragments.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 tr_read8(const char* lds, int off0, int off1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + off0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + off1));
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int MA, int NB, int TW>
+__global__ __launch_bounds__(256) void k_wgrad_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dz, float* __restrict__ partial,
+    int H, int W, int Ci_p, int Co, int tiles_x, int tiles_y, int ntiles, int tiles_per_split) {
+  constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CIT = 16 * MA, COT = 16 * NB, XB = CIT * 2, ZB = COT * 2;
+  constexpr int KPW = TH * TW / 32 / 4;                 // K-steps (32 pixels) per wave per tile
+  constexpr int XS_BYTES = HH * HWID * XB, ZS_BYTES = TH * TW * ZB;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* xs = lds;
+  char* zs = lds + XS_BYTES;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+  const int q = li >> 2, pc = li & 3;
+  const int ci0 = blockIdx.y * CIT, co0 = blockIdx.z * COT;
+  const bool want_bias = blockIdx.y == 0;
+
+  f32x4 acc[9][MA][NB];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int m = 0; m < MA; ++m)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[t][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n) bsum[n] = 0.f;
+
+  const int t_begin = blockIdx.x * tiles_per_split;
+  const int t_end = t_begin + tiles_per_split < ntiles ? t_begin + tiles_per_split : ntiles;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    __syncthreads();
+    for (int u = threadIdx.x; u < HH * HWID * (CIT / 8); u += 256) {
+      const int p = u / (CIT / 8), c = u % (CIT / 8);
+      const int iy = y0 + p / HWID - 1, ix = x0 + p % HWID - 1;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W && ci0 + c * 8 < Ci_p)
+        v = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * Ci_p + ci0 + c * 8);
+      *reinterpret_cast<uint4*>(xs + p * XB + c * 16) = v;
+    }
+    for (int u = threadIdx.x; u < TH * TW * (COT / 8); u += 256) {
+      const int p = u / (COT / 8), c = u % (COT / 8);
+      const int iy = y0 + p / TW, ix = x0 + p % TW;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (iy < H && ix < W) v = *reinterpret_cast<const uint4*>(dz + (((size_t)b * H + iy) * W + ix) * Co + co0 + c * 8);
+      *reinterpret_cast<uint4*>(zs + p * ZB + c * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KPW; ++ks) {
+      const int step = wave * KPW + ks;
+      int row[2], col[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kp = 8 * g + 4 * h + q;                       // pixel of this K-step whose row address the lane supplies
+        if (TW == 32) { row[h] = step; col[h] = kp; }
+        else          { row[h] = 2 * step + (kp >> 4); col[h] = kp & 15; }
+      }
+      bf16x8 bfr[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        bfr[n] = tr_read8(zs, (row[0] * TW + col[0]) * ZB + (n * 16 + 4 * pc) * 2, (row[1] * TW + col[1]) * ZB + (n * 16 + 4 * pc) * 2);
+        if (want_bias) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum[n] += __uint_as_float(((uint32_t)(unsigned short)bfr[n][j]) << 16);
+        }
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int m = 0; m < MA; ++m) {
+          const bf16x8 afr = tr_read8(xs, ((row[0] + dy) * HWID + col[0] + dx) * XB + (m * 16 + 4 * pc) * 2,
+                                      ((row[1] + dy) * HWID + col[1] + dx) * XB + (m * 16 + 4 * pc) * 2);
+#pragma unroll
+          for (int n = 0; n < NB; ++n) acc[tap][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[n], acc[tap][m][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- ordered cross-wave sum through LDS, then one partial per workgroup
+  float* red = reinterpret_cast<float*>(lds);          // [9*MA*NB*4][64]
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int m = 0; m < MA; ++m)
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int idx = (((t * MA + m) * NB + n) * 4 + r) * 64 + lane;
+              red[idx] = (w == 0 ? 0.f : red[idx]) + acc[t][m][n][r];
+            }
+    }
+  }
+  __syncthreads();
+  const size_t per_split = (size_t)9 * Ci_p * Co + Co;
+  float* out = partial + (size_t)blockIdx.x * per_split;
+  for (int idx = wave; idx < 9 * MA * NB * 4; idx += 4) {
+    const int r = idx & 3, n = (idx >> 2) % NB, m = (idx >> 2) / NB % MA, t = (idx >> 2) / (NB * MA);
+    const int cin = ci0 + m * 16 + 4 * g + r, cout = co0 + n * 16 + li;
+    if (cin < Ci_p) out[((size_t)t * Ci_p + cin) * Co + cout] = red[idx * 64 + lane];
+  }
+  if (want_bias) {
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      float v = bsum[n];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 16) red[(wave * NB + n) * 16 + lane] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < COT) {
+      const int n = threadIdx.x >> 4, c = threadIdx.x & 15;
+      out[(size_t)9 * Ci_p * Co + co0 + threadIdx.x] =
+          red[(0 * NB + n) * 16 + c] + red[(1 * NB + n) * 16 + c] + red[(2 * NB + n) * 16 + c] + red[(3 * NB + n) * 16 + c];
+    }
+  }
+}
+
+// sum the partials in a fixed order: 64 outputs x 4 slices per workgroup, slices combined through LDS
+__global__ __launch_bounds__(256) void k_wgrad_reduce2(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
+                                                        int nsplit, int Cin, int Ci_p, int Co) {
+  __shared__ float sm[4][64];
+  const size_t per_split = (size_t)9 * Ci_p * Co + Co;
+  const int o = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const size_t idx = (size_t)blockIdx.x * 64 + o;
+  float s = 0.f;
+  if (idx < per_split)
+    for (int c = part; c < nsplit; c += 4) s += partial[(size_t)c * per_split + idx];
+  sm[part][o] = s;
+  __syncthreads();
+  if (part == 0 && idx < per_split) {
+    s = sm[0][o] + sm[1][o] + sm[2][o] + sm[3][o];
+    if (idx < (size_t)9 * Ci_p * Co) {
+      const int co = (int)(idx % Co), ci = (int)((idx / Co) % Ci_p), t = (int)(idx / ((size_t)Co * Ci_p));
+      if (ci < Cin) dw[((size_t)co * Cin + ci) * 9 + t] = s;
+    } else if (db) {
+      db[idx - (size_t)9 * Ci_p * Co] = s;
+    }
+  }
+}
+
+struct WgradPlan { int ma, nb, tw, tiles_x, tiles_y, ntiles, ytiles, ztiles, nsplit, tps; size_t lds; };
+static WgradPlan wgrad_plan(int B, int H, int W, int Ci_p, int Co) {
+  WgradPlan p;
+  p.ma = Ci_p >= 32 ? 2 : 1;
+  p.nb = Co >= 32 ? 2 : 1;
+  p.tw = W <= 16 ? 16 : 32;
+  p.tiles_x = (W + p.tw - 1) / p.tw; p.tiles_y = (H + 7) / 8; p.ntiles = p.tiles_x * p.tiles_y * B;
+  p.ytiles = (Ci_p + 16 * p.ma - 1) / (16 * p.ma); p.ztiles = Co / (16 * p.nb);
+  int want = 1024 / (p.ytiles * p.ztiles);
+  if (want < 1) want = 1;
+  if (want > p.ntiles) want = p.ntiles;
+  p.tps = (p.ntiles + want - 1) / want;
+  p.nsplit = (p.ntiles + p.tps - 1) / p.tps;
+  const size_t stage = (size_t)10 * (p.tw + 2) * 32 * p.ma + (size_t)8 * p.tw * 32 * p.nb;
+  const size_t red = (size_t)9 * p.ma * p.nb * 4 * 64 * sizeof(float);
+  p.lds = stage > red ? stage : red;
+  return p;
+}
+int bx_wgrad_mfma_supported(int Ci_p, int Co, int dtype) {
+  return dtype == BX_BF16 && Ci_p % 8 == 0 && Co % 16 == 0 && (Co < 32 || Co % 32 == 0) && (Ci_p < 32 || Ci_p % 32 == 0);
+}
+size_t bx_wgrad_mfma_workspace(int B, int H, int W, int Ci_p, int Co) {
+  const WgradPlan p = wgrad_plan(B, H, W, Ci_p, Co);
+  return (size_t)p.nsplit * ((size_t)9 * Ci_p * Co + Co) * sizeof(float);
+}
+template <int MA, int NB, int TW>
+static void launch_wgrad(const WgradPlan& p, const void* x, const void* dz, float* ws, int H, int W, int Ci_p, int Co, hipStream_t s) {
+  dim3 grid(p.nsplit, p.ytiles, p.ztiles);
+  hipLaunchKernelGGL((k_wgrad_mfma<MA, NB, TW>), grid, dim3(256), p.lds, s, (const bf16_t*)x, (const bf16_t*)dz, ws, H, W, Ci_p, Co,
+                     p.tiles_x, p.tiles_y, p.ntiles, p.tps);
+}
+int bx_wgrad_mfma_launch(const void* x, const void* dz, float* dw, float* db, int B, int H, int W, int Cin, int Ci_p,
+                         int Co, void* ws, size_t ws_bytes, hipStream_t s) {
+  const WgradPlan p = wgrad_plan(B, H, W, Ci_p, Co);
+  (void)ws_bytes;
+  float* part = (float*)ws;
+#define BX_WG(MA_, NB_) do { if (p.tw == 16) launch_wgrad<MA_, NB_, 16>(p, x, dz, part, H, W, Ci_p, Co, s); \
+                             else launch_wgrad<MA_, NB_, 32>(p, x, dz, part, H, W, Ci_p, Co, s); } while (0)
+  if (p.ma == 1 && p.nb == 1) BX_WG(1, 1);
+  else if (p.ma == 1 && p.nb == 2) BX_WG(1, 2);
+  else if (p.ma == 2 && p.nb == 1) BX_WG(2, 1);
+  else BX_WG(2, 2);
+#undef BX_WG
+  BX_CHECK_LAUNCH("bx_conv3x3_wgrad(mfma)");
+  const size_t per_split = (size_t)9 * Ci_p * Co + Co;
+  hipLaunchKernelGGL(k_wgrad_reduce2, dim3((unsigned)((per_split + 63) / 64)), dim3(256), 0, s, part, dw, db, p.nsplit, Cin, Ci_p, Co);
+  BX_CHECK_LAUNCH("bx_conv3x3_wgrad(mfma reduce)");
+  return BX_OK;
 }

@@ -261,14 +261,14 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
   BX_DISPATCH_DTYPE(d->dtype, T,
     hipLaunchKernelGGL((k_eeg_conv1<T>), dim3(w.nblk_rows), dim3(EEG_TT), 0, s, x, p->conv1_w, (T*)c1, part, g, tr));
   BX_CHECK_LAUNCH("eeg conv1");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, s, part, w.nblk_rows, (double)g.B * g.Ch * g.T, g.F1, tr, p->bn1_w, p->bn1_b,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(1024), 0, s, part, w.nblk_rows, (double)g.B * g.Ch * g.T, g.F1, tr, p->bn1_w, p->bn1_b,
                      p->bn1_rm, p->bn1_rv, p->bn1_nbt, d->momentum, d->eps, st.sc1, st.sh1, st.mean1, st.inv1);
   BX_CHECK_LAUNCH("eeg bn1");
   dim3 gdw(bx_ceil_div(g.T, 256), g.B);
   BX_DISPATCH_DTYPE(d->dtype, T,
     hipLaunchKernelGGL((k_eeg_dw<T>), gdw, dim3(256), 0, s, (const T*)c1, p->dw_w, st.sc1, st.sh1, dmap, part, g, tr));
   BX_CHECK_LAUNCH("eeg depthwise");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, s, part, (int)(gdw.x * gdw.y), (double)g.B * g.T, g.FD, tr, p->bn2_w, p->bn2_b,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(1024), 0, s, part, (int)(gdw.x * gdw.y), (double)g.B * g.T, g.FD, tr, p->bn2_w, p->bn2_b,
                      p->bn2_rm, p->bn2_rv, p->bn2_nbt, d->momentum, d->eps, st.sc2, st.sh2, st.mean2, st.inv2);
   BX_CHECK_LAUNCH("eeg bn2");
   {
@@ -280,7 +280,7 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
   dim3 gsep(bx_ceil_div(g.T1, 64), g.B);
   hipLaunchKernelGGL(k_eeg_sep, gsep, dim3(64), 0, s, p1, p->sep_w, smap, part, g, tr);
   BX_CHECK_LAUNCH("eeg sepconv");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, s, part, (int)(gsep.x * gsep.y), (double)g.B * g.T1, g.F2, tr, p->bn3_w, p->bn3_b,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(1024), 0, s, part, (int)(gsep.x * gsep.y), (double)g.B * g.T1, g.F2, tr, p->bn3_w, p->bn3_b,
                      p->bn3_rm, p->bn3_rv, p->bn3_nbt, d->momentum, d->eps, st.sc3, st.sh3, st.mean3, st.inv3);
   BX_CHECK_LAUNCH("eeg bn3");
   {
@@ -333,15 +333,16 @@ __global__ __launch_bounds__(256) void k_eeg_act_bwd(const float* __restrict__ d
 __global__ void k_eeg_bn_bwd_finalize(const float* __restrict__ partials, int nblk, double count, int F, int training,
                                       const float* __restrict__ gamma, const float* __restrict__ inv, float* __restrict__ coef,
                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  // partial layout [blk][2][16] regardless of F
+  double s[2] = {0.0, 0.0};
+  sum_partials_256<2>(partials, nblk, 16, s);
   const int f = threadIdx.x;
   if (f >= F) return;
-  double s1 = 0, s2 = 0;
-  for (int k = 0; k < nblk; ++k) { s1 += partials[(size_t)k * 32 + f]; s2 += partials[(size_t)k * 32 + 16 + f]; }
-  if (dbeta) dbeta[f] = (float)s1;
-  if (dgamma) dgamma[f] = (float)s2;
+  if (dbeta) dbeta[f] = (float)s[0];
+  if (dgamma) dgamma[f] = (float)s[1];
   coef[f] = gamma[f] * inv[f];
-  coef[EEG_MAXF + f] = training ? (float)(s1 / count) : 0.f;
-  coef[2 * EEG_MAXF + f] = training ? (float)(s2 / count) : 0.f;
+  coef[EEG_MAXF + f] = training ? (float)(s[0] / count) : 0.f;
+  coef[2 * EEG_MAXF + f] = training ? (float)(s[1] / count) : 0.f;
 }
 // in place: du -> dpre = a * (du - k1 - xhat * k2)
 __global__ void k_eeg_bn_bwd_apply(float* __restrict__ du, const float* __restrict__ pre, const float* __restrict__ mean,
@@ -387,37 +388,39 @@ __global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ d
     wpart[(size_t)b * 4096 + i] = acc;
   }
 }
-__global__ void k_sum_partials(const float* __restrict__ part, float* __restrict__ out, int nchunk, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part, float* __restrict__ out, int nchunk, int n) {
+  // 64 outputs x 4 slices per workgroup, slices combined in fixed order
+  __shared__ float sm[4][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
   float s = 0.f;
-  for (int k = 0; k < nchunk; ++k) s += part[(size_t)k * n + i];
-  out[i] = s;
+  if (i < n)
+    for (int k = sl; k < nchunk; k += 4) s += part[(size_t)k * n + i];
+  sm[sl][o] = s;
+  __syncthreads();
+  if (sl == 0 && i < n) out[i] = sm[0][o] + sm[1][o] + sm[2][o] + sm[3][o];
 }
 
 // depthwise backward pass A: per sample  R[fd][ch] = sum_t dd[fd][t] * c1[f][ch][t],  Sd[fd] = sum_t dd[fd][t]
 template <typename T>
 __global__ __launch_bounds__(256) void k_eeg_dw_bwd_a(const T* __restrict__ c1, const float* __restrict__ dd, float* __restrict__ rpart, EegGeom g) {
-  __shared__ float red[4];
+  // one wave per output: lanes stride over time, shuffle-reduce, no workgroup barriers
   const int b = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nout = g.FD * g.Ch + g.FD;
-  for (int o = 0; o < nout; ++o) {
+  for (int o = blockIdx.y * 4 + wave; o < nout; o += 4 * gridDim.y) {
     float acc = 0.f;
     if (o < g.FD * g.Ch) {
       const int fd = o / g.Ch, ch = o % g.Ch, f = fd / g.D;
       const float* dr = dd + ((size_t)b * g.FD + fd) * g.T;
       const size_t cb = (((size_t)b * g.F1 + f) * g.Ch + ch) * g.T;
-      for (int t = threadIdx.x; t < g.T; t += 256) acc = fmaf(dr[t], ldf(c1, cb + t), acc);
+      for (int t = lane; t < g.T; t += 64) acc = fmaf(dr[t], ldf(c1, cb + t), acc);
     } else {
       const float* dr = dd + ((size_t)b * g.FD + (o - g.FD * g.Ch)) * g.T;
-      for (int t = threadIdx.x; t < g.T; t += 256) acc += dr[t];
+      for (int t = lane; t < g.T; t += 64) acc += dr[t];
     }
     acc = wave_sum(acc);
-    __syncthreads();
-    if (lane == 0) red[wave] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) rpart[(size_t)b * nout + o] = red[0] + red[1] + red[2] + red[3];
+    if (lane == 0) rpart[(size_t)b * nout + o] = acc;
   }
 }
 // finalize of pass A: ddw, dgamma1, dbeta1 and the BN1-backward coefficients
@@ -481,15 +484,34 @@ __global__ __launch_bounds__(256) void k_eeg_conv1_bwd(const T* __restrict__ c1,
     sdc[f * TX + t + EEG_MAXK] = coef[f] * (dbn - coef[EEG_MAXF + f] - xh * coef[2 * EEG_MAXF + f]);
   }
   __syncthreads();
-  if (w1part)
-    for (int o = threadIdx.x; o < 8 * g.K1; o += 256) {
-      const int f = o / g.K1, k = o % g.K1;
+  if (w1part) {
+    // thread = (time half, filter f, 4 consecutive taps k0..k0+3): one dc1 read + one new x read per 4 FMAs
+    const int nq = (g.K1 + 3) / 4;                       // tap quads per filter
+    const int half = threadIdx.x >= 128, tid = threadIdx.x & 127;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int f = tid / nq, k0 = (tid % nq) * 4;
+    const bool active = tid < 8 * nq;
+    if (active) {
+      const int tb = half ? Tn / 2 : 0, te = half ? Tn : Tn / 2;
       const float* dc = sdc + f * TX + EEG_MAXK;
-      const float* xr = sxr + EEG_MAXK + k - g.padl1;
-      float acc = 0.f;
-      for (int t = 0; t < Tn; ++t) acc = fmaf(dc[t], xr[t], acc);
-      w1part[(size_t)row * 8 * g.K1 + o] = acc;
+      const float* xr = sxr + EEG_MAXK + k0 - g.padl1;
+      float x0 = xr[tb], x1 = xr[tb + 1], x2 = xr[tb + 2];
+      for (int t = tb; t < te; ++t) {
+        const float x3 = xr[t + 3], dv = dc[t];
+        a0 = fmaf(dv, x0, a0); a1 = fmaf(dv, x1, a1); a2 = fmaf(dv, x2, a2); a3 = fmaf(dv, x3, a3);
+        x0 = x1; x1 = x2; x2 = x3;
+      }
     }
+    __syncthreads();
+    float* comb = sw + 8 * g.K1;                         // [128][4] scratch behind the weights
+    if (active && half) { comb[tid * 4 + 0] = a0; comb[tid * 4 + 1] = a1; comb[tid * 4 + 2] = a2; comb[tid * 4 + 3] = a3; }
+    __syncthreads();
+    if (active && !half) {
+      const float r[4] = {a0 + comb[tid * 4 + 0], a1 + comb[tid * 4 + 1], a2 + comb[tid * 4 + 2], a3 + comb[tid * 4 + 3]};
+      for (int j = 0; j < 4; ++j)
+        if (k0 + j < g.K1) w1part[(size_t)row * 8 * g.K1 + f * g.K1 + k0 + j] = r[j];
+    }
+  }
   if (dx)
     for (int t = threadIdx.x; t < Tn; t += 256) {
       float acc = 0.f;
@@ -535,7 +557,7 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
   hipLaunchKernelGGL(k_eeg_act_bwd, dim3(g.B), dim3(256), 0, s, dfeat, smap, st.mean3, st.inv3, st.sc3, st.sh3, du3, part, g.F2, g.T1, g.T2, g.P2,
                      seed, pdrop, d->salt + 1);
   BX_CHECK_LAUNCH("eeg act3 bwd");
-  hipLaunchKernelGGL(k_eeg_bn_bwd_finalize, dim3(1), dim3(64), 0, s, part, g.B, (double)g.B * g.T1, g.F2, tr, p->bn3_w, st.inv3, coef3, gr->bn3_w, gr->bn3_b);
+  hipLaunchKernelGGL(k_eeg_bn_bwd_finalize, dim3(1), dim3(1024), 0, s, part, g.B, (double)g.B * g.T1, g.F2, tr, p->bn3_w, st.inv3, coef3, gr->bn3_w, gr->bn3_b);
   BX_CHECK_LAUNCH("eeg bn3 bwd finalize");
   {
     const long long n = (long long)g.B * g.F2 * g.T1;
@@ -551,7 +573,7 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
     hipLaunchKernelGGL(k_eeg_sep_bwd, dim3(g.B), dim3(256), lds, s, du3, p1, p->sep_w, dp1, sepp, g);
     BX_CHECK_LAUNCH("eeg sep bwd");
     if (gr->sep_w) {
-      hipLaunchKernelGGL(k_sum_partials, dim3(16), dim3(256), 0, s, sepp, gr->sep_w, g.B, 4096);
+      hipLaunchKernelGGL(k_sum_partials, dim3(64), dim3(256), 0, s, sepp, gr->sep_w, g.B, 4096);
       BX_CHECK_LAUNCH("eeg sep wgrad reduce");
     }
   }
@@ -559,7 +581,7 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
   hipLaunchKernelGGL(k_eeg_act_bwd, dim3(g.B), dim3(256), 0, s, dp1, dmap, st.mean2, st.inv2, st.sc2, st.sh2, du2, part, g.FD, g.T, g.T1, g.P1,
                      seed, pdrop, d->salt);
   BX_CHECK_LAUNCH("eeg act2 bwd");
-  hipLaunchKernelGGL(k_eeg_bn_bwd_finalize, dim3(1), dim3(64), 0, s, part, g.B, (double)g.B * g.T, g.FD, tr, p->bn2_w, st.inv2, coef2, gr->bn2_w, gr->bn2_b);
+  hipLaunchKernelGGL(k_eeg_bn_bwd_finalize, dim3(1), dim3(1024), 0, s, part, g.B, (double)g.B * g.T, g.FD, tr, p->bn2_w, st.inv2, coef2, gr->bn2_w, gr->bn2_b);
   BX_CHECK_LAUNCH("eeg bn2 bwd finalize");
   {
     const long long n = (long long)g.B * g.FD * g.T;
@@ -568,13 +590,13 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
     BX_CHECK_LAUNCH("eeg bn2 bwd apply");
   }
   // depthwise + BN1
-  BX_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((k_eeg_dw_bwd_a<T>), dim3(g.B), dim3(256), 0, s, (const T*)c1, du2, rpart, g));
+  BX_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((k_eeg_dw_bwd_a<T>), dim3(g.B, (g.FD * g.Ch + g.FD + 3) / 4), dim3(256), 0, s, (const T*)c1, du2, rpart, g));
   BX_CHECK_LAUNCH("eeg dw bwd A");
   hipLaunchKernelGGL(k_eeg_dw_bwd_finalize, dim3(1), dim3(256), 0, s, rpart, g.B, g, tr, p->dw_w, p->bn1_w, st.mean1, st.inv1, st.sc1, st.sh1,
                      gr->dw_w, gr->bn1_w, gr->bn1_b, coef1);
   BX_CHECK_LAUNCH("eeg dw bwd finalize");
   if (gr->conv1_w || dx) {
-    const size_t lds = ((size_t)9 * (g.T + 2 * EEG_MAXK) + 8 * g.K1) * sizeof(float);
+    const size_t lds = ((size_t)9 * (g.T + 2 * EEG_MAXK) + 8 * g.K1 + 512) * sizeof(float);
     BX_REQUIRE(lds <= 160 * 1024, "bx_eeg_features_bwd: T too long for the LDS tile (%zu bytes)", lds);
     BX_DISPATCH_DTYPE(d->dtype, T,
       if (hipFuncSetAttribute((const void*)k_eeg_conv1_bwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -583,7 +605,7 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
                          coef1, gr->conv1_w ? w1part : (float*)nullptr, dx, g));
     BX_CHECK_LAUNCH("eeg conv1 bwd");
     if (gr->conv1_w) {
-      hipLaunchKernelGGL(k_sum_partials, dim3(bx_ceil_div(8 * g.K1, 256)), dim3(256), 0, s, w1part, gr->conv1_w, g.B * g.Ch, 8 * g.K1);
+      hipLaunchKernelGGL(k_sum_partials, dim3(bx_ceil_div(8 * g.K1, 64)), dim3(256), 0, s, w1part, gr->conv1_w, g.B * g.Ch, 8 * g.K1);
       BX_CHECK_LAUNCH("eeg conv1 wgrad reduce");
     }
   }

@@ -188,17 +188,16 @@ __global__ void k_fusion_bwd_in(const float* __restrict__ dlogp, const float* __
     else if (dsp) dsp[(size_t)b * N + (j - N)] = s;
   }
 }
-// parameter gradients: one thread per hidden unit, batch looped in order
-__global__ void k_fusion_bwd_w(const float* __restrict__ dlogp, const float* __restrict__ logp, const float* __restrict__ hidden,
+// parameter gradients: one wave per hidden unit j, lanes over the batch, fixed shuffle-tree sums
+__global__ __launch_bounds__(64) void k_fusion_bwd_w(const float* __restrict__ dlogp, const float* __restrict__ logp, const float* __restrict__ hidden,
                                const float* __restrict__ e, const float* __restrict__ sp, const float* __restrict__ w2,
                                float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
                                int B, int N, int Hd) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= Hd) return;
+  const int j = blockIdx.x, lane = threadIdx.x;
   float a1[2 * HEAD_MAX_N], a2[HEAD_MAX_N], ab2[HEAD_MAX_N], ab1 = 0.f;
   for (int i = 0; i < 2 * N; ++i) a1[i] = 0.f;
   for (int n = 0; n < N; ++n) a2[n] = ab2[n] = 0.f;
-  for (int b = 0; b < B; ++b) {
+  for (int b = lane; b < B; b += 64) {
     float dl[HEAD_MAX_N];
     lsm_bwd_row(dlogp + (size_t)b * N, logp + (size_t)b * N, N, dl);
     const float hj = hidden[(size_t)b * Hd + j];
@@ -208,10 +207,13 @@ __global__ void k_fusion_bwd_w(const float* __restrict__ dlogp, const float* __r
     ab1 += dh;
     for (int i = 0; i < N; ++i) { a1[i] = fmaf(dh, e[(size_t)b * N + i], a1[i]); a1[N + i] = fmaf(dh, sp[(size_t)b * N + i], a1[N + i]); }
   }
-  if (dw1) for (int i = 0; i < 2 * N; ++i) dw1[(size_t)j * 2 * N + i] = a1[i];
-  if (db1) db1[j] = ab1;
-  if (dw2) for (int n = 0; n < N; ++n) dw2[(size_t)n * Hd + j] = a2[n];
-  if (db2 && j == 0) for (int n = 0; n < N; ++n) db2[n] = ab2[n];
+  for (int i = 0; i < 2 * N; ++i) { const float v = wave_sum(a1[i]); if (lane == 0 && dw1) dw1[(size_t)j * 2 * N + i] = v; }
+  { const float v = wave_sum(ab1); if (lane == 0 && db1) db1[j] = v; }
+  for (int n = 0; n < N; ++n) {
+    const float v = wave_sum(a2[n]), vb = wave_sum(ab2[n]);
+    if (lane == 0 && dw2) dw2[(size_t)n * Hd + j] = v;
+    if (lane == 0 && db2 && j == 0) db2[n] = vb;
+  }
 }
 
 extern "C" int bx_fusion_head_fwd(const float* eeg_logp, const float* spec_logp, const float* w1, const float* b1,
@@ -237,7 +239,7 @@ extern "C" int bx_fusion_head_bwd(const float* dlogp, const float* logp, const f
     BX_CHECK_LAUNCH("bx_fusion_head_bwd(in)");
   }
   if (dw1 || db1 || dw2 || db2) {
-    hipLaunchKernelGGL(k_fusion_bwd_w, dim3(bx_ceil_div(Hd, 64)), dim3(64), 0, s, dlogp, logp, hidden, eeg_logp, spec_logp, w2,
+    hipLaunchKernelGGL(k_fusion_bwd_w, dim3(Hd), dim3(64), 0, s, dlogp, logp, hidden, eeg_logp, spec_logp, w2,
                        dw1, db1, dw2, db2, B, N, Hd);
     BX_CHECK_LAUNCH("bx_fusion_head_bwd(w)");
   }

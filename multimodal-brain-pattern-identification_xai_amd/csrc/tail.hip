@@ -9,7 +9,7 @@
 // the partials in double precision.  No atomics: results are run-to-run deterministic.
 #include "bx_common.h"
 
-#define TAIL_MAX_BLOCKS 1024
+#define TAIL_MAX_BLOCKS 512
 
 struct TailGeom {
   int B, H, W, Ho, Wo, C, Cin_p, ncg, slots;
@@ -189,7 +189,7 @@ extern "C" int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void
   BX_DISPATCH_DTYPE(d->dtype, T,
     hipLaunchKernelGGL((k_pool_stats<T>), dim3(nblk), dim3(256), 0, s, (const T*)y3, (T*)pooled, partials, g, d->pool, d->training));
   BX_CHECK_LAUNCH("bx_block_tail_fwd(pool)");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(256), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight, bn_bias,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(1024), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight, bn_bias,
                      running_mean, running_var, num_batches_tracked, d->momentum, d->eps, scale, shift, save_mean, save_invstd);
   BX_CHECK_LAUNCH("bx_block_tail_fwd(finalize)");
   BX_DISPATCH_DTYPE(d->dtype, T,
@@ -236,18 +236,16 @@ __global__ __launch_bounds__(256) void k_tail_bwd_reduce(const T* __restrict__ d
 __global__ void k_tail_bwd_finalize(const float* __restrict__ partials, int nblk, double count, int C, int training,
                                     const float* __restrict__ gamma, const float* __restrict__ invstd, float* __restrict__ coef,
                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db1x1) {
+  double s[3] = {0.0, 0.0, 0.0};
+  sum_partials_256<3>(partials, nblk, C, s);
   const int c = threadIdx.x;
   if (c >= C) return;
-  double s1 = 0, s2 = 0, s3 = 0;
-  for (int k = 0; k < nblk; ++k) {
-    s1 += partials[((size_t)k * 3 + 0) * C + c]; s2 += partials[((size_t)k * 3 + 1) * C + c]; s3 += partials[((size_t)k * 3 + 2) * C + c];
-  }
-  if (dbeta) dbeta[c] = (float)s1;
-  if (dgamma) dgamma[c] = (float)s2;
-  if (db1x1) db1x1[c] = (float)s3;
+  if (dbeta) dbeta[c] = (float)s[0];
+  if (dgamma) dgamma[c] = (float)s[1];
+  if (db1x1) db1x1[c] = (float)s[2];
   coef[c] = gamma[c] * invstd[c];
-  coef[C + c] = training ? (float)(s1 / count) : 0.f;
-  coef[2 * C + c] = training ? (float)(s2 / count) : 0.f;
+  coef[C + c] = training ? (float)(s[0] / count) : 0.f;
+  coef[2 * C + c] = training ? (float)(s[1] / count) : 0.f;
 }
 
 // apply: dP = a*(dD - k1 - xhat*k2); route through the 2x2 pool and conv3's ReLU to full resolution
@@ -306,27 +304,42 @@ __global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ do
   }
 }
 
-// dXs[p][ci] = sum_c W1x1[c][ci] * dOut[p][c]   (half resolution, fp32)
+// dXs[p][ci] = sum_c W1x1[c][ci] * dOut[p][c]   (half resolution, fp32).  One (pixel, 8 input channels) unit per
+// thread; the weight matrix streams through LDS in 64-output-channel slabs ([c][Cin_p], zero padded), dOut comes
+// straight from global as 16-byte vectors.
 template <typename T>
 __global__ __launch_bounds__(256) void k_skip_dxs(const T* __restrict__ dout, const float* __restrict__ w1x1, int Cin,
                                                    float* __restrict__ dxs, TailGeom g) {
+  extern __shared__ float swt[];   // [64][Cin_p]
   const int nci8 = g.Cin_p / 8;
   const long long n = g.npool * nci8;
-  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < n; u += (long long)gridDim.x * 256) {
-    const long long pp = u / nci8;
-    const int c8 = (int)(u % nci8);
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < g.C; c0 += 8) {
-      float go[8];
-      ld8(dout, (size_t)pp * g.C + c0, go);
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int ci = c8 * 8 + j;
-          if (ci < Cin) acc[j] = fmaf(w1x1[(size_t)(c0 + k) * Cin + ci], go[k], acc[j]);
-        }
+  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = u < n;
+  const long long pp = live ? u / nci8 : 0;
+  const int c8 = live ? (int)(u % nci8) : 0;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int cb = 0; cb < g.C; cb += 64) {
+    const int nc = g.C - cb < 64 ? g.C - cb : 64;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nc * g.Cin_p; i += 256) {
+      const int c = i / g.Cin_p, ci = i % g.Cin_p;
+      swt[i] = ci < Cin ? w1x1[(size_t)(cb + c) * Cin + ci] : 0.f;
     }
+    __syncthreads();
+    if (live)
+      for (int c0 = 0; c0 < nc; c0 += 8) {
+        float go[8];
+        ld8(dout, (size_t)pp * g.C + cb + c0, go);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float4 wa = *reinterpret_cast<const float4*>(swt + (c0 + k) * g.Cin_p + c8 * 8);
+          const float4 wb = *reinterpret_cast<const float4*>(swt + (c0 + k) * g.Cin_p + c8 * 8 + 4);
+          acc[0] = fmaf(wa.x, go[k], acc[0]); acc[1] = fmaf(wa.y, go[k], acc[1]); acc[2] = fmaf(wa.z, go[k], acc[2]); acc[3] = fmaf(wa.w, go[k], acc[3]);
+          acc[4] = fmaf(wb.x, go[k], acc[4]); acc[5] = fmaf(wb.y, go[k], acc[5]); acc[6] = fmaf(wb.z, go[k], acc[6]); acc[7] = fmaf(wb.w, go[k], acc[7]);
+        }
+      }
+  }
+  if (live) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) dxs[(size_t)pp * g.Cin_p + c8 * 8 + j] = acc[j];
   }
@@ -446,7 +459,7 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
     hipLaunchKernelGGL((k_tail_bwd_reduce<T>), dim3(nblk), dim3(256), 0, s, (const T*)dout, (const T*)pooled, save_mean, save_invstd,
                        seed, p, d->salt, partials, g));
   BX_CHECK_LAUNCH("bx_block_tail_bwd(reduce)");
-  hipLaunchKernelGGL(k_tail_bwd_finalize, dim3(1), dim3(256), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight,
+  hipLaunchKernelGGL(k_tail_bwd_finalize, dim3(1), dim3(1024), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight,
                      save_invstd, coef, d_bn_weight, d_bn_bias, d_b1x1);
   BX_CHECK_LAUNCH("bx_block_tail_bwd(finalize)");
   BX_DISPATCH_DTYPE(d->dtype, T,
@@ -469,7 +482,7 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
   if (dx_skip) {
     const long long n1 = g.npool * (g.Cin_p / 8);
     BX_DISPATCH_DTYPE(d->dtype, T,
-      hipLaunchKernelGGL((k_skip_dxs<T>), dim3(bx_ceil_div(n1, 256) > 2048 ? 2048 : bx_ceil_div(n1, 256)), dim3(256), 0, s,
+      hipLaunchKernelGGL((k_skip_dxs<T>), dim3(bx_ceil_div(n1, 256)), dim3(256), (size_t)64 * g.Cin_p * sizeof(float), s,
                          (const T*)dout, w1x1, Cin, dxs, g));
     BX_CHECK_LAUNCH("bx_block_tail_bwd(dxs)");
     const long long n2 = (long long)g.B * g.H * g.W * (g.Cin_p / 8);

@@ -156,17 +156,19 @@ class InputLayout(torch.autograd.Function):
         return to_nchw_f32(g.contiguous(), ctx.channels), None
 
 
-def _pack(w: torch.Tensor, flip: bool):
-    """fp32 OIHW -> library operand(s). Returns (packed_f32, packed_mfma|None, I_p, O_p)."""
+def _pack(w: torch.Tensor, flip: bool, dtype=None):
+    """fp32 OIHW -> library operand(s). Returns (packed_f32|None, packed_mfma|None, I_p, O_p).
+    With bf16 activations and an MFMA layout available only the MFMA operand is produced."""
     lib = L.load()
     co, ci = w.shape[0], w.shape[1]
     i_log, o_log = (co, ci) if flip else (ci, co)
     ip, op = pad8(i_log), pad8(o_log)
-    pf = torch.empty(9 * ip * op, dtype=torch.float32, device=w.device)
     pm = None
-    nb = lib.bx_conv3x3_packed_mfma_bytes(ip, op) if hasattr(lib, "bx_conv3x3_packed_mfma_bytes") else 0
+    nb = lib.bx_conv3x3_packed_mfma_bytes(ip, op) if dtype in (None, torch.bfloat16) and CONV_ALGO != L.BX_ALGO_DIRECT else 0
     if nb:
         pm = torch.empty(nb, dtype=torch.uint8, device=w.device)
+    need_f32 = dtype is None or pm is None or CONV_ALGO == L.BX_ALGO_DIRECT
+    pf = torch.empty(9 * ip * op, dtype=torch.float32, device=w.device) if need_f32 else None
     L.check(lib.bx_conv3x3_pack(_p(w), _p(pf), _p(pm), co, ci, ip, op, 1 if flip else 0, _stream()), "bx_conv3x3_pack")
     return pf, pm, ip, op
 
@@ -220,7 +222,7 @@ class BlockFn(torch.autograd.Function):
         ws_, bs_ = (w1, w2, w3), (b1, b2, b3)
         acts, pre = [x], None
         for k in range(3):
-            packed = _pack(ws_[k], flip=False)
+            packed = _pack(ws_[k], flip=False, dtype=dt)
             if cfg.preact == k + 1:
                 pre = _conv(acts[-1], packed, bs_[k], None, None, False, dt)
                 y = torch.empty_like(pre)
@@ -273,11 +275,11 @@ class BlockFn(torch.autograd.Function):
             if need_w:
                 grads_w[k], grads_b[k] = _wgrad(acts[k], dz, wts[k], bss[k])
             if k > 0:
-                dz = _conv(dz, _pack(wts[k], flip=True), None, acts[k], None, False, dt)
+                dz = _conv(dz, _pack(wts[k], flip=True, dtype=dt), None, acts[k], None, False, dt)
                 if cfg.preact == k:
                     cfg.capture["grad"] = dz
             elif need_dx:
-                dz = _conv(dz, _pack(wts[0], flip=True), None, None, dx_skip, False, dt)
+                dz = _conv(dz, _pack(wts[0], flip=True, dtype=dt), None, None, dx_skip, False, dt)
         dx = dz if need_dx else None
         return (dx, grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2], d_bnw, d_bnb, d_w11, d_b11,
                 None, None, None, None)

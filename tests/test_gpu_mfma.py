@@ -1,0 +1,130 @@
+"""GPU: the MFMA implicit-GEMM kernels (bf16 operands, fp32 accumulate) against (a) the direct VALU kernel on
+the SAME bf16 inputs and bf16-rounded weights -- agreement to fp32-summation noise before the final bf16
+rounding -- and (b) a plain PyTorch fp32 reference of the op."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import brainxai
+from brainxai import _lib as L
+from brainxai import ops
+from tests.golden_util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+SHAPES = [(8, 16, 9, 13), (16, 16, 8, 32), (16, 32, 17, 40), (32, 64, 8, 16), (64, 64, 5, 6), (64, 128, 16, 32),
+          (128, 256, 8, 16), (256, 256, 4, 8), (128, 128, 25, 18)]
+
+
+@pytest.mark.parametrize("cin,cout,h,w", SHAPES)
+def test_conv_mfma_forward(cin, cout, h, w):
+    torch.manual_seed(cin * 131 + cout)
+    x = _bf(torch.randn(3, cin, h, w))
+    wt = _bf(torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5))
+    b = torch.randn(cout)
+    want = F.relu(F.conv2d(x, wt, b, padding=1))
+    xn = ops.to_nhwc(x.to(DEV), torch.bfloat16)
+    packed = ops._pack(wt.to(DEV), False)
+    assert packed[1] is not None, "MFMA operand must be produced for this shape"
+    lib = L.load()
+    outs = {}
+    for name, algo in (("direct", L.BX_ALGO_DIRECT), ("mfma", L.BX_ALGO_MFMA)):
+        y = torch.empty(3, h, w, cout, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.bx_conv3x3(xn.data_ptr(), packed[0].data_ptr(), packed[1].data_ptr(), b.to(DEV).data_ptr(), None, None, y.data_ptr(),
+                               3, h, w, cin, cout, L.BX_BF16, L.BX_EPI_RELU, algo, torch.cuda.current_stream().cuda_stream), name)
+        outs[name] = ops.to_nchw_f32(y, cout).cpu()
+    torch.cuda.synchronize()
+    assert rel_err(outs["mfma"], want) < 6e-3            # bf16 output rounding: 2^-8 relative per element
+    assert rel_err(outs["mfma"], outs["direct"]) < 6e-3  # both round the same fp32 sums (up to summation order)
+    frac_equal = float((outs["mfma"] == outs["direct"]).float().mean())
+    assert frac_equal > 0.98, frac_equal
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(16, 16, 12, 20), (32, 16, 9, 33), (64, 32, 8, 16), (128, 64, 6, 7), (256, 128, 4, 8)])
+def test_conv_mfma_data_gradient_epilogue(cin, cout, h, w):
+    """flip/transpose pack + ReLU-mask + addend epilogue: dX = conv(dZ, W^T flipped) * (Y > 0) + A"""
+    torch.manual_seed(7 + cin)
+    co_layer, ci_layer = cin, cout          # the layer maps ci_layer -> co_layer; its data-gradient maps back
+    wt = _bf(torch.randn(co_layer, ci_layer, 3, 3) / (3 * ci_layer ** 0.5))
+    dz = _bf(torch.randn(2, co_layer, h, w))
+    ymask = _bf(torch.randn(2, ci_layer, h, w))
+    add = _bf(torch.randn(2, ci_layer, h, w))
+    want = F.conv_transpose2d(dz, wt, padding=1) * (ymask > 0) + add
+    packed = ops._pack(wt.to(DEV), True)
+    assert packed[1] is not None
+    dzn, mn, an = (ops.to_nhwc(t.to(DEV), torch.bfloat16) for t in (dz, ymask, add))
+    lib = L.load()
+    outs = {}
+    for name, algo in (("direct", L.BX_ALGO_DIRECT), ("mfma", L.BX_ALGO_MFMA)):
+        y = torch.empty(2, h, w, ci_layer, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.bx_conv3x3(dzn.data_ptr(), packed[0].data_ptr(), packed[1].data_ptr(), None, mn.data_ptr(), an.data_ptr(), y.data_ptr(),
+                               2, h, w, co_layer, ci_layer, L.BX_BF16, 0, algo, torch.cuda.current_stream().cuda_stream), name)
+        outs[name] = ops.to_nchw_f32(y, ci_layer).cpu()
+    torch.cuda.synchronize()
+    assert rel_err(outs["mfma"], want) < 8e-3
+    assert rel_err(outs["mfma"], outs["direct"]) < 8e-3
+
+
+def test_block_bf16_mfma_matches_direct_path():
+    """whole Block forward+backward in bf16: MFMA kernels vs direct kernels (same storage rounding points)"""
+    torch.manual_seed(11)
+    res = {}
+    for name, algo in (("direct", L.BX_ALGO_DIRECT), ("auto", L.BX_ALGO_AUTO)):
+        ops.CONV_ALGO = ops.WGRAD_ALGO = algo
+        try:
+            torch.manual_seed(11)
+            blk = brainxai.Block(32, 64, "avg", (2, 2), dropout_p=0.0).to(DEV).train()
+            blk.compute_dtype = torch.bfloat16
+            x = torch.randn(4, 32, 16, 32, generator=torch.Generator().manual_seed(5)).to(DEV).requires_grad_(True)
+            out = blk(x)
+            (out.float() * torch.linspace(-1, 1, out.numel(), device=DEV).view_as(out)).sum().backward()
+            res[name] = (out.detach().float().cpu(), x.grad.cpu(), {n: p.grad.cpu() for n, p in blk.named_parameters()})
+        finally:
+            ops.CONV_ALGO = ops.WGRAD_ALGO = L.BX_ALGO_AUTO
+    torch.cuda.synchronize()
+    assert rel_err(res["auto"][0], res["direct"][0]) < 2e-2
+    # the two paths round different fp32 sums to bf16, so a few ReLU masks flip: compare dX in relative L2
+    dxa, dxd = res["auto"][1].double(), res["direct"][1].double()
+    assert float((dxa - dxd).norm() / dxd.norm()) < 0.12
+    for n in res["auto"][2]:
+        a, d = res["auto"][2][n], res["direct"][2][n]
+        cos = float(F.cosine_similarity(a.flatten().double(), d.flatten().double(), dim=0))
+        assert cos > 0.98, (n, cos)
+
+
+WG_SHAPES = [(4, 8, 16, 9, 13), (16, 16, 16, 8, 32), (16, 16, 32, 17, 40), (32, 32, 32, 8, 16), (32, 32, 64, 16, 32),
+             (64, 64, 64, 5, 6), (64, 64, 128, 16, 32), (128, 128, 256, 8, 16), (256, 256, 256, 4, 8), (128, 128, 128, 25, 18)]
+
+
+@pytest.mark.parametrize("cin,cip,cout,h,w", WG_SHAPES)
+def test_wgrad_mfma(cin, cip, cout, h, w):
+    torch.manual_seed(cin + 3 * cout)
+    B = 3
+    x = _bf(torch.randn(B, cin, h, w))
+    dz = _bf(torch.randn(B, cout, h, w))
+    wt = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    bias = torch.zeros(cout, requires_grad=True)
+    (F.conv2d(x, wt, bias, padding=1) * dz).sum().backward()
+    xn = ops.to_nhwc(x.to(DEV), torch.bfloat16)
+    assert xn.shape[3] == cip
+    dzn = ops.to_nhwc(dz.to(DEV), torch.bfloat16)
+    lib = L.load()
+    got = {}
+    for name, algo in (("direct", L.BX_ALGO_DIRECT), ("mfma", L.BX_ALGO_MFMA)):
+        need = lib.bx_conv3x3_wgrad_workspace(B, h, w, cip, cout, L.BX_BF16, algo)
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=DEV)
+        dw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV)
+        db = torch.full((cout,), float("nan"), device=DEV)
+        L.check(lib.bx_conv3x3_wgrad(xn.data_ptr(), dzn.data_ptr(), dw.data_ptr(), db.data_ptr(), B, h, w, cin, cip, cout, L.BX_BF16, algo,
+                                     ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), name)
+        got[name] = (dw.cpu(), db.cpu())
+    torch.cuda.synchronize()
+    for name in got:
+        assert rel_err(got[name][0], wt.grad) < 1e-4, name          # bf16 inputs are exact in fp32; only summation order differs
+        assert rel_err(got[name][1], bias.grad) < 1e-4, name
