@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gradcam", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     return ap.parse_args()
 
 
@@ -109,20 +110,51 @@ def main():
         return brainxai.train_step(model, opt, eeg, spec, labels, crit, ddp=ddp)
 
     for _ in range(args.warmup):
-        step()
+        loss, _ = step()
+    # ---- the whole step (forward, loss, backward, AdamW; ~130 launches) captured once into a hipGraph and replayed:
+    # launch-bound otherwise.  Multi-GPU runs stay eager (the RCCL all-reduce is issued by torch.distributed).
+    graph = None
+    if not args.no_graph and world == 1:
+        try:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()                                    # allocate everything once on the capture stream
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                g_loss, _ = step()
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as exc:                          # noqa: BLE001
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            graph = None
     # ---- timed region: exactly K steps between barrier + synchronize on both sides
-    prof = []
-    ops.CONV_PROFILE = prof
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, _ = step()
+        if graph is not None:
+            graph.replay()
+        else:
+            loss, _ = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if graph is not None:
+        loss = g_loss
+    # ---- per-kernel HIP-event timing of the conv family: the same step launched eagerly right after the timed
+    # region (events cannot bracket kernels inside a replayed graph), same buffers, same data
+    prof = []
+    ops.CONV_PROFILE = prof
+    prof_steps = min(args.steps, 5)
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
     ops.CONV_PROFILE = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -137,7 +169,7 @@ def main():
     for kind, ev0, ev1 in prof:
         kinds.setdefault(kind, []).append(ev0.elapsed_time(ev1) * 1e-3)
     work = conv_work(B, 2 if args.dtype == "bf16" else 4)
-    conv_time = sum(sum(v) for v in kinds.values()) / args.steps            # seconds per step in conv kernels
+    conv_time = sum(sum(v) for v in kinds.values()) / prof_steps            # seconds per step in conv kernels
     conv_flops = sum(w[0] for w in work.values())
     conv_bytes = sum(w[1] for w in work.values())
     n_launch = sum(len(v) for v in kinds.values())
@@ -146,14 +178,14 @@ def main():
     if conv_time > 0:
         ach_gbs = conv_bytes / conv_time / 1e9
         ach_tf = conv_flops / conv_time / 1e12
-        roofline = {"bound": "mfma", "kernel": "conv3x3 fwd+dgrad+wgrad (%d launches/step)" % (n_launch // max(args.steps, 1)),
+        roofline = {"bound": "mfma", "kernel": "conv3x3 fwd+dgrad+wgrad (%d launches/step)" % (n_launch // max(prof_steps, 1)),
                     "achieved": round(ach_tf, 3), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": round(ach_tf / MFMA_PEAK_TFLOPS[args.dtype], 5), "traffic": None,
-                    "avg_launch_us": round(conv_time / max(n_launch / args.steps, 1) * 1e6, 2),
+                    "avg_launch_us": round(conv_time / max(n_launch / prof_steps, 1) * 1e6, 2),
                     "share_of_step": round(conv_time / (elapsed / args.steps), 3)}
         extra["roofline_hbm"] = {"bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(ach_gbs / HBM_PEAK_GBS, 5)}
-        extra["conv_ms_per_step"] = {k_: round(sum(v) / args.steps * 1e3, 3) for k_, v in kinds.items()}
+        extra["conv_ms_per_step"] = {k_: round(sum(v) / prof_steps * 1e3, 3) for k_, v in kinds.items()}
     # whole-step algorithmic roofline (5.71 GFLOP and 52.2 MB bf16 / 104.5 MB fp32 per sample)
     per_sample_bytes = 52.2e6 if args.dtype == "bf16" else 104.5e6
     extra["step_roofline"] = {"hbm_frac": round(per_sample_bytes * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
@@ -216,7 +248,7 @@ def main():
                 "config": {"workload": "configs[1]: multimodal train step, B=64 per GPU, spec [64,4,128,256] + EEG [64,1,19,2000] (stacked from [64,10000,19])",
                            "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": "AdamW(1e-3) fused flat arena",
                            "loss": "KLDivLoss(mean)", "dropout": 0.5, "params": sum(p.numel() for p in model.parameters())},
-                "final_loss": round(loss_val, 6), "gradcam": gradcam, "stacker_samples_per_sec": round(stacker_sps, 1),
+                "hip_graph": graph is not None, "final_loss": round(loss_val, 6), "gradcam": gradcam, "stacker_samples_per_sec": round(stacker_sps, 1),
                 "roofline": roofline, "cpu_baseline": cpu}
         line.update(extra)
         print(json.dumps(line))

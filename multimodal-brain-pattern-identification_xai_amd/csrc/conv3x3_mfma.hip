@@ -241,26 +241,46 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const bf16_t* __restrict__ x
 
   const int t_begin = blockIdx.x * tiles_per_split;
   const int t_end = t_begin + tiles_per_split < ntiles ? t_begin + tiles_per_split : ntiles;
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // software pipeline: the next tile's global loads are issued into registers before the current tile's MFMAs
+  constexpr int NXU = HH * HWID * (CIT / 8), NZU = TH * TW * (COT / 8);
+  constexpr int NX = (NXU + 255) / 256, NZ = (NZU + 255) / 256;
+  uint4 rx[NX], rz[NZ];
+  auto fetch = [&](int tile) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int y0 = ty * TH, x0 = tx * TW;
-    __syncthreads();
-    for (int u = threadIdx.x; u < HH * HWID * (CIT / 8); u += 256) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int u = threadIdx.x + k * 256;
       const int p = u / (CIT / 8), c = u % (CIT / 8);
       const int iy = y0 + p / HWID - 1, ix = x0 + p % HWID - 1;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W && ci0 + c * 8 < Ci_p)
-        v = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * Ci_p + ci0 + c * 8);
-      *reinterpret_cast<uint4*>(xs + p * XB + c * 16) = v;
+      rx[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (u < NXU && iy >= 0 && iy < H && ix >= 0 && ix < W && ci0 + c * 8 < Ci_p)
+        rx[k] = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * Ci_p + ci0 + c * 8);
     }
-    for (int u = threadIdx.x; u < TH * TW * (COT / 8); u += 256) {
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) {
+      const int u = threadIdx.x + k * 256;
       const int p = u / (COT / 8), c = u % (COT / 8);
       const int iy = y0 + p / TW, ix = x0 + p % TW;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (iy < H && ix < W) v = *reinterpret_cast<const uint4*>(dz + (((size_t)b * H + iy) * W + ix) * Co + co0 + c * 8);
-      *reinterpret_cast<uint4*>(zs + p * ZB + c * 16) = v;
+      rz[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (u < NZU && iy < H && ix < W) rz[k] = *reinterpret_cast<const uint4*>(dz + (((size_t)b * H + iy) * W + ix) * Co + co0 + c * 8);
+    }
+  };
+  if (t_begin < t_end) fetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int u = threadIdx.x + k * 256;
+      if (u < NXU) *reinterpret_cast<uint4*>(xs + (u / (CIT / 8)) * XB + (u % (CIT / 8)) * 16) = rx[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) {
+      const int u = threadIdx.x + k * 256;
+      if (u < NZU) *reinterpret_cast<uint4*>(zs + (u / (COT / 8)) * ZB + (u % (COT / 8)) * 16) = rz[k];
     }
     __syncthreads();
+    if (tile + 1 < t_end) fetch(tile + 1);
 #pragma unroll
     for (int ks = 0; ks < KPW; ++ks) {
       const int step = wave * KPW + ks;
@@ -368,7 +388,8 @@ static WgradPlan wgrad_plan(int B, int H, int W, int Ci_p, int Co) {
   p.tw = W <= 16 ? 16 : 32;
   p.tiles_x = (W + p.tw - 1) / p.tw; p.tiles_y = (H + 7) / 8; p.ntiles = p.tiles_x * p.tiles_y * B;
   p.ytiles = (Ci_p + 16 * p.ma - 1) / (16 * p.ma); p.ztiles = Co / (16 * p.nb);
-  int want = 1024 / (p.ytiles * p.ztiles);
+  // (2,2) tiles run one workgroup per CU (register bound): aim at two rounds of 256; lighter tiles at four
+  int want = (p.ma * p.nb == 4 ? 512 : 1024) / (p.ytiles * p.ztiles);
   if (want < 1) want = 1;
   if (want > p.ntiles) want = p.ntiles;
   p.tps = (p.ntiles + want - 1) / want;

@@ -299,35 +299,35 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
 __global__ __launch_bounds__(256) void k_eeg_act_bwd(const float* __restrict__ dpool, const float* __restrict__ pre, const float* __restrict__ mean,
     const float* __restrict__ inv, const float* __restrict__ sc, const float* __restrict__ sh, float* __restrict__ du,
     float* __restrict__ partials, int F, int Tin, int Tout, int P, const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt) {
-  __shared__ float red[4][32];
-  const int b = blockIdx.x;
+  // grid (B, F): one workgroup per (sample, feature map); partial layout [b][2][16]
+  __shared__ float red[4][2];
+  const int b = blockIdx.x, f = blockIdx.y;
   const uint64_t sd = (dropout_p > 0.f && seed) ? seed[0] : 0;
   const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int f = 0; f < F; ++f) {
-    float s1 = 0.f, s2 = 0.f;
-    const float a = sc[f], c = sh[f], mu = mean[f], is = inv[f];
-    for (int t = threadIdx.x; t < Tin; t += 256) {
-      const size_t i = ((size_t)b * F + f) * Tin + t;
-      float g_ = 0.f;
-      const int to = t / P;
-      if (to < Tout) {
-        const size_t io = ((size_t)b * F + f) * Tout + to;
-        float go = dpool[io] / (float)P;
-        if (dropout_p > 0.f) go *= bx_dropout_scale(sd, salt, (uint64_t)io, dropout_p, inv_keep);
-        const float v = pre[i];
-        const float u = v * a + c;
-        g_ = u > 0.f ? go : go * expf(u);
-        s2 += g_ * (v - mu) * is;
-      }
-      du[i] = g_;
-      s1 += g_;
+  float s1 = 0.f, s2 = 0.f;
+  const float a = sc[f], c = sh[f], mu = mean[f], is = inv[f];
+  for (int t = threadIdx.x; t < Tin; t += 256) {
+    const size_t i = ((size_t)b * F + f) * Tin + t;
+    float g_ = 0.f;
+    const int to = t / P;
+    if (to < Tout) {
+      const size_t io = ((size_t)b * F + f) * Tout + to;
+      float go = dpool[io] / (float)P;
+      if (dropout_p > 0.f) go *= bx_dropout_scale(sd, salt, (uint64_t)io, dropout_p, inv_keep);
+      const float v = pre[i];
+      const float u = v * a + c;
+      g_ = u > 0.f ? go : go * expf(u);
+      s2 += g_ * (v - mu) * is;
     }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == 0) { red[wave][f] = s1; red[wave][16 + f] = s2; }
+    du[i] = g_;
+    s1 += g_;
   }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) { red[wave][0] = s1; red[wave][1] = s2; }
   __syncthreads();
-  if (threadIdx.x < 32) partials[(size_t)b * 32 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (threadIdx.x < 2)
+    partials[(size_t)b * 32 + threadIdx.x * 16 + f] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 // finalize: dgamma, dbeta, coefficients a = gamma*invstd, k1 = s1/N, k2 = s2/N (zero in eval mode)
 __global__ void k_eeg_bn_bwd_finalize(const float* __restrict__ partials, int nblk, double count, int F, int training,
@@ -554,7 +554,7 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
   if (!gr) gr = &none;
 
   // pool2/dropout/ELU/BN3
-  hipLaunchKernelGGL(k_eeg_act_bwd, dim3(g.B), dim3(256), 0, s, dfeat, smap, st.mean3, st.inv3, st.sc3, st.sh3, du3, part, g.F2, g.T1, g.T2, g.P2,
+  hipLaunchKernelGGL(k_eeg_act_bwd, dim3(g.B, g.F2), dim3(256), 0, s, dfeat, smap, st.mean3, st.inv3, st.sc3, st.sh3, du3, part, g.F2, g.T1, g.T2, g.P2,
                      seed, pdrop, d->salt + 1);
   BX_CHECK_LAUNCH("eeg act3 bwd");
   hipLaunchKernelGGL(k_eeg_bn_bwd_finalize, dim3(1), dim3(1024), 0, s, part, g.B, (double)g.B * g.T1, g.F2, tr, p->bn3_w, st.inv3, coef3, gr->bn3_w, gr->bn3_b);
@@ -578,7 +578,7 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
     }
   }
   // pool1/dropout/ELU/BN2
-  hipLaunchKernelGGL(k_eeg_act_bwd, dim3(g.B), dim3(256), 0, s, dp1, dmap, st.mean2, st.inv2, st.sc2, st.sh2, du2, part, g.FD, g.T, g.T1, g.P1,
+  hipLaunchKernelGGL(k_eeg_act_bwd, dim3(g.B, g.FD), dim3(256), 0, s, dp1, dmap, st.mean2, st.inv2, st.sc2, st.sh2, du2, part, g.FD, g.T, g.T1, g.P1,
                      seed, pdrop, d->salt);
   BX_CHECK_LAUNCH("eeg act2 bwd");
   hipLaunchKernelGGL(k_eeg_bn_bwd_finalize, dim3(1), dim3(1024), 0, s, part, g.B, (double)g.B * g.T, g.FD, tr, p->bn2_w, st.inv2, coef2, gr->bn2_w, gr->bn2_b);

@@ -423,14 +423,20 @@ __global__ __launch_bounds__(256) void k_w1x1_grad(const T* __restrict__ dout, c
   }
   if (ci0 + ci < g.Cin_p) partial[((size_t)blockIdx.x * g.C + c0 + c) * g.Cin_p + ci0 + ci] = acc;
 }
-__global__ void k_w1x1_reduce(const float* __restrict__ partial, float* __restrict__ dw, int nchunk, int C, int Cin, int Cin_p) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= C * Cin_p) return;
-  const int c = idx / Cin_p, ci = idx % Cin_p;
-  if (ci >= Cin) return;
+__global__ __launch_bounds__(256) void k_w1x1_reduce(const float* __restrict__ partial, float* __restrict__ dw, int nchunk, int C, int Cin, int Cin_p) {
+  // 64 outputs x 4 chunk slices per workgroup, combined in fixed order
+  __shared__ float sm[4][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + o;
   float s = 0.f;
-  for (int k = 0; k < nchunk; ++k) s += partial[(size_t)k * C * Cin_p + idx];
-  dw[(size_t)c * Cin + ci] = s;
+  if (idx < C * Cin_p)
+    for (int k = sl; k < nchunk; k += 4) s += partial[(size_t)k * C * Cin_p + idx];
+  sm[sl][o] = s;
+  __syncthreads();
+  if (sl == 0 && idx < C * Cin_p) {
+    const int c = idx / Cin_p, ci = idx % Cin_p;
+    if (ci < Cin) dw[(size_t)c * Cin + ci] = sm[0][o] + sm[1][o] + sm[2][o] + sm[3][o];
+  }
 }
 
 extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const void* y3, const void* x, const void* pooled,
@@ -468,7 +474,7 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
   BX_CHECK_LAUNCH("bx_block_tail_bwd(apply)");
   if (d_w1x1) {
     int nchunk = (int)((g.npool + 63) / 64);
-    if (nchunk > 256) nchunk = 256;
+    if (nchunk > 128) nchunk = 128;
     int ppc = (int)((g.npool + nchunk - 1) / nchunk);
     ppc = (ppc + 63) / 64 * 64;
     nchunk = (int)((g.npool + ppc - 1) / ppc);
@@ -476,7 +482,7 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
     BX_DISPATCH_DTYPE(d->dtype, T,
       hipLaunchKernelGGL((k_w1x1_grad<T>), grid, dim3(256), 0, s, (const T*)dout, (const T*)x, wpart, ppc, g));
     BX_CHECK_LAUNCH("bx_block_tail_bwd(w1x1)");
-    hipLaunchKernelGGL(k_w1x1_reduce, dim3(bx_ceil_div(g.C * g.Cin_p, 256)), dim3(256), 0, s, wpart, d_w1x1, nchunk, g.C, Cin, g.Cin_p);
+    hipLaunchKernelGGL(k_w1x1_reduce, dim3(bx_ceil_div(g.C * g.Cin_p, 64)), dim3(256), 0, s, wpart, d_w1x1, nchunk, g.C, Cin, g.Cin_p);
     BX_CHECK_LAUNCH("bx_block_tail_bwd(w1x1 reduce)");
   }
   if (dx_skip) {
