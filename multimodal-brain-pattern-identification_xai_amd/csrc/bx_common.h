@@ -32,6 +32,10 @@ __device__ __forceinline__ float ldf(const bf16_t* p, size_t i) { return bf2f(p[
 __device__ __forceinline__ void stf(float* p, size_t i, float v) { p[i] = v; }
 __device__ __forceinline__ void stf(bf16_t* p, size_t i, float v) { p[i] = f2bf(v); }
 
+// value as it will read back after being stored as T (identity for fp32, round-to-nearest-even for bf16)
+__device__ __forceinline__ float round_as(const float*, float v) { return v; }
+__device__ __forceinline__ float round_as(const bf16_t*, float v) { return bf2f(f2bf(v)); }
+
 // ---- 8-channel vector access (16 B for bf16, 2 x 16 B for fp32); p + i must be 8-element aligned ----
 __device__ __forceinline__ void ld8(const float* p, size_t i, float v[8]) {
   const float4 a = *reinterpret_cast<const float4*>(p + i);

@@ -357,25 +357,49 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const bf16_t* __restrict__ x
   }
 }
 
-// sum the partials in a fixed order: 64 outputs x 4 slices per workgroup, slices combined through LDS
+// sum the partials in a fixed order.  A workgroup covers NO = 256/S float4 output groups x S split slices (S = 4,
+// 16 or 64: small outputs get many slices so that the chip is filled and no thread walks hundreds of splits);
+// slices are combined through LDS in slice order.  per_split is a multiple of 4 (Co % 16 == 0): float4s are aligned.
 __global__ __launch_bounds__(256) void k_wgrad_reduce2(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
-                                                        int nsplit, int Cin, int Ci_p, int Co) {
-  __shared__ float sm[4][64];
+                                                        int nsplit, int Cin, int Ci_p, int Co, int S) {
+  __shared__ float4 sm[256];
   const size_t per_split = (size_t)9 * Ci_p * Co + Co;
-  const int o = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const size_t idx = (size_t)blockIdx.x * 64 + o;
-  float s = 0.f;
-  if (idx < per_split)
-    for (int c = part; c < nsplit; c += 4) s += partial[(size_t)c * per_split + idx];
-  sm[part][o] = s;
+  const int NO = 256 / S;
+  const int o = threadIdx.x % NO, part = threadIdx.x / NO;
+  const size_t idx = ((size_t)blockIdx.x * NO + o) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (idx < per_split) {
+    int c = part;
+    for (; c + 3 * S < nsplit; c += 4 * S) {      // four independent loads in flight; adds stay in split order
+      const float4 v0 = *reinterpret_cast<const float4*>(partial + (size_t)c * per_split + idx);
+      const float4 v1 = *reinterpret_cast<const float4*>(partial + (size_t)(c + S) * per_split + idx);
+      const float4 v2 = *reinterpret_cast<const float4*>(partial + (size_t)(c + 2 * S) * per_split + idx);
+      const float4 v3 = *reinterpret_cast<const float4*>(partial + (size_t)(c + 3 * S) * per_split + idx);
+      s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+      s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+      s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+      s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+    }
+    for (; c < nsplit; c += S) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)c * per_split + idx);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  sm[threadIdx.x] = s;
   __syncthreads();
   if (part == 0 && idx < per_split) {
-    s = sm[0][o] + sm[1][o] + sm[2][o] + sm[3][o];
-    if (idx < (size_t)9 * Ci_p * Co) {
-      const int co = (int)(idx % Co), ci = (int)((idx / Co) % Ci_p), t = (int)(idx / ((size_t)Co * Ci_p));
-      if (ci < Cin) dw[((size_t)co * Cin + ci) * 9 + t] = s;
-    } else if (db) {
-      db[idx - (size_t)9 * Ci_p * Co] = s;
+    float4 r = sm[o];
+    for (int k = 1; k < S; ++k) { const float4 v = sm[k * NO + o]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+    const float rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t i = idx + j;
+      if (i < (size_t)9 * Ci_p * Co) {
+        const int co = (int)(i % Co), ci = (int)((i / Co) % Ci_p), t = (int)(i / ((size_t)Co * Ci_p));
+        if (ci < Cin) dw[((size_t)co * Cin + ci) * 9 + t] = rr[j];
+      } else if (db) {
+        db[i - (size_t)9 * Ci_p * Co] = rr[j];
+      }
     }
   }
 }
@@ -426,7 +450,9 @@ int bx_wgrad_mfma_launch(const void* x, const void* dz, float* dw, float* db, in
 #undef BX_WG
   BX_CHECK_LAUNCH("bx_conv3x3_wgrad(mfma)");
   const size_t per_split = (size_t)9 * Ci_p * Co + Co;
-  hipLaunchKernelGGL(k_wgrad_reduce2, dim3((unsigned)((per_split + 63) / 64)), dim3(256), 0, s, part, dw, db, p.nsplit, Cin, Ci_p, Co);
+  const int S = per_split >= 65536 ? 4 : per_split >= 8192 ? 16 : 64;
+  const int per_wg = (256 / S) * 4;
+  hipLaunchKernelGGL(k_wgrad_reduce2, dim3((unsigned)((per_split + per_wg - 1) / per_wg)), dim3(256), 0, s, part, dw, db, p.nsplit, Cin, Ci_p, Co, S);
   BX_CHECK_LAUNCH("bx_conv3x3_wgrad(mfma reduce)");
   return BX_OK;
 }

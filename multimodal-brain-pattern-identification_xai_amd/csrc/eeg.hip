@@ -86,7 +86,6 @@ template <typename T>
 __global__ __launch_bounds__(EEG_TT) void k_eeg_conv1(const float* __restrict__ x, const float* __restrict__ w1, T* __restrict__ c1,
                                                       float* __restrict__ partials, EegGeom g, int want_stats) {
   __shared__ float sx[EEG_TT + EEG_MAXK];
-  __shared__ float sw[8 * EEG_MAXK];
   __shared__ float red[4][16];
   const int nblk_t = (g.T + EEG_TT - 1) / EEG_TT;
   const int row = blockIdx.x / nblk_t, tb = blockIdx.x % nblk_t;
@@ -97,14 +96,13 @@ __global__ __launch_bounds__(EEG_TT) void k_eeg_conv1(const float* __restrict__ 
     const int t = t0 + i - g.padl1;
     sx[i] = (t >= 0 && t < g.T) ? xr[t] : 0.f;
   }
-  for (int i = threadIdx.x; i < 8 * g.K1; i += EEG_TT) sw[i] = w1[i];
   __syncthreads();
   const int t = t0 + threadIdx.x;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int k = 0; k < g.K1; ++k) {
     const float xv = sx[threadIdx.x + k];
 #pragma unroll
-    for (int f = 0; f < 8; ++f) acc[f] = fmaf(sw[f * g.K1 + k], xv, acc[f]);
+    for (int f = 0; f < 8; ++f) acc[f] = fmaf(w1[f * g.K1 + k], xv, acc[f]);   // wave-uniform index -> s_load, SGPR operand
   }
   float s[8], q[8];
 #pragma unroll
@@ -113,7 +111,7 @@ __global__ __launch_bounds__(EEG_TT) void k_eeg_conv1(const float* __restrict__ 
     if (t < g.T) {
       const size_t o = (((size_t)b * g.F1 + f) * g.Ch + ch) * g.T + t;
       stf(c1, o, acc[f]);
-      v = ldf(c1, o);                       // statistics of the stored value
+      v = round_as(c1, acc[f]);             // statistics of the stored value
     }
     s[f] = v; q[f] = v * v;
   }
@@ -371,8 +369,9 @@ __global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ d
   }
   for (int i = threadIdx.x; i < 4096; i += 256) sw[i] = ws[i];
   __syncthreads();
-  // (a)
-  for (int i = threadIdx.x; i < 16 * T1; i += 256) {
+  // (a)  blockIdx.y selects a quarter of the maps / of the weight-gradient outputs
+  const int qa = blockIdx.y, nq = gridDim.y;
+  for (int i = qa * 256 + threadIdx.x; i < 16 * T1; i += 256 * nq) {
     const int fd = i / T1, t = i % T1;
     float acc = 0.f;
     for (int o = 0; o < 16; ++o)
@@ -381,7 +380,7 @@ __global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ d
     dp1[((size_t)b * 16 + fd) * T1 + t] = acc;
   }
   // (b)
-  for (int i = threadIdx.x; i < 4096; i += 256) {
+  for (int i = qa * 256 + threadIdx.x; i < 4096; i += 256 * nq) {
     const int k = i & 15, fd = (i >> 4) & 15, o = i >> 8;
     float acc = 0.f;
     for (int t = 0; t < T1; ++t) acc = fmaf(sds[o * TP + t + 8], sp1[fd * TP + (t + k - g.padl2) + 8], acc);
@@ -476,12 +475,19 @@ __global__ __launch_bounds__(256) void k_eeg_conv1_bwd(const T* __restrict__ c1,
   for (int i = threadIdx.x; i < TX; i += 256) { const int t = i - EEG_MAXK; sxr[i] = (t >= 0 && t < Tn) ? x[(size_t)row * Tn + t] : 0.f; }
   for (int i = threadIdx.x; i < 8 * g.K1; i += 256) sw[i] = w1[i];
   __syncthreads();
-  for (int i = threadIdx.x; i < 8 * Tn; i += 256) {
-    const int f = i / Tn, t = i % Tn;
-    float dbn = 0.f;
-    for (int q = 0; q < g.D; ++q) dbn = fmaf(dw[(f * g.D + q) * g.Ch + ch], dd[((size_t)b * g.FD + f * g.D + q) * Tn + t], dbn);
-    const float xh = (ldf(c1, (((size_t)b * g.F1 + f) * g.Ch + ch) * Tn + t) - mean1[f]) * inv1[f];
-    sdc[f * TX + t + EEG_MAXK] = coef[f] * (dbn - coef[EEG_MAXF + f] - xh * coef[2 * EEG_MAXF + f]);
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    const float w0 = dw[(f * 2) * g.Ch + ch], w1d = dw[(f * 2 + 1) * g.Ch + ch];      // D == 2 (eeg_geom enforces it)
+    const float mu = mean1[f], is = inv1[f], ca = coef[f], k1 = coef[EEG_MAXF + f], k2 = coef[2 * EEG_MAXF + f];
+    const float* d0 = dd + ((size_t)b * g.FD + f * 2) * Tn;
+    const float* d1 = d0 + Tn;
+    const size_t cb = (((size_t)b * g.F1 + f) * g.Ch + ch) * Tn;
+#pragma unroll 4
+    for (int t = threadIdx.x; t < Tn; t += 256) {
+      const float dbn = fmaf(w1d, d1[t], w0 * d0[t]);
+      const float xh = (ldf(c1, cb + t) - mu) * is;
+      sdc[f * TX + t + EEG_MAXK] = ca * (dbn - k1 - xh * k2);
+    }
   }
   __syncthreads();
   if (w1part) {
@@ -570,7 +576,7 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
     BX_REQUIRE(lds <= 160 * 1024, "bx_eeg_features_bwd: T/P1 too long for the LDS tile (%zu bytes)", lds);
     if (hipFuncSetAttribute((const void*)k_eeg_sep_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       BX_FAIL(BX_EHIP, "bx_eeg_features_bwd: cannot reserve %zu bytes of LDS", lds);
-    hipLaunchKernelGGL(k_eeg_sep_bwd, dim3(g.B), dim3(256), lds, s, du3, p1, p->sep_w, dp1, sepp, g);
+    hipLaunchKernelGGL(k_eeg_sep_bwd, dim3(g.B, 4), dim3(256), lds, s, du3, p1, p->sep_w, dp1, sepp, g);
     BX_CHECK_LAUNCH("eeg sep bwd");
     if (gr->sep_w) {
       hipLaunchKernelGGL(k_sum_partials, dim3(64), dim3(256), 0, s, sepp, gr->sep_w, g.B, 4096);

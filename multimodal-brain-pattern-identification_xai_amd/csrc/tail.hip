@@ -53,8 +53,14 @@ __device__ __forceinline__ void block_channel_reduce(float (*vals)[8], float* ld
 // forward 1: pooled = pool2x2(y3) (stored, needed again by backward) + per-workgroup (sum, sumsq)
 template <typename T>
 __global__ __launch_bounds__(256) void k_pool_stats(const T* __restrict__ y3, T* __restrict__ pooled, float* __restrict__ partials,
-                                                     TailGeom g, int pool, int want_stats) {
+                                                     TailGeom g, int pool, int want_stats, const float* __restrict__ w1x1, int Cin,
+                                                     float* __restrict__ wT) {
   __shared__ float lds[2048];
+  if (blockIdx.x == 0)                                  // wT[ci][c] = W1x1[c][ci] (zero rows for padded inputs): read by k_tail_apply
+    for (int i = threadIdx.x; i < g.Cin_p * g.C; i += 256) {
+      const int ci = i / g.C, c = i % g.C;
+      wT[i] = ci < Cin ? w1x1[(size_t)c * Cin + ci] : 0.f;
+    }
   const int cg = threadIdx.x % g.ncg, slot = threadIdx.x / g.ncg;
   float acc[2][8];
 #pragma unroll
@@ -72,10 +78,11 @@ __global__ __launch_bounds__(256) void k_pool_stats(const T* __restrict__ y3, T*
       v[j] = pool == BX_POOL_MAX ? fmaxf(fmaxf(a[j], bq[j]), fmaxf(c[j], dq[j])) : 0.25f * (a[j] + bq[j] + c[j] + dq[j]);
     st8(pooled, (size_t)pp * g.C + cg * 8, v);
     if (want_stats) {
-      float q[8];
-      ld8(pooled, (size_t)pp * g.C + cg * 8, q);  // statistics of the values as stored (bf16-rounded if bf16)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { acc[0][j] += q[j]; acc[1][j] += q[j] * q[j]; }
+      for (int j = 0; j < 8; ++j) {          // statistics of the values as stored (bf16-rounded if bf16)
+        const float q = round_as(pooled, v[j]);
+        acc[0][j] += q; acc[1][j] += q * q;
+      }
     }
   }
   if (!want_stats) return;
@@ -104,7 +111,7 @@ __device__ __forceinline__ void skip_sample(const T* __restrict__ x, const TailG
 
 // forward 3: out = dropout(pooled*scale + shift) + b1x1 + W1x1 . bilinear(x)
 template <typename T>
-__global__ __launch_bounds__(256) void k_tail_apply(const T* __restrict__ pooled, const T* __restrict__ x, const float* __restrict__ w1x1,
+__global__ __launch_bounds__(256) void k_tail_apply(const T* __restrict__ pooled, const T* __restrict__ x, const float* __restrict__ wT,
     int Cin, const float* __restrict__ b1x1, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, T* __restrict__ out, TailGeom g) {
   extern __shared__ float xs[];  // [slots][Cin_p + 1]
@@ -144,8 +151,10 @@ __global__ __launch_bounds__(256) void k_tail_apply(const T* __restrict__ pooled
     }
     for (int ci = 0; ci < Cin; ++ci) {
       const float xv = xs[slot * xstride + ci];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = fmaf(w1x1[(size_t)(cg * 8 + j) * Cin + ci], xv, acc[j]);
+      const float4 wa = *reinterpret_cast<const float4*>(wT + (size_t)ci * g.C + cg * 8);
+      const float4 wb = *reinterpret_cast<const float4*>(wT + (size_t)ci * g.C + cg * 8 + 4);
+      acc[0] = fmaf(wa.x, xv, acc[0]); acc[1] = fmaf(wa.y, xv, acc[1]); acc[2] = fmaf(wa.z, xv, acc[2]); acc[3] = fmaf(wa.w, xv, acc[3]);
+      acc[4] = fmaf(wb.x, xv, acc[4]); acc[5] = fmaf(wb.y, xv, acc[5]); acc[6] = fmaf(wb.z, xv, acc[6]); acc[7] = fmaf(wb.w, xv, acc[7]);
     }
     st8(out, (size_t)pp * g.C + cg * 8, acc);
   }
@@ -155,10 +164,10 @@ extern "C" size_t bx_block_tail_workspace(const bxTailDesc* d) {
   TailGeom g;
   if (!d || make_geom(d, &g)) return 0;
   const size_t Ho = d->H / 2, Wo = d->W / 2;
-  size_t fwd = ((size_t)TAIL_MAX_BLOCKS * 2 + 2) * d->C * sizeof(float);
+  size_t fwd = ((size_t)TAIL_MAX_BLOCKS * 2 + 2) * d->C * sizeof(float) + (size_t)d->Cin_p * d->C * sizeof(float);
   size_t bwd = ((size_t)TAIL_MAX_BLOCKS * 3 + 3) * d->C * sizeof(float)                 // partials + coefficients
              + bx_align_up((size_t)d->B * Ho * Wo * d->Cin_p * sizeof(float), 256)       // dXs (half-res, fp32)
-             + (size_t)256 * d->C * d->Cin_p * sizeof(float);                            // conv1x1 weight-grad partials
+             + (size_t)1024 * 256 * sizeof(float) + (size_t)64 * d->C * d->Cin_p * sizeof(float);   // conv1x1 weight-grad partials
   return bx_align_up(fwd > bwd ? fwd : bwd, 256);
 }
 
@@ -185,15 +194,17 @@ extern "C" int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void
   float* partials = (float*)workspace;
   float* scale = partials + (size_t)TAIL_MAX_BLOCKS * 2 * g.C;
   float* shift = scale + g.C;
+  float* wT = shift + g.C;
   const float p = d->training ? d->dropout_p : 0.f;
   BX_DISPATCH_DTYPE(d->dtype, T,
-    hipLaunchKernelGGL((k_pool_stats<T>), dim3(nblk), dim3(256), 0, s, (const T*)y3, (T*)pooled, partials, g, d->pool, d->training));
+    hipLaunchKernelGGL((k_pool_stats<T>), dim3(nblk), dim3(256), 0, s, (const T*)y3, (T*)pooled, partials, g, d->pool, d->training,
+                       w1x1, Cin, wT));
   BX_CHECK_LAUNCH("bx_block_tail_fwd(pool)");
   hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(1024), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight, bn_bias,
                      running_mean, running_var, num_batches_tracked, d->momentum, d->eps, scale, shift, save_mean, save_invstd);
   BX_CHECK_LAUNCH("bx_block_tail_fwd(finalize)");
   BX_DISPATCH_DTYPE(d->dtype, T,
-    hipLaunchKernelGGL((k_tail_apply<T>), dim3(nblk), dim3(256), xs_bytes, s, (const T*)pooled, (const T*)x, w1x1, Cin, b1x1,
+    hipLaunchKernelGGL((k_tail_apply<T>), dim3(nblk), dim3(256), xs_bytes, s, (const T*)pooled, (const T*)x, wT, Cin, b1x1,
                        scale, shift, seed, p, d->salt, (T*)out, g));
   BX_CHECK_LAUNCH("bx_block_tail_fwd(apply)");
   return BX_OK;
@@ -473,8 +484,13 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
                        save_invstd, coef, seed, p, d->salt, d->pool, (T*)dz3, g));
   BX_CHECK_LAUNCH("bx_block_tail_bwd(apply)");
   if (d_w1x1) {
+    // ~1024 workgroups in total; partial buffer = nchunk * C * Cin_p floats <= 1024*256 + 64*C*Cin_p (workspace formula)
+    const int otiles = (g.C / 16) * ((g.Cin_p + 15) / 16);
     int nchunk = (int)((g.npool + 63) / 64);
-    if (nchunk > 128) nchunk = 128;
+    int cap = 1024 / otiles;
+    if (cap < 64) cap = 64;
+    while ((size_t)cap * g.C * g.Cin_p > (size_t)1024 * 256 + (size_t)64 * g.C * g.Cin_p) cap /= 2;
+    if (nchunk > cap) nchunk = cap;
     int ppc = (int)((g.npool + nchunk - 1) / nchunk);
     ppc = (ppc + 63) / 64 * 64;
     nchunk = (int)((g.npool + ppc - 1) / ppc);
