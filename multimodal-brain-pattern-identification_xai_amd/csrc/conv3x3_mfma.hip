@@ -86,31 +86,50 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
     for (int n = 0; n < NC; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nchunk = Ci / CK;
+  // staging: every thread issues ALL of its 16-byte global loads before the first LDS write (a rolled
+  // load->wait->write loop serialises one HBM round trip per iteration)
+  constexpr int NU = HH * HWID * NCH, NR = (NU + 255) / 256;
   for (int chunk = 0; chunk < nchunk; ++chunk) {
-    __syncthreads();
-    for (int u = threadIdx.x; u < HH * HWID * NCH; u += 256) {
+    uint4 rv[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int u = threadIdx.x + k * 256;
       const int p = u / NCH, c = u % NCH;
-      const int hy = p / HWID, hx = p % HWID;
-      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-        v = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * Ci + chunk * CK + c * 8);
-      *reinterpret_cast<uint4*>(lds + p * CKB + 16 * lds_chunk<CK>(c, p)) = v;
+      const int iy = y0 + p / HWID - 1, ix = x0 + p % HWID - 1;
+      rv[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (u < NU && iy >= 0 && iy < H && ix >= 0 && ix < W)
+        rv[k] = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * Ci + chunk * CK + c * 8);
+    }
+    const bf16_t* wchunk = wp + (size_t)chunk * KS * Co * 32;
+    // weight fragments run two K-steps ahead of the MFMAs that consume them (L2 latency >> one K-step)
+    bf16x8 a[3][NC];
+    auto load_a = [&](int s, bf16x8 (&dst)[NC]) {
+#pragma unroll
+      for (int n = 0; n < NC; ++n)
+        dst[n] = *reinterpret_cast<const bf16x8*>(wchunk + ((size_t)s * Co + co_base + n * 16 + li) * 32 + 8 * g);
+    };
+    load_a(0, a[0]);
+    if (KS > 1) load_a(1, a[1]);
+    __syncthreads();                          // previous chunk's fragment reads are done
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int u = threadIdx.x + k * 256;
+      if (u < NU) {
+        const int p = u / NCH, c = u % NCH;
+        *reinterpret_cast<uint4*>(lds + p * CKB + 16 * lds_chunk<CK>(c, p)) = rv[k];
+      }
     }
     __syncthreads();
-    const bf16_t* wchunk = wp + (size_t)chunk * KS * Co * 32;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
+      if (s + 2 < KS) load_a(s + 2, a[(s + 2) % 3]);
+      __builtin_amdgcn_sched_barrier(0);        // keep the prefetch loads up here: hipcc otherwise sinks them to their use
       const int q0 = s * 32 + 8 * g;
       int tap = q0 / CK;
       const int c = (q0 % CK) / 8;
       const bool valid = tap < 9;
       if (!valid) tap = 0;
       const int dy = tap / 3, dx = tap - 3 * dy;
-      bf16x8 a[NC];
-#pragma unroll
-      for (int n = 0; n < NC; ++n)
-        a[n] = *reinterpret_cast<const bf16x8*>(wchunk + ((size_t)s * Co + co_base + n * 16 + li) * 32 + 8 * g);
 #pragma unroll
       for (int i = 0; i < MP; ++i) {
         const int t = wave * MP + i;
@@ -118,11 +137,15 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
         bf16x8 bv = *reinterpret_cast<const bf16x8*>(lds + p * CKB + 16 * lds_chunk<CK>(c, p));
         if (!valid) bv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int n = 0; n < NC; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[n], bv, acc[i][n], 0, 0, 0);
+        for (int n = 0; n < NC; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s % 3][n], bv, acc[i][n], 0, 0, 0);
       }
     }
   }
   // epilogue: lane = (pixel li of tile t, output channels co_base + n*16 + 4g .. +3)
+  float4 bz[NC];
+#pragma unroll
+  for (int n = 0; n < NC; ++n)
+    bz[n] = bias ? *reinterpret_cast<const float4*>(bias + co_base + n * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < MP; ++i) {
     const int t = wave * MP + i;
@@ -132,11 +155,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
     for (int n = 0; n < NC; ++n) {
       const int co = co_base + n * 16 + 4 * g;
       const size_t o = (((size_t)b * H + oy) * W + ox) * Co + co;
-      float v[4];
+      float v[4] = {acc[i][n][0] + bz[n].x, acc[i][n][1] + bz[n].y, acc[i][n][2] + bz[n].z, acc[i][n][3] + bz[n].w};
+      if (relu) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = acc[i][n][r] + (bias ? bias[co + r] : 0.f);
-        if (relu) v[r] = fmaxf(v[r], 0.f);
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
       if (mask_src) {
         const uint2 m = *reinterpret_cast<const uint2*>(mask_src + o);
