@@ -62,6 +62,14 @@ int bx_conv3x3_pack(const float* w_oihw, float* packed_f32, void* packed_mfma, i
                     int I_p, int O_p, int transpose_flip, bxStream stream);
 /* bytes of the MFMA operand for padded dims (0 when the MFMA path does not cover them). */
 size_t bx_conv3x3_packed_mfma_bytes(int I_p, int O_p);
+/* All MFMA weight operands of a model in ONE launch.  `jobs_device` is a device array of njobs descriptors sorted by
+ * block_begin (job j owns launch blocks [block_begin_j, block_begin_{j+1})); total_blocks = end of the last job. */
+typedef struct {
+  const void* w_oihw;      /* fp32 [Cout,Cin,3,3] */
+  void* packed_mfma;       /* bx_conv3x3_packed_mfma_bytes(I_p, O_p) bytes */
+  int Cout, Cin, I_p, O_p, transpose_flip, block_begin;
+} bxPackJob;
+int bx_conv3x3_pack_many(const bxPackJob* jobs_device, int njobs, int total_blocks, bxStream stream);
 /* y = epi(conv3x3(x, Wp) + bias);  x [B,H,W,Ci] -> y [B,H,W,Co], both `dtype`.
  *   bias (fp32 [Co]) may be NULL; flags & BX_EPI_RELU applies max(.,0);
  *   relu_mask_src (dtype [B,H,W,Co], may be NULL): y *= (relu_mask_src > 0)  -- the ReLU backward

@@ -35,6 +35,11 @@ class EegParams(C.Structure):
                                   "bn2_rm", "bn2_rv", "bn2_nbt", "sep_w", "bn3_w", "bn3_b", "bn3_rm", "bn3_rv", "bn3_nbt")]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w_oihw", vp), ("packed_mfma", vp), ("Cout", i32), ("Cin", i32), ("I_p", i32), ("O_p", i32),
+                ("transpose_flip", i32), ("block_begin", i32)]
+
+
 class EegGrads(C.Structure):
     _fields_ = [(n, vp) for n in ("conv1_w", "bn1_w", "bn1_b", "dw_w", "bn2_w", "bn2_b", "sep_w", "bn3_w", "bn3_b")]
 
@@ -48,6 +53,7 @@ SIGNATURES = {
     "bx_nhwc_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "bx_conv3x3_pack": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "bx_conv3x3_packed_mfma_bytes": (sz, [i32, i32]),
+    "bx_conv3x3_pack_many": (i32, [vp, i32, i32, vp]),
     "bx_scale_dev": (i32, [vp, vp, vp, sz, vp]),
     "bx_abs": (i32, [vp, vp, sz, vp]),
     "bx_conv3x3": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),

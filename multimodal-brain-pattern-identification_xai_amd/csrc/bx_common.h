@@ -158,5 +158,34 @@ static __global__ void k_bn_finalize(const float* __restrict__ partials, int nbl
   save_invstd[c] = invstd;
 }
 
+// out[i] = sum_k part[k*n + i], fixed order.  A 256-thread workgroup covers NO = 256/S outputs x S chunk slices
+// (S = 4, 16 or 64, chosen by bx_partial_slices so that small outputs still fill the chip).
+static __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part, float* __restrict__ out, int nchunk, int n, int S) {
+  __shared__ float sm[256];
+  const int NO = 256 / S;
+  const int o = threadIdx.x % NO, sl = threadIdx.x / NO;
+  const int i = blockIdx.x * NO + o;
+  float s = 0.f;
+  if (i < n) {
+    int k = sl;
+    for (; k + 3 * S < nchunk; k += 4 * S) {
+      const float v0 = part[(size_t)k * n + i], v1 = part[(size_t)(k + S) * n + i];
+      const float v2 = part[(size_t)(k + 2 * S) * n + i], v3 = part[(size_t)(k + 3 * S) * n + i];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; k < nchunk; k += S) s += part[(size_t)k * n + i];
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    float r = sm[o];
+    for (int k = 1; k < S; ++k) r += sm[k * NO + o];
+    out[i] = r;
+  }
+}
+static inline int bx_partial_slices(int n, int nchunk) { return (n >= 16384 || nchunk <= 8) ? 4 : (n >= 2048 || nchunk <= 64) ? 16 : 64; }
+#define BX_SUM_PARTIALS(part, out, nchunk, n, stream) do { const int S_ = bx_partial_slices((n), (nchunk)); \
+  hipLaunchKernelGGL(k_sum_partials, dim3(bx_ceil_div((n), 256 / S_)), dim3(256), 0, (stream), (part), (out), (nchunk), (n), S_); } while (0)
+
 #define BX_DISPATCH_DTYPE(dtype, T, ...) \
   do { if ((dtype) == BX_F32) { typedef float T; __VA_ARGS__; } else { typedef bf16_t T; __VA_ARGS__; } } while (0)

@@ -59,6 +59,38 @@ void bx_conv3x3_mfma_pack_launch(const float* w_oihw, void* packed, int Cout, in
   hipLaunchKernelGGL(k_pack_mfma, dim3(grid), dim3(256), 0, s, w_oihw, (bf16_t*)packed, Cout, Cin, I_p, O_p, tf, ck, mfma_ks(ck), n);
 }
 
+// Many pack jobs in ONE launch (all 3x3 convolutions of the model, forward and data-gradient operands): the job
+// table lives in device memory and is built once by the host (parameter pointers are stable under FlatAdamW).
+__global__ __launch_bounds__(256) void k_pack_mfma_many(const bxPackJob* __restrict__ jobs, int njobs) {
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block_begin) ++j;
+  const bxPackJob jb = jobs[j];
+  const int ck = jb.I_p < 64 ? jb.I_p : 64, ks = (9 * ck + 31) / 32;
+  const size_t n = (size_t)(jb.I_p / ck) * ks * jb.O_p * 32;
+  const float* __restrict__ w = (const float*)jb.w_oihw;
+  bf16_t* __restrict__ wp = (bf16_t*)jb.packed_mfma;
+  const int nblk = (j + 1 < njobs ? jobs[j + 1].block_begin : (int)gridDim.x) - jb.block_begin;
+  for (size_t idx = (size_t)(blockIdx.x - jb.block_begin) * 256 + threadIdx.x; idx < n; idx += (size_t)nblk * 256) {
+    const int kk = (int)(idx & 31);
+    const int o = (int)((idx >> 5) % jb.O_p);
+    const int s = (int)((idx / ((size_t)32 * jb.O_p)) % ks);
+    const int chunk = (int)(idx / ((size_t)32 * jb.O_p * ks));
+    const int q = s * 32 + kk, tap = q / ck, i = chunk * ck + q % ck;
+    float v = 0.f;
+    if (tap < 9) {
+      if (!jb.transpose_flip) { if (i < jb.Cin && o < jb.Cout) v = w[((size_t)o * jb.Cin + i) * 9 + tap]; }
+      else                    { if (i < jb.Cout && o < jb.Cin) v = w[((size_t)i * jb.Cin + o) * 9 + (8 - tap)]; }
+    }
+    wp[idx] = f2bf(v);
+  }
+}
+extern "C" int bx_conv3x3_pack_many(const bxPackJob* jobs_device, int njobs, int total_blocks, bxStream stream) {
+  BX_REQUIRE(jobs_device && njobs > 0 && total_blocks > 0, "bx_conv3x3_pack_many: bad arguments");
+  hipLaunchKernelGGL(k_pack_mfma_many, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs);
+  BX_CHECK_LAUNCH("bx_conv3x3_pack_many");
+  return BX_OK;
+}
+
 template <int CK>
 __device__ __forceinline__ int lds_chunk(int c, int p) {
   if (CK == 32) return c ^ ((p >> 1) & 3);
@@ -237,7 +269,7 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* lds, int off0, int off1) 
 }
 
 template <int MA, int NB, int TW>
-__global__ __launch_bounds__(256) void k_wgrad_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dz, float* __restrict__ partial,
+__global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dz, float* __restrict__ partial,
     int H, int W, int Ci_p, int Co, int tiles_x, int tiles_y, int ntiles, int tiles_per_split) {
   constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CIT = 16 * MA, COT = 16 * NB, XB = CIT * 2, ZB = COT * 2;
   constexpr int KPW = TH * TW / 32 / 4;                 // K-steps (32 pixels) per wave per tile

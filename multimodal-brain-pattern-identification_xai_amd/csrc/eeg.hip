@@ -57,7 +57,7 @@ struct EegWs { size_t off_part, off_du3, off_dp1, off_du2, off_r, off_w1p, off_s
 static EegWs eeg_ws(const EegGeom& g) {
   EegWs w; size_t o = 0;
   const int rows = g.B * g.Ch;
-  w.nblk_rows = rows * ((g.T + EEG_TT - 1) / EEG_TT);
+  w.nblk_rows = rows;
   size_t npart = (size_t)w.nblk_rows;
   const size_t n_dw = (size_t)g.B * ((g.T + 255) / 256), n_sep = (size_t)g.B * ((g.T1 + 63) / 64);
   if (npart < n_dw) npart = n_dw;
@@ -81,39 +81,38 @@ extern "C" size_t bx_eeg_workspace(const bxEegDesc* d) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// E1: temporal convolution, one workgroup per (row = sample*electrode, 256-step time block).
+// E1: temporal convolution, one workgroup per row (sample, electrode): the whole padded row sits in LDS, each
+// thread walks the row in steps of 256 (8 filters x K1 taps per output, weights from wave-uniform scalar loads)
+// and keeps the BatchNorm partial sums in registers, so there is ONE partial per row.
 template <typename T>
 __global__ __launch_bounds__(EEG_TT) void k_eeg_conv1(const float* __restrict__ x, const float* __restrict__ w1, T* __restrict__ c1,
                                                       float* __restrict__ partials, EegGeom g, int want_stats) {
-  __shared__ float sx[EEG_TT + EEG_MAXK];
+  extern __shared__ float sx[];        // [T + K1 - 1]
   __shared__ float red[4][16];
-  const int nblk_t = (g.T + EEG_TT - 1) / EEG_TT;
-  const int row = blockIdx.x / nblk_t, tb = blockIdx.x % nblk_t;
+  const int row = blockIdx.x;
   const int b = row / g.Ch, ch = row % g.Ch;
-  const int t0 = tb * EEG_TT;
   const float* xr = x + (size_t)row * g.T;
-  for (int i = threadIdx.x; i < EEG_TT + g.K1 - 1; i += EEG_TT) {
-    const int t = t0 + i - g.padl1;
+  for (int i = threadIdx.x; i < g.T + g.K1 - 1; i += EEG_TT) {
+    const int t = i - g.padl1;
     sx[i] = (t >= 0 && t < g.T) ? xr[t] : 0.f;
   }
   __syncthreads();
-  const int t = t0 + threadIdx.x;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < g.K1; ++k) {
-    const float xv = sx[threadIdx.x + k];
-#pragma unroll
-    for (int f = 0; f < 8; ++f) acc[f] = fmaf(w1[f * g.K1 + k], xv, acc[f]);   // wave-uniform index -> s_load, SGPR operand
-  }
   float s[8], q[8];
 #pragma unroll
-  for (int f = 0; f < 8; ++f) {
-    float v = 0.f;
-    if (t < g.T) {
-      const size_t o = (((size_t)b * g.F1 + f) * g.Ch + ch) * g.T + t;
-      stf(c1, o, acc[f]);
-      v = round_as(c1, acc[f]);             // statistics of the stored value
+  for (int f = 0; f < 8; ++f) s[f] = q[f] = 0.f;
+  for (int t = threadIdx.x; t < g.T; t += EEG_TT) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < g.K1; ++k) {
+      const float xv = sx[t + k];
+#pragma unroll
+      for (int f = 0; f < 8; ++f) acc[f] = fmaf(w1[f * g.K1 + k], xv, acc[f]);   // wave-uniform index -> s_load, SGPR operand
     }
-    s[f] = v; q[f] = v * v;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      stf(c1, (((size_t)b * g.F1 + f) * g.Ch + ch) * g.T + t, acc[f]);
+      const float v = round_as(c1, acc[f]);                                    // statistics of the stored value
+      s[f] += v; q[f] += v * v;
+    }
   }
   if (!want_stats) return;
 #pragma unroll
@@ -123,11 +122,8 @@ __global__ __launch_bounds__(EEG_TT) void k_eeg_conv1(const float* __restrict__ 
 #pragma unroll
     for (int f = 0; f < 8; ++f) { red[wave][f] = s[f]; red[wave][8 + f] = q[f]; }
   __syncthreads();
-  if (threadIdx.x < 16) {
-    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    // layout [blk][2][F1]
-    partials[(size_t)blockIdx.x * 16 + threadIdx.x] = v;
-  }
+  if (threadIdx.x < 16)      // layout [row][2][F1]
+    partials[(size_t)blockIdx.x * 16 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // E2: BN1 apply + depthwise electrode mix; thread per (b, t) produces all FD maps.  grid (ceil(T/256), B)
@@ -242,6 +238,7 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
   EegGeom g;
   const int ge = eeg_geom(d, &g);
   BX_REQUIRE(ge == 0, "bx_eeg_features_fwd: unsupported geometry (code %d): need F1=8, D=2, F2=16, K1<=64, K2=16, Chans<=64", ge);
+  BX_REQUIRE(d->T <= 15000, "bx_eeg_features_fwd: T=%d exceeds the one-row LDS tile (<= 15000)", d->T);
   const EegWs w = eeg_ws(g);
   if (!workspace || workspace_bytes < w.total) BX_FAIL(BX_EWORKSPACE, "bx_eeg_features_fwd: workspace %zu < %zu", workspace_bytes, w.total);
   BX_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "bx_eeg_features_fwd: dropout_p must be in [0,1)");
@@ -257,7 +254,7 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
   BX_REQUIRE(pdrop == 0.f || seed, "bx_eeg_features_fwd: dropout needs a device seed");
 
   BX_DISPATCH_DTYPE(d->dtype, T,
-    hipLaunchKernelGGL((k_eeg_conv1<T>), dim3(w.nblk_rows), dim3(EEG_TT), 0, s, x, p->conv1_w, (T*)c1, part, g, tr));
+    hipLaunchKernelGGL((k_eeg_conv1<T>), dim3(w.nblk_rows), dim3(EEG_TT), (size_t)(g.T + g.K1) * sizeof(float), s, x, p->conv1_w, (T*)c1, part, g, tr));
   BX_CHECK_LAUNCH("eeg conv1");
   hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(1024), 0, s, part, w.nblk_rows, (double)g.B * g.Ch * g.T, g.F1, tr, p->bn1_w, p->bn1_b,
                      p->bn1_rm, p->bn1_rv, p->bn1_nbt, d->momentum, d->eps, st.sc1, st.sh1, st.mean1, st.inv1);
@@ -387,19 +384,6 @@ __global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ d
     wpart[(size_t)b * 4096 + i] = acc;
   }
 }
-__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part, float* __restrict__ out, int nchunk, int n) {
-  // 64 outputs x 4 slices per workgroup, slices combined in fixed order
-  __shared__ float sm[4][64];
-  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + o;
-  float s = 0.f;
-  if (i < n)
-    for (int k = sl; k < nchunk; k += 4) s += part[(size_t)k * n + i];
-  sm[sl][o] = s;
-  __syncthreads();
-  if (sl == 0 && i < n) out[i] = sm[0][o] + sm[1][o] + sm[2][o] + sm[3][o];
-}
-
 // depthwise backward pass A: per sample  R[fd][ch] = sum_t dd[fd][t] * c1[f][ch][t],  Sd[fd] = sum_t dd[fd][t]
 template <typename T>
 __global__ __launch_bounds__(256) void k_eeg_dw_bwd_a(const T* __restrict__ c1, const float* __restrict__ dd, float* __restrict__ rpart, EegGeom g) {
@@ -459,72 +443,90 @@ __global__ void k_eeg_dw_bwd_finalize(const float* __restrict__ rpart, int B, Ee
     coef[2 * EEG_MAXF + f] = training ? (float)(dg / N) : 0.f;
   }
 }
-// pass B: per (sample, electrode) row rebuild dc1[f][t] in LDS, then the temporal-conv weight gradient
-// partial dW1[f][k] = sum_t dc1[f][t] x[t+k-padl] and (optionally) dx[t] = sum_{f,k} w1[f][k] dc1[f][t-k+padl].
+// pass B: per (sample, electrode) row rebuild dc1[f][t] in LDS -- four filters at a time, so that three workgroups
+// fit a CU -- then the temporal-conv weight gradient partial dW1[f][k] = sum_t dc1[f][t] x[t+k-padl] (thread = filter x
+// 4 consecutive taps x one time quarter, sliding x window: 1 dc1 + 1 x LDS read per 4 FMAs) and, optionally,
+// dx[t] = sum_{f,k} w1[f][k] dc1[f][t-k+padl].
+#define EEG_DX_MAX 16          // dx values a thread can own: T <= 256*16
 template <typename T>
 __global__ __launch_bounds__(256) void k_eeg_conv1_bwd(const T* __restrict__ c1, const float* __restrict__ dd, const float* __restrict__ x,
     const float* __restrict__ dw, const float* __restrict__ w1, const float* __restrict__ mean1, const float* __restrict__ inv1,
     const float* __restrict__ coef, float* __restrict__ w1part, float* __restrict__ dx, EegGeom g) {
   extern __shared__ float sm[];
   const int Tn = g.T, TX = Tn + 2 * EEG_MAXK;
-  float* sdc = sm;                 // [8][TX]  dc1 with zero halo, index t + 64
-  float* sxr = sm + 8 * TX;        // [TX]     x row with zero halo, index t + 64
-  float* sw = sxr + TX;            // [8*K1]
+  float* sdc = sm;                 // [4][TX]  dc1 of the current filter group, zero halo, index t + 64
+  float* sxr = sm + 4 * TX;        // [TX]     x row with zero halo, index t + 64
+  float* comb = sxr + TX;          // [256][4]
   const int row = blockIdx.x, b = row / g.Ch, ch = row % g.Ch;
-  for (int i = threadIdx.x; i < 8 * TX; i += 256) sdc[i] = 0.f;
+  for (int i = threadIdx.x; i < 4 * TX; i += 256) sdc[i] = 0.f;
   for (int i = threadIdx.x; i < TX; i += 256) { const int t = i - EEG_MAXK; sxr[i] = (t >= 0 && t < Tn) ? x[(size_t)row * Tn + t] : 0.f; }
-  for (int i = threadIdx.x; i < 8 * g.K1; i += 256) sw[i] = w1[i];
-  __syncthreads();
+  float dxa[EEG_DX_MAX];
 #pragma unroll
-  for (int f = 0; f < 8; ++f) {
-    const float w0 = dw[(f * 2) * g.Ch + ch], w1d = dw[(f * 2 + 1) * g.Ch + ch];      // D == 2 (eeg_geom enforces it)
-    const float mu = mean1[f], is = inv1[f], ca = coef[f], k1 = coef[EEG_MAXF + f], k2 = coef[2 * EEG_MAXF + f];
-    const float* d0 = dd + ((size_t)b * g.FD + f * 2) * Tn;
-    const float* d1 = d0 + Tn;
-    const size_t cb = (((size_t)b * g.F1 + f) * g.Ch + ch) * Tn;
+  for (int k = 0; k < EEG_DX_MAX; ++k) dxa[k] = 0.f;
+  const int tid = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int ff = tid >> 4, k0 = (tid & 15) * 4;
+  for (int fg = 0; fg < 2; ++fg) {
+    __syncthreads();
+#pragma unroll
+    for (int f4 = 0; f4 < 4; ++f4) {
+      const int f = fg * 4 + f4;
+      const float w0 = dw[(f * 2) * g.Ch + ch], w1d = dw[(f * 2 + 1) * g.Ch + ch];      // D == 2 (eeg_geom enforces it)
+      const float mu = mean1[f], is = inv1[f], ca = coef[f], k1 = coef[EEG_MAXF + f], k2 = coef[2 * EEG_MAXF + f];
+      const float* d0 = dd + ((size_t)b * g.FD + f * 2) * Tn;
+      const float* d1 = d0 + Tn;
+      const size_t cb = (((size_t)b * g.F1 + f) * g.Ch + ch) * Tn;
 #pragma unroll 4
-    for (int t = threadIdx.x; t < Tn; t += 256) {
-      const float dbn = fmaf(w1d, d1[t], w0 * d0[t]);
-      const float xh = (ldf(c1, cb + t) - mu) * is;
-      sdc[f * TX + t + EEG_MAXK] = ca * (dbn - k1 - xh * k2);
-    }
-  }
-  __syncthreads();
-  if (w1part) {
-    // thread = (time half, filter f, 4 consecutive taps k0..k0+3): one dc1 read + one new x read per 4 FMAs
-    const int nq = (g.K1 + 3) / 4;                       // tap quads per filter
-    const int half = threadIdx.x >= 128, tid = threadIdx.x & 127;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const int f = tid / nq, k0 = (tid % nq) * 4;
-    const bool active = tid < 8 * nq;
-    if (active) {
-      const int tb = half ? Tn / 2 : 0, te = half ? Tn : Tn / 2;
-      const float* dc = sdc + f * TX + EEG_MAXK;
-      const float* xr = sxr + EEG_MAXK + k0 - g.padl1;
-      float x0 = xr[tb], x1 = xr[tb + 1], x2 = xr[tb + 2];
-      for (int t = tb; t < te; ++t) {
-        const float x3 = xr[t + 3], dv = dc[t];
-        a0 = fmaf(dv, x0, a0); a1 = fmaf(dv, x1, a1); a2 = fmaf(dv, x2, a2); a3 = fmaf(dv, x3, a3);
-        x0 = x1; x1 = x2; x2 = x3;
+      for (int t = threadIdx.x; t < Tn; t += 256) {
+        const float dbn = fmaf(w1d, d1[t], w0 * d0[t]);
+        const float xh = (ldf(c1, cb + t) - mu) * is;
+        sdc[f4 * TX + t + EEG_MAXK] = ca * (dbn - k1 - xh * k2);
       }
     }
     __syncthreads();
-    float* comb = sw + 8 * g.K1;                         // [128][4] scratch behind the weights
-    if (active && half) { comb[tid * 4 + 0] = a0; comb[tid * 4 + 1] = a1; comb[tid * 4 + 2] = a2; comb[tid * 4 + 3] = a3; }
-    __syncthreads();
-    if (active && !half) {
-      const float r[4] = {a0 + comb[tid * 4 + 0], a1 + comb[tid * 4 + 1], a2 + comb[tid * 4 + 2], a3 + comb[tid * 4 + 3]};
-      for (int j = 0; j < 4; ++j)
-        if (k0 + j < g.K1) w1part[(size_t)row * 8 * g.K1 + f * g.K1 + k0 + j] = r[j];
+    if (w1part) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      const bool active = k0 < g.K1;
+      if (active) {
+        const int tb = (int)((long long)Tn * part / 4), te = (int)((long long)Tn * (part + 1) / 4);
+        const float* dc = sdc + ff * TX + EEG_MAXK;
+        const float* xr = sxr + EEG_MAXK + k0 - g.padl1;
+        float x0 = xr[tb], x1 = xr[tb + 1], x2 = xr[tb + 2];
+        for (int t = tb; t < te; ++t) {
+          const float x3 = xr[t + 3], dv = dc[t];
+          a0 = fmaf(dv, x0, a0); a1 = fmaf(dv, x1, a1); a2 = fmaf(dv, x2, a2); a3 = fmaf(dv, x3, a3);
+          x0 = x1; x1 = x2; x2 = x3;
+        }
+      }
+      comb[threadIdx.x * 4 + 0] = a0; comb[threadIdx.x * 4 + 1] = a1; comb[threadIdx.x * 4 + 2] = a2; comb[threadIdx.x * 4 + 3] = a3;
+      __syncthreads();
+      if (part == 0 && active) {
+        for (int j = 0; j < 4; ++j)
+          if (k0 + j < g.K1)
+            w1part[(size_t)row * 8 * g.K1 + (fg * 4 + ff) * g.K1 + k0 + j] =
+                comb[tid * 4 + j] + comb[(64 + tid) * 4 + j] + comb[(128 + tid) * 4 + j] + comb[(192 + tid) * 4 + j];
+      }
+    }
+    if (dx) {
+#pragma unroll
+      for (int k = 0; k < EEG_DX_MAX; ++k) {
+        const int t = threadIdx.x + k * 256;
+        if (t < Tn) {
+          float acc = dxa[k];
+          for (int f4 = 0; f4 < 4; ++f4)
+            for (int kk = 0; kk < g.K1; ++kk)
+              acc = fmaf(w1[(fg * 4 + f4) * g.K1 + kk], sdc[f4 * TX + EEG_MAXK + t - kk + g.padl1], acc);
+          dxa[k] = acc;
+        }
+      }
     }
   }
-  if (dx)
-    for (int t = threadIdx.x; t < Tn; t += 256) {
-      float acc = 0.f;
-      for (int f = 0; f < 8; ++f)
-        for (int k = 0; k < g.K1; ++k) acc = fmaf(sw[f * g.K1 + k], sdc[f * TX + EEG_MAXK + t - k + g.padl1], acc);
-      dx[(size_t)row * Tn + t] = acc;
+  if (dx) {
+#pragma unroll
+    for (int k = 0; k < EEG_DX_MAX; ++k) {
+      const int t = threadIdx.x + k * 256;
+      if (t < Tn) dx[(size_t)row * Tn + t] = dxa[k];
     }
+  }
 }
 
 extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, const float* x, const float* dfeat,
@@ -579,7 +581,7 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
     hipLaunchKernelGGL(k_eeg_sep_bwd, dim3(g.B, 4), dim3(256), lds, s, du3, p1, p->sep_w, dp1, sepp, g);
     BX_CHECK_LAUNCH("eeg sep bwd");
     if (gr->sep_w) {
-      hipLaunchKernelGGL(k_sum_partials, dim3(64), dim3(256), 0, s, sepp, gr->sep_w, g.B, 4096);
+      BX_SUM_PARTIALS(sepp, gr->sep_w, g.B, 4096, s);
       BX_CHECK_LAUNCH("eeg sep wgrad reduce");
     }
   }
@@ -602,8 +604,8 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
                      gr->dw_w, gr->bn1_w, gr->bn1_b, coef1);
   BX_CHECK_LAUNCH("eeg dw bwd finalize");
   if (gr->conv1_w || dx) {
-    const size_t lds = ((size_t)9 * (g.T + 2 * EEG_MAXK) + 8 * g.K1 + 512) * sizeof(float);
-    BX_REQUIRE(lds <= 160 * 1024, "bx_eeg_features_bwd: T too long for the LDS tile (%zu bytes)", lds);
+    const size_t lds = ((size_t)5 * (g.T + 2 * EEG_MAXK) + 1024) * sizeof(float);
+    BX_REQUIRE(lds <= 160 * 1024 && g.T <= 256 * EEG_DX_MAX, "bx_eeg_features_bwd: T too long (LDS tile %zu bytes, T <= %d)", lds, 256 * EEG_DX_MAX);
     BX_DISPATCH_DTYPE(d->dtype, T,
       if (hipFuncSetAttribute((const void*)k_eeg_conv1_bwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         BX_FAIL(BX_EHIP, "bx_eeg_features_bwd: cannot reserve %zu bytes of LDS", lds);
@@ -611,7 +613,7 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
                          coef1, gr->conv1_w ? w1part : (float*)nullptr, dx, g));
     BX_CHECK_LAUNCH("eeg conv1 bwd");
     if (gr->conv1_w) {
-      hipLaunchKernelGGL(k_sum_partials, dim3(bx_ceil_div(8 * g.K1, 64)), dim3(256), 0, s, w1part, gr->conv1_w, g.B * g.Ch, 8 * g.K1);
+      BX_SUM_PARTIALS(w1part, gr->conv1_w, g.B * g.Ch, 8 * g.K1, s);
       BX_CHECK_LAUNCH("eeg conv1 wgrad reduce");
     }
   }

@@ -167,7 +167,7 @@ extern "C" size_t bx_block_tail_workspace(const bxTailDesc* d) {
   size_t fwd = ((size_t)TAIL_MAX_BLOCKS * 2 + 2) * d->C * sizeof(float) + (size_t)d->Cin_p * d->C * sizeof(float);
   size_t bwd = ((size_t)TAIL_MAX_BLOCKS * 3 + 3) * d->C * sizeof(float)                 // partials + coefficients
              + bx_align_up((size_t)d->B * Ho * Wo * d->Cin_p * sizeof(float), 256)       // dXs (half-res, fp32)
-             + (size_t)1024 * 256 * sizeof(float) + (size_t)64 * d->C * d->Cin_p * sizeof(float);   // conv1x1 weight-grad partials
+             + (size_t)1024 * 256 * sizeof(float) + (size_t)65 * d->C * d->Cin_p * sizeof(float);   // conv1x1 weight-grad partials (+1 slab for compaction)
   return bx_align_up(fwd > bwd ? fwd : bwd, 256);
 }
 
@@ -434,20 +434,12 @@ __global__ __launch_bounds__(256) void k_w1x1_grad(const T* __restrict__ dout, c
   }
   if (ci0 + ci < g.Cin_p) partial[((size_t)blockIdx.x * g.C + c0 + c) * g.Cin_p + ci0 + ci] = acc;
 }
-__global__ __launch_bounds__(256) void k_w1x1_reduce(const float* __restrict__ partial, float* __restrict__ dw, int nchunk, int C, int Cin, int Cin_p) {
-  // 64 outputs x 4 chunk slices per workgroup, combined in fixed order
-  __shared__ float sm[4][64];
-  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + o;
-  float s = 0.f;
-  if (idx < C * Cin_p)
-    for (int k = sl; k < nchunk; k += 4) s += partial[(size_t)k * C * Cin_p + idx];
-  sm[sl][o] = s;
-  __syncthreads();
-  if (sl == 0 && idx < C * Cin_p) {
-    const int c = idx / Cin_p, ci = idx % Cin_p;
-    if (ci < Cin) dw[(size_t)c * Cin + ci] = sm[0][o] + sm[1][o] + sm[2][o] + sm[3][o];
-  }
+// dW1x1: partial layout [chunk][C][Cin_p]; when Cin == Cin_p the sum lands directly in the OIHW gradient,
+// otherwise (padded first stage) it goes through a compaction.
+__global__ void k_w1x1_compact(const float* __restrict__ src, float* __restrict__ dw, int C, int Cin, int Cin_p) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= C * Cin) return;
+  dw[idx] = src[(idx / Cin) * Cin_p + idx % Cin];
 }
 
 extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const void* y3, const void* x, const void* pooled,
@@ -498,7 +490,13 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
     BX_DISPATCH_DTYPE(d->dtype, T,
       hipLaunchKernelGGL((k_w1x1_grad<T>), grid, dim3(256), 0, s, (const T*)dout, (const T*)x, wpart, ppc, g));
     BX_CHECK_LAUNCH("bx_block_tail_bwd(w1x1)");
-    hipLaunchKernelGGL(k_w1x1_reduce, dim3(bx_ceil_div(g.C * g.Cin_p, 64)), dim3(256), 0, s, wpart, d_w1x1, nchunk, g.C, Cin, g.Cin_p);
+    if (Cin == g.Cin_p) {
+      BX_SUM_PARTIALS(wpart, d_w1x1, nchunk, g.C * g.Cin_p, s);
+    } else {
+      float* tmp = wpart + (size_t)nchunk * g.C * g.Cin_p;           // spare room behind the partials (workspace formula)
+      BX_SUM_PARTIALS(wpart, tmp, nchunk, g.C * g.Cin_p, s);
+      hipLaunchKernelGGL(k_w1x1_compact, dim3(bx_ceil_div(g.C * Cin, 256)), dim3(256), 0, s, tmp, d_w1x1, g.C, Cin, g.Cin_p);
+    }
     BX_CHECK_LAUNCH("bx_block_tail_bwd(w1x1 reduce)");
   }
   if (dx_skip) {

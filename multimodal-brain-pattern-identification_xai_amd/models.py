@@ -48,6 +48,7 @@ class Block(nn.Module):
         self.salt = 0
         self._preact = 0          # set by explain.grad_cam for targets "blockN.convK"
         self._capture = None
+        self._prepacked, self._pack_base = None, 0      # set per forward by Spectrogram_Model (one pack launch for all stages)
 
     def forward(self, x):
         dt = self.compute_dtype
@@ -62,7 +63,7 @@ class Block(nn.Module):
         bn = self.bn
         cfg = ops.block_cfg(pool=self.pool_type, training=self.training, dropout_p=self.dropout.p if self.training else 0.0,
                             eps=bn.eps, momentum=0.1 if bn.momentum is None else bn.momentum, salt=self.salt,
-                            preact=self._preact, capture=self._capture)
+                            preact=self._preact, capture=self._capture, prepacked=self._prepacked, pack_base=self._pack_base)
         out = ops.BlockFn.apply(xi, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.conv3.weight,
                                 self.conv3.bias, bn.weight, bn.bias, self.conv1x1.weight, self.conv1x1.bias,
                                 bn.running_mean, bn.running_var, bn.num_batches_tracked, cfg)
@@ -86,9 +87,30 @@ class Spectrogram_Model(nn.Module):
         self.log_softmax = nn.LogSoftmax(dim=1)
         self.compute_dtype = torch.float32
 
+    def _pack_all(self):
+        """bf16 MFMA path: ONE launch packs the forward and data-gradient operands of all 15 convolutions."""
+        blocks = [getattr(self, f"block{i}") for i in range(1, 6)]
+        for blk in blocks:
+            blk._prepacked = None
+        if self.compute_dtype != torch.bfloat16 or ops.CONV_ALGO == ops.L.BX_ALGO_DIRECT or not self.fc.weight.is_cuda:
+            return
+        weights = [getattr(b, f"conv{k}").weight for b in blocks for k in (1, 2, 3)]
+        plan = getattr(self, "_pack_plan", None)
+        if plan is None or plan.key != tuple(w.data_ptr() for w in weights):
+            plan = ops.PackPlan(weights)
+            self._pack_plan = plan
+        plan.run()
+        for bi, blk in enumerate(blocks):
+            blk._prepacked, blk._pack_base = plan, 3 * bi
+
     def features(self, x):
-        for i in range(1, 6):
-            x = getattr(self, f"block{i}")(x)
+        self._pack_all()
+        try:
+            for i in range(1, 6):
+                x = getattr(self, f"block{i}")(x)
+        finally:
+            for i in range(1, 6):
+                getattr(self, f"block{i}")._prepacked = None
         return x
 
     def forward(self, x):

@@ -173,6 +173,47 @@ def _pack(w: torch.Tensor, flip: bool, dtype=None):
     return pf, pm, ip, op
 
 
+class PackPlan:
+    """All MFMA weight operands (forward + data-gradient) of a list of 3x3 convolutions, packed by ONE launch.
+
+    Built once per set of parameter storages (stable under FlatAdamW); ``run()`` re-packs every step because the
+    weights change.  ``get(i, flip)`` returns the operand tuple _conv expects, or None when the MFMA path does not
+    cover that shape (the caller then packs it individually)."""
+
+    def __init__(self, weights):
+        import ctypes
+        lib = L.load()
+        dev = weights[0].device
+        self.key = tuple(w.data_ptr() for w in weights)
+        entries, off = [], 0
+        for i, w in enumerate(weights):
+            co, ci = w.shape[0], w.shape[1]
+            for flip in (False, True):
+                i_log, o_log = (co, ci) if flip else (ci, co)
+                ip, op = pad8(i_log), pad8(o_log)
+                nb = lib.bx_conv3x3_packed_mfma_bytes(ip, op)
+                if nb:
+                    entries.append((i, flip, w, co, ci, ip, op, off, nb))
+                    off += (nb + 255) // 256 * 256
+        self.buf = torch.empty(max(off, 256), dtype=torch.uint8, device=dev)
+        self.views, jobs, blk = {}, (L.PackJob * len(entries))(), 0
+        for j, (i, flip, w, co, ci, ip, op, o, nb) in enumerate(entries):
+            view = self.buf.narrow(0, o, nb)
+            self.views[(i, flip)] = (None, view, ip, op)
+            jobs[j] = L.PackJob(w.data_ptr(), view.data_ptr(), co, ci, ip, op, 1 if flip else 0, blk)
+            blk += max(1, min(64, (nb // 2 + 1023) // 1024))
+        self.njobs, self.nblocks = len(entries), blk
+        raw = bytes(memoryview(jobs)) if entries else b"\0" * 8
+        self.jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+
+    def run(self):
+        if self.njobs:
+            L.check(L.load().bx_conv3x3_pack_many(_p(self.jobs_dev), self.njobs, self.nblocks, _stream()), "bx_conv3x3_pack_many")
+
+    def get(self, i, flip):
+        return self.views.get((i, flip))
+
+
 def _conv(x, packed, bias, mask_src, addend, relu: bool, dtype):
     pf, pm, ip, op = packed
     B, H, W, Ci = x.shape
@@ -222,7 +263,9 @@ class BlockFn(torch.autograd.Function):
         ws_, bs_ = (w1, w2, w3), (b1, b2, b3)
         acts, pre = [x], None
         for k in range(3):
-            packed = _pack(ws_[k], flip=False, dtype=dt)
+            packed = cfg.prepacked.get(cfg.pack_base + k, False) if cfg.prepacked is not None else None
+            if packed is None:
+                packed = _pack(ws_[k], flip=False, dtype=dt)
             if cfg.preact == k + 1:
                 pre = _conv(acts[-1], packed, bs_[k], None, None, False, dt)
                 y = torch.empty_like(pre)
@@ -274,12 +317,13 @@ class BlockFn(torch.autograd.Function):
         for k in (2, 1, 0):
             if need_w:
                 grads_w[k], grads_b[k] = _wgrad(acts[k], dz, wts[k], bss[k])
+            packed = cfg.prepacked.get(cfg.pack_base + k, True) if cfg.prepacked is not None else None
             if k > 0:
-                dz = _conv(dz, _pack(wts[k], flip=True, dtype=dt), None, acts[k], None, False, dt)
+                dz = _conv(dz, packed or _pack(wts[k], flip=True, dtype=dt), None, acts[k], None, False, dt)
                 if cfg.preact == k:
                     cfg.capture["grad"] = dz
             elif need_dx:
-                dz = _conv(dz, _pack(wts[0], flip=True, dtype=dt), None, None, dx_skip, False, dt)
+                dz = _conv(dz, packed or _pack(wts[0], flip=True, dtype=dt), None, None, dx_skip, False, dt)
         dx = dz if need_dx else None
         return (dx, grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2], d_bnw, d_bnb, d_w11, d_b11,
                 None, None, None, None)
@@ -433,6 +477,7 @@ class EegFeaturesFn(torch.autograd.Function):
 
 
 def block_cfg(**kw) -> SimpleNamespace:
-    base = dict(pool="max", training=False, dropout_p=0.0, eps=1e-5, momentum=0.1, salt=0, preact=0, capture=None)
+    base = dict(pool="max", training=False, dropout_p=0.0, eps=1e-5, momentum=0.1, salt=0, preact=0, capture=None,
+                prepacked=None, pack_base=0)
     base.update(kw)
     return SimpleNamespace(**base)
