@@ -223,16 +223,20 @@ static int launch_conv(const void* x, const void* wp, const float* bias, const v
   BX_CHECK_LAUNCH("bx_conv3x3(mfma)");
   return BX_OK;
 }
+// Tile choice: small late-stage maps would launch fewer workgroups than the chip has CUs (each then serialises its
+// own stage -> MFMA chain); prefer 8x16 pixel tiles and fewer output channels per workgroup until >= 512 are in flight.
 template <int CK, int NC>
 static int launch_conv_tw(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
                           int B, int H, int W, int Ci, int Co, int relu, hipStream_t s) {
-  if (W <= 16) return launch_conv<CK, NC, 16>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
+  const long long wgs32 = (long long)((W + 31) / 32) * ((H + 7) / 8) * B * (Co / (16 * NC));
+  if (W <= 16 || wgs32 < 512) return launch_conv<CK, NC, 16>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
   return launch_conv<CK, NC, 32>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
 }
 template <int CK>
 static int launch_conv_nc(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
                           int B, int H, int W, int Ci, int Co, int relu, hipStream_t s) {
-  if (Co % 64 == 0) return launch_conv_tw<CK, 4>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
+  const long long tiles16 = (long long)((W + 15) / 16) * ((H + 7) / 8) * B;
+  if (Co % 64 == 0 && tiles16 * (Co / 64) >= 512) return launch_conv_tw<CK, 4>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
   if (Co % 32 == 0) return launch_conv_tw<CK, 2>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
   return launch_conv_tw<CK, 1>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
 }

@@ -81,37 +81,61 @@ extern "C" size_t bx_eeg_workspace(const bxEegDesc* d) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// E1: temporal convolution, one workgroup per row (sample, electrode): the whole padded row sits in LDS, each
-// thread walks the row in steps of 256 (8 filters x K1 taps per output, weights from wave-uniform scalar loads)
-// and keeps the BatchNorm partial sums in registers, so there is ONE partial per row.
+// E1: temporal convolution, one workgroup per row (sample, electrode): the whole padded row and the transposed
+// filter bank ([k][8 filters]) sit in LDS; a thread produces 4 consecutive time steps x 8 filters (32 accumulators)
+// with a sliding input window: per tap 1 input read + 2 broadcast ds_read_b128 of weights feed 32 FMAs.  BatchNorm
+// partial sums stay in registers: ONE partial per row.
 template <typename T>
 __global__ __launch_bounds__(EEG_TT) void k_eeg_conv1(const float* __restrict__ x, const float* __restrict__ w1, T* __restrict__ c1,
                                                       float* __restrict__ partials, EegGeom g, int want_stats) {
-  extern __shared__ float sx[];        // [T + K1 - 1]
+  extern __shared__ __attribute__((aligned(16))) float sm1[];
+  float* swt = sm1;                    // [K1][8]
+  float* sx = sm1 + 8 * EEG_MAXK;      // [T + K1 + 3]
   __shared__ float red[4][16];
   const int row = blockIdx.x;
   const int b = row / g.Ch, ch = row % g.Ch;
   const float* xr = x + (size_t)row * g.T;
-  for (int i = threadIdx.x; i < g.T + g.K1 - 1; i += EEG_TT) {
+  for (int i = threadIdx.x; i < g.T + g.K1 + 3; i += EEG_TT) {
     const int t = i - g.padl1;
     sx[i] = (t >= 0 && t < g.T) ? xr[t] : 0.f;
   }
+  for (int i = threadIdx.x; i < 8 * g.K1; i += EEG_TT) swt[(i % g.K1) * 8 + i / g.K1] = w1[i];
   __syncthreads();
   float s[8], q[8];
 #pragma unroll
   for (int f = 0; f < 8; ++f) s[f] = q[f] = 0.f;
-  for (int t = threadIdx.x; t < g.T; t += EEG_TT) {
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < g.K1; ++k) {
-      const float xv = sx[t + k];
+  const int nq = (g.T + 3) / 4;
+  for (int i = threadIdx.x; i < nq; i += EEG_TT) {
+    const int t0 = 4 * i;
+    float acc[4][8];
 #pragma unroll
-      for (int f = 0; f < 8; ++f) acc[f] = fmaf(w1[f * g.K1 + k], xv, acc[f]);   // wave-uniform index -> s_load, SGPR operand
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int f = 0; f < 8; ++f) acc[j][f] = 0.f;
+    float x0 = sx[t0], x1 = sx[t0 + 1], x2 = sx[t0 + 2];
+#pragma unroll 4
+    for (int k = 0; k < g.K1; ++k) {
+      const float x3 = sx[t0 + k + 3];
+      const float4 wa = *reinterpret_cast<const float4*>(swt + k * 8);
+      const float4 wb = *reinterpret_cast<const float4*>(swt + k * 8 + 4);
+      const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+      const float xw[4] = {x0, x1, x2, x3};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int f = 0; f < 8; ++f) acc[j][f] = fmaf(wv[f], xw[j], acc[j][f]);
+      x0 = x1; x1 = x2; x2 = x3;
     }
 #pragma unroll
     for (int f = 0; f < 8; ++f) {
-      stf(c1, (((size_t)b * g.F1 + f) * g.Ch + ch) * g.T + t, acc[f]);
-      const float v = round_as(c1, acc[f]);                                    // statistics of the stored value
-      s[f] += v; q[f] += v * v;
+      const size_t o = (((size_t)b * g.F1 + f) * g.Ch + ch) * g.T + t0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (t0 + j < g.T) {
+          stf(c1, o + j, acc[j][f]);
+          const float v = round_as(c1, acc[j][f]);                                // statistics of the stored value
+          s[f] += v; q[f] += v * v;
+        }
     }
   }
   if (!want_stats) return;
@@ -254,7 +278,7 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
   BX_REQUIRE(pdrop == 0.f || seed, "bx_eeg_features_fwd: dropout needs a device seed");
 
   BX_DISPATCH_DTYPE(d->dtype, T,
-    hipLaunchKernelGGL((k_eeg_conv1<T>), dim3(w.nblk_rows), dim3(EEG_TT), (size_t)(g.T + g.K1) * sizeof(float), s, x, p->conv1_w, (T*)c1, part, g, tr));
+    hipLaunchKernelGGL((k_eeg_conv1<T>), dim3(w.nblk_rows), dim3(EEG_TT), (size_t)(8 * EEG_MAXK + g.T + g.K1 + 8) * sizeof(float), s, x, p->conv1_w, (T*)c1, part, g, tr));
   BX_CHECK_LAUNCH("eeg conv1");
   hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(1024), 0, s, part, w.nblk_rows, (double)g.B * g.Ch * g.T, g.F1, tr, p->bn1_w, p->bn1_b,
                      p->bn1_rm, p->bn1_rv, p->bn1_nbt, d->momentum, d->eps, st.sc1, st.sh1, st.mean1, st.inv1);
@@ -491,7 +515,18 @@ __global__ __launch_bounds__(256) void k_eeg_conv1_bwd(const T* __restrict__ c1,
         const float* dc = sdc + ff * TX + EEG_MAXK;
         const float* xr = sxr + EEG_MAXK + k0 - g.padl1;
         float x0 = xr[tb], x1 = xr[tb + 1], x2 = xr[tb + 2];
-        for (int t = tb; t < te; ++t) {
+        int t = tb;
+        for (; t + 8 <= te; t += 8) {           // 16 LDS reads issued together, then 32 FMAs (a serial 1-read-per-step loop is LDS-latency bound)
+          float dv[8], xn[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { dv[j] = dc[t + j]; xn[j] = xr[t + 3 + j]; }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            a0 = fmaf(dv[j], x0, a0); a1 = fmaf(dv[j], x1, a1); a2 = fmaf(dv[j], x2, a2); a3 = fmaf(dv[j], xn[j], a3);
+            x0 = x1; x1 = x2; x2 = xn[j];
+          }
+        }
+        for (; t < te; ++t) {
           const float x3 = xr[t + 3], dv = dc[t];
           a0 = fmaf(dv, x0, a0); a1 = fmaf(dv, x1, a1); a2 = fmaf(dv, x2, a2); a3 = fmaf(dv, x3, a3);
           x0 = x1; x1 = x2; x2 = x3;

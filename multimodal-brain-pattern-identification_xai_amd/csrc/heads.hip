@@ -43,10 +43,13 @@ __global__ __launch_bounds__(256) void k_linear_lsm_fwd(const float* __restrict_
 }
 
 // dlogit = dlogp - softmax * sum(dlogp)
+// (loops are fully unrolled over HEAD_MAX_N with guards: a runtime-indexed per-thread array would live in scratch memory)
 __device__ __forceinline__ void lsm_bwd_row(const float* dlogp, const float* logp, int N, float* dlogit) {
   float s = 0.f;
-  for (int n = 0; n < N; ++n) s += dlogp[n];
-  for (int n = 0; n < N; ++n) dlogit[n] = dlogp[n] - expf(logp[n]) * s;
+#pragma unroll
+  for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) s += dlogp[n];
+#pragma unroll
+  for (int n = 0; n < HEAD_MAX_N; ++n) dlogit[n] = n < N ? dlogp[n] - expf(logp[n]) * s : 0.f;
 }
 
 // input gradient: dx[b][k] = sum_n dlogit[b][n] W[n][k]; GAP variant broadcasts dx/HW over the pixels
@@ -58,7 +61,8 @@ __global__ __launch_bounds__(256) void k_linear_lsm_bwd_dx(const float* __restri
   lsm_bwd_row(dlogp + (size_t)b * N, logp + (size_t)b * N, N, dl);
   for (int k = threadIdx.x; k < K; k += 256) {
     float s = 0.f;
-    for (int n = 0; n < N; ++n) s = fmaf(dl[n], w[(size_t)n * K + k], s);
+#pragma unroll
+    for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) s = fmaf(dl[n], w[(size_t)n * K + k], s);
     if (GAP) {
       s /= (float)HW;
       for (int p = 0; p < HW; ++p) stf(dfeat, ((size_t)b * HW + p) * K + k, s);
@@ -67,22 +71,37 @@ __global__ __launch_bounds__(256) void k_linear_lsm_bwd_dx(const float* __restri
     }
   }
 }
-// parameter gradients: thread per (n,k); loops the batch in order
+// parameter gradients: the workgroup first builds dlogit[b][n] in LDS (B*N values), then thread k accumulates its N
+// outputs over the batch in order (x[b][k] coalesced, dlogit broadcast from LDS); thread 0 of block 0 sums the bias.
 __global__ __launch_bounds__(256) void k_linear_lsm_bwd_w(const float* __restrict__ dlogp, const float* __restrict__ logp,
     const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int B, int K, int N) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= N * K + N) return;
-  const bool is_bias = idx >= N * K;
-  const int n = is_bias ? idx - N * K : idx / K, k = is_bias ? 0 : idx % K;
-  float acc = 0.f;
-  for (int b = 0; b < B; ++b) {
-    float s = 0.f;
-    for (int j = 0; j < N; ++j) s += dlogp[(size_t)b * N + j];
-    const float dl = dlogp[(size_t)b * N + n] - expf(logp[(size_t)b * N + n]) * s;
-    acc += is_bias ? dl : dl * x[(size_t)b * K + k];
+  extern __shared__ float sdl[];   // [B][N]
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float dl[HEAD_MAX_N];
+    lsm_bwd_row(dlogp + (size_t)b * N, logp + (size_t)b * N, N, dl);
+#pragma unroll
+    for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) sdl[b * N + n] = dl[n];
   }
-  if (is_bias) { if (db) db[n] = acc; }
-  else if (dw) dw[idx] = acc;
+  __syncthreads();
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < K && dw) {
+    float acc[HEAD_MAX_N];
+#pragma unroll
+    for (int n = 0; n < HEAD_MAX_N; ++n) acc[n] = 0.f;
+#pragma unroll 4
+    for (int b = 0; b < B; ++b) {              // independent loads: keep several in flight
+      const float xv = x[(size_t)b * K + k];
+#pragma unroll
+      for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) acc[n] = fmaf(sdl[b * N + n], xv, acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) dw[(size_t)n * K + k] = acc[n];
+  }
+  if (db && blockIdx.x == 0 && (int)threadIdx.x < N) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += sdl[b * N + threadIdx.x];
+    db[threadIdx.x] = s;
+  }
 }
 
 extern "C" int bx_linear_lsm_fwd(const float* x, const float* w, const float* b, float* logp, int B, int K, int N, bxStream stream) {
@@ -94,13 +113,14 @@ extern "C" int bx_linear_lsm_fwd(const float* x, const float* w, const float* b,
 extern "C" int bx_linear_lsm_bwd(const float* dlogp, const float* logp, const float* x, const float* w, float* dx,
                                  float* dw, float* db, int B, int K, int N, bxStream stream) {
   BX_REQUIRE(dlogp && logp && x && w && B > 0 && K > 0 && N > 0 && N <= HEAD_MAX_N, "bx_linear_lsm_bwd: bad arguments");
+  BX_REQUIRE((size_t)B * N * sizeof(float) <= 60 * 1024, "bx_linear_lsm_bwd: batch %d too large for the LDS gradient tile (B*N <= 15360)", B);
   hipStream_t s = (hipStream_t)stream;
   if (dx) {
     hipLaunchKernelGGL((k_linear_lsm_bwd_dx<float, false>), dim3(B), dim3(256), 0, s, dlogp, logp, w, dx, (float*)nullptr, K, N, 1);
     BX_CHECK_LAUNCH("bx_linear_lsm_bwd(dx)");
   }
   if (dw || db) {
-    hipLaunchKernelGGL(k_linear_lsm_bwd_w, dim3(bx_ceil_div(N * K + N, 256)), dim3(256), 0, s, dlogp, logp, x, dw, db, B, K, N);
+    hipLaunchKernelGGL(k_linear_lsm_bwd_w, dim3(bx_ceil_div(K, 256)), dim3(256), (size_t)B * N * sizeof(float), s, dlogp, logp, x, dw, db, B, K, N);
     BX_CHECK_LAUNCH("bx_linear_lsm_bwd(w)");
   }
   return BX_OK;
@@ -121,6 +141,7 @@ extern "C" int bx_gap_fc_lsm_bwd(const float* dlogp, const float* logp, const fl
                                  void* dfeat, float* dw, float* db, int B, int HW, int C, int N, int dtype, bxStream stream) {
   BX_DTYPE_OK(dtype);
   BX_REQUIRE(dlogp && logp && gap_out && w && B > 0 && HW > 0 && C > 0 && N > 0 && N <= HEAD_MAX_N, "bx_gap_fc_lsm_bwd: bad arguments");
+  BX_REQUIRE((size_t)B * N * sizeof(float) <= 60 * 1024, "bx_gap_fc_lsm_bwd: batch %d too large for the LDS gradient tile (B*N <= 15360)", B);
   hipStream_t s = (hipStream_t)stream;
   if (dfeat) {
     BX_DISPATCH_DTYPE(dtype, T,
@@ -128,7 +149,7 @@ extern "C" int bx_gap_fc_lsm_bwd(const float* dlogp, const float* logp, const fl
     BX_CHECK_LAUNCH("bx_gap_fc_lsm_bwd(dfeat)");
   }
   if (dw || db) {
-    hipLaunchKernelGGL(k_linear_lsm_bwd_w, dim3(bx_ceil_div(N * C + N, 256)), dim3(256), 0, s, dlogp, logp, gap_out, dw, db, B, C, N);
+    hipLaunchKernelGGL(k_linear_lsm_bwd_w, dim3(bx_ceil_div(C, 256)), dim3(256), (size_t)B * N * sizeof(float), s, dlogp, logp, gap_out, dw, db, B, C, N);
     BX_CHECK_LAUNCH("bx_gap_fc_lsm_bwd(w)");
   }
   return BX_OK;
@@ -177,7 +198,8 @@ __global__ void k_fusion_bwd_in(const float* __restrict__ dlogp, const float* __
   lsm_bwd_row(dlogp + (size_t)b * N, logp + (size_t)b * N, N, dl);
   if (j < Hd) {
     float s = 0.f;
-    for (int n = 0; n < N; ++n) s = fmaf(dl[n], w2[(size_t)n * Hd + j], s);
+#pragma unroll
+    for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) s = fmaf(dl[n], w2[(size_t)n * Hd + j], s);
     sm[j] = hidden[(size_t)b * Hd + j] > 0.f ? s : 0.f;
   }
   __syncthreads();
@@ -194,26 +216,37 @@ __global__ __launch_bounds__(64) void k_fusion_bwd_w(const float* __restrict__ d
                                float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
                                int B, int N, int Hd) {
   const int j = blockIdx.x, lane = threadIdx.x;
-  float a1[2 * HEAD_MAX_N], a2[HEAD_MAX_N], ab2[HEAD_MAX_N], ab1 = 0.f;
-  for (int i = 0; i < 2 * N; ++i) a1[i] = 0.f;
-  for (int n = 0; n < N; ++n) a2[n] = ab2[n] = 0.f;
+  float a1e[HEAD_MAX_N], a1s[HEAD_MAX_N], a2[HEAD_MAX_N], ab2[HEAD_MAX_N], ab1 = 0.f;
+#pragma unroll
+  for (int n = 0; n < HEAD_MAX_N; ++n) a1e[n] = a1s[n] = a2[n] = ab2[n] = 0.f;
   for (int b = lane; b < B; b += 64) {
     float dl[HEAD_MAX_N];
     lsm_bwd_row(dlogp + (size_t)b * N, logp + (size_t)b * N, N, dl);
     const float hj = hidden[(size_t)b * Hd + j];
     float dh = 0.f;
-    for (int n = 0; n < N; ++n) { dh = fmaf(dl[n], w2[(size_t)n * Hd + j], dh); a2[n] = fmaf(dl[n], hj, a2[n]); ab2[n] += dl[n]; }
+#pragma unroll
+    for (int n = 0; n < HEAD_MAX_N; ++n)
+      if (n < N) { dh = fmaf(dl[n], w2[(size_t)n * Hd + j], dh); a2[n] = fmaf(dl[n], hj, a2[n]); ab2[n] += dl[n]; }
     dh = hj > 0.f ? dh : 0.f;
     ab1 += dh;
-    for (int i = 0; i < N; ++i) { a1[i] = fmaf(dh, e[(size_t)b * N + i], a1[i]); a1[N + i] = fmaf(dh, sp[(size_t)b * N + i], a1[N + i]); }
+#pragma unroll
+    for (int i = 0; i < HEAD_MAX_N; ++i)
+      if (i < N) { a1e[i] = fmaf(dh, e[(size_t)b * N + i], a1e[i]); a1s[i] = fmaf(dh, sp[(size_t)b * N + i], a1s[i]); }
   }
-  for (int i = 0; i < 2 * N; ++i) { const float v = wave_sum(a1[i]); if (lane == 0 && dw1) dw1[(size_t)j * 2 * N + i] = v; }
+#pragma unroll
+  for (int i = 0; i < HEAD_MAX_N; ++i)
+    if (i < N) {
+      const float ve = wave_sum(a1e[i]), vs = wave_sum(a1s[i]);
+      if (lane == 0 && dw1) { dw1[(size_t)j * 2 * N + i] = ve; dw1[(size_t)j * 2 * N + N + i] = vs; }
+    }
   { const float v = wave_sum(ab1); if (lane == 0 && db1) db1[j] = v; }
-  for (int n = 0; n < N; ++n) {
-    const float v = wave_sum(a2[n]), vb = wave_sum(ab2[n]);
-    if (lane == 0 && dw2) dw2[(size_t)n * Hd + j] = v;
-    if (lane == 0 && db2 && j == 0) db2[n] = vb;
-  }
+#pragma unroll
+  for (int n = 0; n < HEAD_MAX_N; ++n)
+    if (n < N) {
+      const float v = wave_sum(a2[n]), vb = wave_sum(ab2[n]);
+      if (lane == 0 && dw2) dw2[(size_t)n * Hd + j] = v;
+      if (lane == 0 && db2 && j == 0) db2[n] = vb;
+    }
 }
 
 extern "C" int bx_fusion_head_fwd(const float* eeg_logp, const float* spec_logp, const float* w1, const float* b1,

@@ -145,8 +145,8 @@ class DataParallel(nn.Module):
         return self.module(*args, **kw)
 
     def sync_gradients(self, optimizer=None):
-        if self.world_size == 1:
-            return
+        if not dist.is_initialized():
+            return          # plain single-process use; with an initialised group the collective runs even for world_size 1
         if isinstance(optimizer, FlatAdamW):
             optimizer.gather_grads()
             flat = optimizer.flat_g
@@ -254,13 +254,6 @@ def train_and_validate_combined(model, train_loader, valid_loader, epochs, optim
                          "train_losses": tr_l, "valid_losses": va_l, "train_accuracies": tr_a, "valid_accuracies": va_a},
                         checkpoint_dir, name)
     return tr_l, va_l, tr_a, va_a
-
-
-class _L2Criterion:
-    """criterion(out, y) + weight_decay * sum(p^2): value via bx_sumsq, gradient 2*wd*p added to the arena."""
-
-    def __init__(self, criterion, optimizer, weight_decay):
-        self.criterion, self.opt, self.wd = criterion, optimizer, float(weight_decay)
 
 
 def train_and_validate_eeg_distributed(model, train_loader, valid_loader, epochs, optimizer, criterion, scheduler, device,

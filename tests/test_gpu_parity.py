@@ -333,3 +333,35 @@ def test_zz_error_report():
     print("\n[parity] worst recorded deviations (label, max rel err, outlier fraction):")
     for label, err, frac in worst:
         print(f"[parity]   {label:70s} {err:.3e} {frac:.3%}")
+
+
+def test_rccl_single_rank_group_matches_plain_training():
+    """the data-parallel code path on the GPU (RCCL all-reduce(AVG) of the flat gradient arena) with a 1-rank group:
+    must reproduce plain training bit for bit"""
+    import torch.distributed as dist
+    import os, socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    eeg, spec = O.seeded((4, 1, 19, 2000), 42, "randn").to(DEV), O.seeded((4, 4, 32, 64), 43, "rand").to(DEV)
+    lab = torch.softmax(O.seeded((4, 6), 44, "randn"), 1).to(DEV)
+    finals = []
+    for use_ddp in (False, True):
+        torch.manual_seed(3)
+        net = brainxai.build_multimodal(19, 2000, 4, dropout=0.0).to(DEV).train()
+        ddp = None
+        if use_ddp:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+            ddp = brainxai.DataParallel(net)
+        try:
+            opt = brainxai.FlatAdamW(net.parameters(), lr=1e-3)
+            for _ in range(2):
+                brainxai.train_step(net, opt, eeg, spec, lab, brainxai.KLDivLoss(), ddp=ddp)
+            torch.cuda.synchronize()
+            finals.append(opt.flat_p.clone())
+            if use_ddp:
+                assert all(k.startswith("module.") for k in ddp.state_dict())
+        finally:
+            ops.clear_grad_views()
+            if use_ddp:
+                dist.destroy_process_group()
+    assert torch.equal(finals[0], finals[1])
