@@ -63,12 +63,63 @@ def resize_bilinear(maps: torch.Tensor, size) -> torch.Tensor:
     """F.interpolate(maps[:,None], size, mode='bilinear', align_corners=False)[:,0] on fp32 [N,h,w]."""
     n, h, w = maps.shape
     H, W = size
+    maps = maps.contiguous()
     out = torch.empty(n, H, W, dtype=torch.float32, device=maps.device)
-    L.check(L.load().bx_resize_bilinear(_p(maps.contiguous()), _p(out), n, h, w, H, W, _stream()), "bx_resize_bilinear")
+    L.check(L.load().bx_resize_bilinear(_p(maps), _p(out), n, h, w, H, W, _stream()), "bx_resize_bilinear")
     return out
 
 
 _TARGET = re.compile(r"^(?:spectrogram_model\.)?block([1-5])(?:\.conv([1-3]))?$")
+
+
+def _grad_cam_last_stage(model, eeg, spec, class_idx, upsample, relu, return_parts):
+    """Default target (the last stage feeds the heads directly): no autograd at all.  One forward, then the
+    backward of the two tiny heads for ALL requested classes at once (the class axis is folded into the batch of
+    bx_fusion_head_bwd / bx_gap_fc_lsm_bwd), then the fused channel reduce -- a handful of launches per batch."""
+    lib = L.load()
+    sm = model.spectrogram_model
+    with torch.no_grad():
+        e = model.eeg_model(eeg).contiguous()
+        A = sm.features(spec).permute(0, 2, 3, 1).contiguous()
+        B, h, w, C = A.shape
+        N, Hd = model.fc2.out_features, model.fc1.out_features
+        dev = A.device
+        gap = torch.empty(B, C, dtype=torch.float32, device=dev)
+        s_lp = torch.empty(B, N, dtype=torch.float32, device=dev)
+        L.check(lib.bx_gap_fc_lsm_fwd(_p(A), _p(sm.fc.weight), _p(sm.fc.bias), _p(gap), _p(s_lp), B, h * w, C, N, ops.bx_dtype(A.dtype), _stream()),
+                "bx_gap_fc_lsm_fwd")
+        hidden = torch.empty(B, Hd, dtype=torch.float32, device=dev)
+        out = torch.empty(B, N, dtype=torch.float32, device=dev)
+        L.check(lib.bx_fusion_head_fwd(_p(e), _p(s_lp), _p(model.fc1.weight), _p(model.fc1.bias), _p(model.fc2.weight), _p(model.fc2.bias),
+                                       _p(hidden), _p(out), B, N, Hd, _stream()), "bx_fusion_head_fwd")
+        if class_idx is None:
+            nm, cls = 1, out.argmax(1)
+        elif isinstance(class_idx, str):
+            if class_idx != "all":
+                raise ValueError(class_idx)
+            nm, cls = N, torch.arange(N, device=dev).repeat(B)
+        else:
+            nm, cls = 1, torch.full((B,), int(class_idx), dtype=torch.int64, device=dev)
+        rep = (lambda t: t.repeat_interleave(nm, 0).contiguous()) if nm > 1 else (lambda t: t)
+        seeds = _one_hot_rows(cls, N)                                       # [B*nm, N], map index = sample*nm + class
+        d_s = torch.empty(B * nm, N, dtype=torch.float32, device=dev)
+        # keep the repeated operands alive until the launches are queued (a temporary freed right after data_ptr()
+        # would hand its memory to the next allocation)
+        r_out, r_hid, r_e, r_s = rep(out), rep(hidden), rep(e), rep(s_lp)
+        L.check(lib.bx_fusion_head_bwd(_p(seeds), _p(r_out), _p(r_hid), _p(r_e), _p(r_s), _p(model.fc1.weight),
+                                       _p(model.fc2.weight), None, _p(d_s), None, None, None, None, B * nm, N, Hd, _stream()), "bx_fusion_head_bwd")
+        G = torch.empty(B * nm, h, w, C, dtype=A.dtype, device=dev)
+        L.check(lib.bx_gap_fc_lsm_bwd(_p(d_s), _p(r_s), _p(gap), _p(sm.fc.weight), _p(G), None, None, B * nm, h * w, C, N,
+                                      ops.bx_dtype(A.dtype), _stream()), "bx_gap_fc_lsm_bwd")
+        cam, wts = _reduce(A, G, nm, relu=relu)
+        raw = _reduce(A, G, nm, relu=False)[0] if (return_parts and relu) else cam
+        if upsample:
+            cam = resize_bilinear(cam, spec.shape[-2:])
+    stacked = isinstance(class_idx, str)
+    shape = (lambda t: t.reshape(B, nm, *t.shape[1:])) if stacked else (lambda t: t)
+    if return_parts:
+        return shape(cam), shape(raw), shape(wts), A, out
+    return shape(cam)
 
 
 def grad_cam(model, eeg, spec, target_layer="spectrogram_model.block5", class_idx=None, upsample=True, relu=True,
@@ -89,6 +140,13 @@ def grad_cam(model, eeg, spec, target_layer="spectrogram_model.block5", class_id
     spec_model = model.spectrogram_model if hasattr(model, "spectrogram_model") else model
     blk = getattr(spec_model, f"block{m.group(1)}")
     conv_k = int(m.group(2)) if m.group(2) else 0
+    if conv_k == 0 and m.group(1) == "5" and hasattr(model, "eeg_model") and hasattr(model, "fc1"):
+        was_training = model.training
+        model.eval()
+        try:
+            return _grad_cam_last_stage(model, eeg, spec, class_idx, upsample, relu, return_parts)
+        finally:
+            model.train(was_training)
     with _eval_frozen(model):
         spec_in = spec.detach().clone().requires_grad_(True)
         grabbed = {}

@@ -352,7 +352,8 @@ class GapFcLsmFn(torch.autograd.Function):
         dfeat = torch.empty(B, H, W, Cc, dtype=ctx.dt, device=gap.device) if ctx.needs_input_grad[0] else None
         need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dw, db = (new_grad(w), new_grad(b)) if need_w else (None, None)
-        L.check(L.load().bx_gap_fc_lsm_bwd(_p(dlogp.contiguous()), _p(logp), _p(gap), _p(w), _p(dfeat), _p(dw), _p(db), B, H * W, Cc, N,
+        dlogp = dlogp.contiguous()          # keep any temporary alive across the launch
+        L.check(L.load().bx_gap_fc_lsm_bwd(_p(dlogp), _p(logp), _p(gap), _p(w), _p(dfeat), _p(dw), _p(db), B, H * W, Cc, N,
                                            bx_dtype(ctx.dt), _stream()), "bx_gap_fc_lsm_bwd")
         return dfeat, dw, db
 
@@ -377,7 +378,8 @@ class LinearLsmFn(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dw, db = (new_grad(w), new_grad(b)) if need_w else (None, None)
-        L.check(L.load().bx_linear_lsm_bwd(_p(dlogp.contiguous()), _p(logp), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, K, N, _stream()),
+        dlogp = dlogp.contiguous()
+        L.check(L.load().bx_linear_lsm_bwd(_p(dlogp), _p(logp), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, K, N, _stream()),
                 "bx_linear_lsm_bwd")
         return dx, dw, db
 
@@ -406,7 +408,8 @@ class FusionHeadFn(torch.autograd.Function):
         ds = torch.empty_like(s) if ctx.needs_input_grad[1] else None
         need_w = any(ctx.needs_input_grad[2:])
         dw1, db1, dw2, db2 = (new_grad(w1), new_grad(b1), new_grad(w2), new_grad(b2)) if need_w else (None,) * 4
-        L.check(L.load().bx_fusion_head_bwd(_p(dlogp.contiguous()), _p(logp), _p(hidden), _p(e), _p(s), _p(w1), _p(w2), _p(de), _p(ds),
+        dlogp = dlogp.contiguous()
+        L.check(L.load().bx_fusion_head_bwd(_p(dlogp), _p(logp), _p(hidden), _p(e), _p(s), _p(w1), _p(w2), _p(de), _p(ds),
                                             _p(dw1), _p(db1), _p(dw2), _p(db2), B, N, Hd, _stream()), "bx_fusion_head_bwd")
         return de, ds, dw1, db1, dw2, db2
 
@@ -422,7 +425,8 @@ class KLDivFn(torch.autograd.Function):
         B, N = logp.shape
         loss = torch.empty((), dtype=torch.float32, device=logp.device)
         dlogp = torch.empty_like(logp)
-        L.check(L.load().bx_kldiv_fwd_bwd(_p(logp.contiguous()), _p(target.contiguous().float()), _p(loss), _p(dlogp), B, N,
+        logp_c, target_c = logp.contiguous(), target.contiguous().float()
+        L.check(L.load().bx_kldiv_fwd_bwd(_p(logp_c), _p(target_c), _p(loss), _p(dlogp), B, N,
                                           _REDUCTIONS[reduction], float(grad_scale), _stream()), "bx_kldiv_fwd_bwd")
         ctx.save_for_backward(dlogp)
         return loss
@@ -431,7 +435,8 @@ class KLDivFn(torch.autograd.Function):
     def backward(ctx, g):
         (dlogp,) = ctx.saved_tensors
         out = torch.empty_like(dlogp)
-        L.check(L.load().bx_scale_dev(_p(dlogp), _p(g.contiguous()), _p(out), dlogp.numel(), _stream()), "bx_scale_dev")
+        g = g.contiguous()
+        L.check(L.load().bx_scale_dev(_p(dlogp), _p(g), _p(out), dlogp.numel(), _stream()), "bx_scale_dev")
         return out, None, None, None
 
 
@@ -471,7 +476,8 @@ class EegFeaturesFn(torch.autograd.Function):
         gl = [new_grad(t) for t in (c1w, bn1w, bn1b, dww, bn2w, bn2b, sepw, bn3w, bn3b)] if need_w else [None] * 9
         grads = L.EegGrads(*[_p(t) for t in gl])
         ws = workspace(lib.bx_eeg_workspace(C.byref(ctx.desc)), x.device)
-        L.check(lib.bx_eeg_features_bwd(C.byref(ctx.desc), C.byref(ctx.params), _p(x), _p(dfeat.contiguous()), _p(ctx.seed), _p(saved),
+        dfeat = dfeat.contiguous()
+        L.check(lib.bx_eeg_features_bwd(C.byref(ctx.desc), C.byref(ctx.params), _p(x), _p(dfeat), _p(ctx.seed), _p(saved),
                                         C.byref(grads), _p(dx), _p(ws), ws.numel(), _stream()), "bx_eeg_features_bwd")
         return (dx, *gl, None, None)
 
