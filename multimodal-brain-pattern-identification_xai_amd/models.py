@@ -177,8 +177,20 @@ class MultimodalModel(nn.Module):
         self.log_softmax = nn.LogSoftmax(dim=1)
 
     def forward(self, eeg_data, spectrogram_data):
-        e = self.eeg_model(eeg_data)
-        s = self.spectrogram_model(spectrogram_data)
+        if ops.OVERLAP and eeg_data.is_cuda and ops.CONV_PROFILE is None:
+            # the EEG branch (small, latency-bound kernels) runs on a side stream beside the spectrogram branch; autograd
+            # replays each branch's backward on the stream its forward ran on, so the backward overlaps too
+            cur = torch.cuda.current_stream()
+            side = ops.side_stream("eeg", eeg_data.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                e = self.eeg_model(eeg_data)
+            s = self.spectrogram_model(spectrogram_data)
+            cur.wait_stream(side)
+            e.record_stream(cur)
+        else:
+            e = self.eeg_model(eeg_data)
+            s = self.spectrogram_model(spectrogram_data)
         if e.shape[1] != s.shape[1]:
             raise RuntimeError("MultimodalModel: both branches must emit the same number of classes")
         return ops.FusionHeadFn.apply(e, s, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)

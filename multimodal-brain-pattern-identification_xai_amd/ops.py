@@ -17,6 +17,47 @@ from . import _lib as L
 CONV_ALGO = L.BX_ALGO_AUTO        # module-level switch used by tests to force the direct / MFMA kernels
 WGRAD_ALGO = L.BX_ALGO_AUTO
 CONV_PROFILE = None               # bench.py sets a list: every conv launch appends (kind, start_event, end_event)
+# Multi-stream overlap (most kernels of this model are latency-bound and leave CUs idle): weight-gradient kernels run
+# on a side stream beside the data-gradient chain, the EEG branch beside the spectrogram branch.  join_side_streams()
+# must run before anything consumes the gradients (FlatAdamW.step / DataParallel.sync_gradients do it).
+# Measured on MI355X (round 1): +2 % under hipGraph replay, -10 % when launching eagerly (host-side stream switches),
+# so it is OFF by default; BX_OVERLAP=1 turns it on.
+import os as _os
+OVERLAP = _os.environ.get("BX_OVERLAP", "0") == "1"
+_SIDE = {}
+
+
+def side_stream(name: str, device) -> "torch.cuda.Stream":
+    key = (name, device.index if device.index is not None else torch.cuda.current_device())
+    st = _SIDE.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE[key] = st
+    return st
+
+
+def join_side_streams(device=None):
+    cur = torch.cuda.current_stream()
+    for (name, idx), st in _SIDE.items():
+        if device is None or idx == (device.index if device.index is not None else torch.cuda.current_device()):
+            cur.wait_stream(st)
+
+
+_JOIN_QUEUED = [False]
+
+
+def _join_after_backward():
+    """Queue ONE engine callback per backward pass: when autograd finishes, the caller's stream waits for the side
+    streams, so `p.grad` is safe to read right after `loss.backward()` returns (eager users, torch optimizers)."""
+    if _JOIN_QUEUED[0]:
+        return
+
+    def _cb():
+        _JOIN_QUEUED[0] = False
+        join_side_streams()
+
+    _JOIN_QUEUED[0] = True
+    torch.autograd.Variable._execution_engine.queue_callback(_cb)
 
 
 class _Timed:
@@ -62,8 +103,8 @@ _WS = {}
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffer per device (all uses are ordered on the current stream)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """Grow-only scratch buffer per (device, stream): all uses of one buffer are ordered on its stream."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -74,24 +115,27 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 _SEED = {}
 
 
-def seed_state(device) -> torch.Tensor:
-    key = device.index if device.index is not None else torch.cuda.current_device()
+def seed_state(device, lane: str = "spec") -> torch.Tensor:
+    """Dropout counter of a (device, lane); the EEG branch has its own lane because it runs on its own stream."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), lane)
     st = _SEED.get(key)
     if st is None:
-        st = torch.full((1,), torch.initial_seed() & 0x7FFFFFFFFFFF, dtype=torch.int64, device=device)
+        base = (torch.initial_seed() & 0x7FFFFFFFFFFF) + (0 if lane == "spec" else 0x5EED0000)
+        st = torch.full((1,), base, dtype=torch.int64, device=device)
         _SEED[key] = st
     return st
 
 
 def manual_seed(seed: int, device=None):
-    """Reset the dropout counter stream of ``device`` (default: current device)."""
+    """Reset the dropout counter streams of ``device`` (default: current device)."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    seed_state(device).fill_(int(seed))
+    seed_state(device, "spec").fill_(int(seed))
+    seed_state(device, "eeg").fill_(int(seed) + 0x5EED0000)
 
 
-def next_seed(device) -> torch.Tensor:
+def next_seed(device, lane: str = "spec") -> torch.Tensor:
     out = torch.empty(1, dtype=torch.int64, device=device)
-    L.check(L.load().bx_seed_next(_p(seed_state(device)), _p(out), _stream()), "bx_seed_next")
+    L.check(L.load().bx_seed_next(_p(seed_state(device, lane)), _p(out), _stream()), "bx_seed_next")
     return out
 
 
@@ -314,8 +358,18 @@ class BlockFn(torch.autograd.Function):
         bss = (b1, b2, b3)
         grads_w, grads_b = [None] * 3, [None] * 3
         dz = dz3
+        use_side = OVERLAP and need_w and CONV_PROFILE is None
+        side = side_stream("wgrad", x.device) if use_side else None
+        if use_side:
+            _join_after_backward()
         for k in (2, 1, 0):
-            if need_w:
+            if need_w and side is not None:
+                # dW/db of this layer only feed the optimizer: compute them beside the data-gradient chain
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    grads_w[k], grads_b[k] = _wgrad(acts[k], dz, wts[k], bss[k])
+                dz.record_stream(side); acts[k].record_stream(side)
+            elif need_w:
                 grads_w[k], grads_b[k] = _wgrad(acts[k], dz, wts[k], bss[k])
             packed = cfg.prepacked.get(cfg.pack_base + k, True) if cfg.prepacked is not None else None
             if k > 0:
@@ -460,7 +514,7 @@ class EegFeaturesFn(torch.autograd.Function):
                              _p(bufs[4]), _p(bufs[5]), _p(sepw), _p(bn3w), _p(bn3b), _p(bufs[6]), _p(bufs[7]), _p(bufs[8]))
         T2 = (T // cfg.P1) // cfg.P2
         feat = torch.empty(B, cfg.F2 * T2, dtype=torch.float32, device=x.device)
-        seed = next_seed(x.device) if (cfg.training and cfg.dropout_p > 0) else None
+        seed = next_seed(x.device, "eeg") if (cfg.training and cfg.dropout_p > 0) else None
         L.check(lib.bx_eeg_features_fwd(C.byref(desc), C.byref(params), _p(x), _p(seed), _p(feat), _p(saved), _p(ws), ws.numel(), _stream()),
                 "bx_eeg_features_fwd")
         ctx.desc, ctx.params, ctx.seed, ctx.bufs = desc, params, seed, bufs

@@ -65,6 +65,8 @@ class FlatAdamW:
 
     def gather_grads(self):
         """Make the gradient arena hold every parameter's gradient (no-op for slices the kernels wrote)."""
+        if self.is_cuda:
+            ops.join_side_streams(self.flat_g.device)      # weight-gradient kernels may still run on the side stream
         base = self.flat_g.data_ptr()
         for p, off in zip(self.params, self.offsets):
             slot = self.flat_g.narrow(0, off, p.numel())
@@ -151,6 +153,8 @@ class DataParallel(nn.Module):
             optimizer.gather_grads()
             flat = optimizer.flat_g
         else:
+            if torch.cuda.is_available():
+                ops.join_side_streams()
             grads = [p.grad for p in self.module.parameters() if p.grad is not None]
             flat = torch.cat([g.reshape(-1) for g in grads])
         if flat.is_cuda:
