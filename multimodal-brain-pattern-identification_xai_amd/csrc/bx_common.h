@@ -109,10 +109,23 @@ __device__ __forceinline__ void sum_partials_256(const float* __restrict__ parti
   double acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = 0.0;
-  if (slice < nslice)
-    for (int k = slice; k < nblk; k += nslice)
+  if (slice < nslice) {
+    int k = slice;
+    for (; k + 3 * nslice < nblk; k += 4 * nslice) {        // 4*NV independent loads in flight; adds stay in k order
+      float t[4][NV];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) t[u][v] = partials[((size_t)(k + u * nslice) * NV + v) * C + c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] += (double)t[u][v];
+    }
+    for (; k < nblk; k += nslice)
 #pragma unroll
       for (int v = 0; v < NV; ++v) acc[v] += (double)partials[((size_t)k * NV + v) * C + c];
+  }
 #pragma unroll
   for (int v = 0; v < NV; ++v) sp[v][threadIdx.x] = acc[v];
   __syncthreads();

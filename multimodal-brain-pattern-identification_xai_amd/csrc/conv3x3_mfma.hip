@@ -212,11 +212,135 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   }
 }
 
+// Persistent variant for single-chunk layers (Ci == CK <= 32: the HBM-bound early stages).  A workgroup walks tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ...; the NEXT tile's halo is fetched into registers before the current tile's
+// MFMAs and epilogue, so every CU always has input loads in flight (the one-shot kernel exposes one HBM round trip per
+// workgroup and relies on occupancy alone to hide it).
+template <int CK, int NC, int TW>
+__global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+    const bf16_t* __restrict__ mask_src, const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
+    int H, int W, int Co, int relu, int tiles_x, int tiles_y, int ntiles) {
+  constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CKB = CK * 2, NCH = CK / 8, KS = (9 * CK + 31) / 32;
+  constexpr int MP = TH * TW / 64, TPR = TW / 16;
+  constexpr int NU = HH * HWID * NCH, NR = (NU + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int co_base = blockIdx.y * (NC * 16);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+  uint4 rv[NR];
+  auto fetch = [&](int tile) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int u = threadIdx.x + k * 256;
+      const int p = u / NCH, c = u % NCH;
+      const int iy = ty * TH + p / HWID - 1, ix = tx * TW + p % HWID - 1;
+      rv[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (u < NU && iy >= 0 && iy < H && ix >= 0 && ix < W)
+        rv[k] = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * CK + c * 8);
+    }
+  };
+  float4 bz[NC];
+#pragma unroll
+  for (int n = 0; n < NC; ++n)
+    bz[n] = bias ? *reinterpret_cast<const float4*>(bias + co_base + n * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    __syncthreads();                          // previous tile's fragment reads are done
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int u = threadIdx.x + k * 256;
+      if (u < NU) {
+        const int p = u / NCH, c = u % NCH;
+        *reinterpret_cast<uint4*>(lds + p * CKB + 16 * lds_chunk<CK>(c, p)) = rv[k];
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+    f32x4 acc[MP][NC];
+#pragma unroll
+    for (int i = 0; i < MP; ++i)
+#pragma unroll
+      for (int n = 0; n < NC; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 a[3][NC];
+    auto load_a = [&](int s, bf16x8 (&dst)[NC]) {
+#pragma unroll
+      for (int n = 0; n < NC; ++n)
+        dst[n] = *reinterpret_cast<const bf16x8*>(wp + ((size_t)s * Co + co_base + n * 16 + li) * 32 + 8 * g);
+    };
+    load_a(0, a[0]);
+    if (KS > 1) load_a(1, a[1]);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + 2 < KS) load_a(s + 2, a[(s + 2) % 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int q0 = s * 32 + 8 * g;
+      int tap = q0 / CK;
+      const int c = (q0 % CK) / 8;
+      const bool valid = tap < 9;
+      if (!valid) tap = 0;
+      const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+      for (int i = 0; i < MP; ++i) {
+        const int t = wave * MP + i;
+        const int p = (t / TPR + dy) * HWID + (t % TPR) * 16 + li + dx;
+        bf16x8 bv = *reinterpret_cast<const bf16x8*>(lds + p * CKB + 16 * lds_chunk<CK>(c, p));
+        if (!valid) bv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int n = 0; n < NC; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s % 3][n], bv, acc[i][n], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MP; ++i) {
+      const int t = wave * MP + i;
+      const int oy = y0 + t / TPR, ox = x0 + (t % TPR) * 16 + li;
+      if (oy >= H || ox >= W) continue;
+#pragma unroll
+      for (int n = 0; n < NC; ++n) {
+        const int co = co_base + n * 16 + 4 * g;
+        const size_t o = (((size_t)b * H + oy) * W + ox) * Co + co;
+        float v[4] = {acc[i][n][0] + bz[n].x, acc[i][n][1] + bz[n].y, acc[i][n][2] + bz[n].z, acc[i][n][3] + bz[n].w};
+        if (relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (mask_src) {
+          const uint2 mk = *reinterpret_cast<const uint2*>(mask_src + o);
+          const uint32_t mm[4] = {mk.x & 0xffffu, mk.x >> 16, mk.y & 0xffffu, mk.y >> 16};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (mm[r] != 0u && mm[r] < 0x8000u) ? v[r] : 0.f;
+        }
+        if (addend) {
+          const uint2 a2 = *reinterpret_cast<const uint2*>(addend + o);
+          v[0] += __uint_as_float(a2.x << 16); v[1] += __uint_as_float(a2.x & 0xffff0000u);
+          v[2] += __uint_as_float(a2.y << 16); v[3] += __uint_as_float(a2.y & 0xffff0000u);
+        }
+        uint2 out;
+        out.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        out.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(y + o) = out;
+      }
+    }
+  }
+}
+
 template <int CK, int NC, int TW>
 static int launch_conv(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
                        int B, int H, int W, int Ci, int Co, int relu, hipStream_t s) {
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + 7) / 8;
   const size_t lds = (size_t)10 * (TW + 2) * CK * 2;
+  if (CK <= 32 && Ci == CK) {
+    const int ntiles = tiles_x * tiles_y * B, ygroups = Co / (16 * NC);
+    int gx = 2048 / ygroups;                       // ~8 workgroups per CU in total, each walking ntiles/gx tiles
+    if (gx > ntiles) gx = ntiles;
+    if (ntiles >= 4 * gx) {
+      hipLaunchKernelGGL((k_conv_mfma_p<CK, NC, TW>), dim3((unsigned)gx, (unsigned)ygroups), dim3(256), lds, s, (const bf16_t*)x,
+                         (const bf16_t*)wp, bias, (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Co, relu, tiles_x, tiles_y, ntiles);
+      BX_CHECK_LAUNCH("bx_conv3x3(mfma persistent)");
+      return BX_OK;
+    }
+  }
   dim3 grid((unsigned)(tiles_x * tiles_y * B), (unsigned)(Co / (16 * NC)));
   hipLaunchKernelGGL((k_conv_mfma<CK, NC, TW>), grid, dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)wp, bias,
                      (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y);

@@ -476,8 +476,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_eeg_conv1_bwd(const T* __restrict__ c1, const float* __restrict__ dd, const float* __restrict__ x,
     const float* __restrict__ dw, const float* __restrict__ w1, const float* __restrict__ mean1, const float* __restrict__ inv1,
     const float* __restrict__ coef, float* __restrict__ w1part, float* __restrict__ dx, EegGeom g) {
-  extern __shared__ float sm[];
-  const int Tn = g.T, TX = Tn + 2 * EEG_MAXK;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Tn = g.T, TX = (Tn + 2 * EEG_MAXK + 3) & ~3;       // rows stay 16-byte aligned for the float4 reads
   float* sdc = sm;                 // [4][TX]  dc1 of the current filter group, zero halo, index t + 64
   float* sxr = sm + 4 * TX;        // [TX]     x row with zero halo, index t + 64
   float* comb = sxr + TX;          // [256][4]
@@ -508,37 +508,56 @@ __global__ __launch_bounds__(256) void k_eeg_conv1_bwd(const T* __restrict__ c1,
     }
     __syncthreads();
     if (w1part) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      const bool active = k0 < g.K1;
-      if (active) {
-        const int tb = (int)((long long)Tn * part / 4), te = (int)((long long)Tn * (part + 1) / 4);
-        const float* dc = sdc + ff * TX + EEG_MAXK;
-        const float* xr = sxr + EEG_MAXK + k0 - g.padl1;
-        float x0 = xr[tb], x1 = xr[tb + 1], x2 = xr[tb + 2];
+      // thread = (filter pair fp, tap octet k8, time part tp): 2 filters x 8 taps = 16 accumulators; per 4 time steps it
+      // reads 2 dc1 float4 + 1 x float4 from LDS and issues 64 FMAs (the previous version was LDS-throughput bound).
+      const int tp = threadIdx.x >> 4, fp = (threadIdx.x >> 3) & 1, k8 = threadIdx.x & 7, kb = k8 * 8;
+      float acc[2][8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.f;
+      if (kb < g.K1) {
+        const int T4 = Tn & ~3;
+        int tb = (int)((long long)(T4 / 4) * tp / 16) * 4, te = (int)((long long)(T4 / 4) * (tp + 1) / 16) * 4;
+        if (tp == 15) te = Tn;
+        const float* dc0 = sdc + (2 * fp) * TX + EEG_MAXK;
+        const float* dc1 = dc0 + TX;
+        const float* xr = sxr + EEG_MAXK + kb - g.padl1;         // xr[t + j] = x[t + kb + j - padl]
+        float win[12];                                          // x window xr[t .. t+10]
         int t = tb;
-        for (; t + 8 <= te; t += 8) {           // 16 LDS reads issued together, then 32 FMAs (a serial 1-read-per-step loop is LDS-latency bound)
-          float dv[8], xn[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { dv[j] = dc[t + j]; xn[j] = xr[t + 3 + j]; }
+        for (int j = 0; j < 8; ++j) win[j] = xr[t + j];
+        for (; t + 4 <= te; t += 4) {
+          const float4 d0 = *reinterpret_cast<const float4*>(dc0 + t);
+          const float4 d1 = *reinterpret_cast<const float4*>(dc1 + t);
+          win[8] = xr[t + 8]; win[9] = xr[t + 9]; win[10] = xr[t + 10]; win[11] = xr[t + 11];
+          const float dv0[4] = {d0.x, d0.y, d0.z, d0.w}, dv1[4] = {d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            a0 = fmaf(dv[j], x0, a0); a1 = fmaf(dv[j], x1, a1); a2 = fmaf(dv[j], x2, a2); a3 = fmaf(dv[j], xn[j], a3);
-            x0 = x1; x1 = x2; x2 = xn[j];
-          }
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { acc[0][j] = fmaf(dv0[i], win[i + j], acc[0][j]); acc[1][j] = fmaf(dv1[i], win[i + j], acc[1][j]); }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) win[j] = win[j + 4];
         }
         for (; t < te; ++t) {
-          const float x3 = xr[t + 3], dv = dc[t];
-          a0 = fmaf(dv, x0, a0); a1 = fmaf(dv, x1, a1); a2 = fmaf(dv, x2, a2); a3 = fmaf(dv, x3, a3);
-          x0 = x1; x1 = x2; x2 = x3;
+          const float v0 = dc0[t], v1 = dc1[t];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float xv = xr[t + j]; acc[0][j] = fmaf(v0, xv, acc[0][j]); acc[1][j] = fmaf(v1, xv, acc[1][j]); }
         }
       }
-      comb[threadIdx.x * 4 + 0] = a0; comb[threadIdx.x * 4 + 1] = a1; comb[threadIdx.x * 4 + 2] = a2; comb[threadIdx.x * 4 + 3] = a3;
+      // combine the 16 time parts: comb[(tp*16 + fp*8 + k8)][16 values] -> thread o = (filter, tap) sums 16 entries
       __syncthreads();
-      if (part == 0 && active) {
-        for (int j = 0; j < 4; ++j)
-          if (k0 + j < g.K1)
-            w1part[(size_t)row * 8 * g.K1 + (fg * 4 + ff) * g.K1 + k0 + j] =
-                comb[tid * 4 + j] + comb[(64 + tid) * 4 + j] + comb[(128 + tid) * 4 + j] + comb[(192 + tid) * 4 + j];
+      float* cb = comb;                                        // needs 256*16 floats (sized by the launcher)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { cb[threadIdx.x * 16 + j] = acc[0][j]; cb[threadIdx.x * 16 + 8 + j] = acc[1][j]; }
+      __syncthreads();
+      {
+        const int o = threadIdx.x;                             // 4 filters x 64 taps = 256 outputs
+        const int f4 = o >> 6, kk = o & 63;
+        if (kk < g.K1) {
+          const int fpo = f4 >> 1, fi = f4 & 1, k8o = kk >> 3, j = kk & 7;
+          float s = 0.f;
+          for (int p = 0; p < 16; ++p) s += cb[(p * 16 + fpo * 8 + k8o) * 16 + fi * 8 + j];
+          w1part[(size_t)row * 8 * g.K1 + (fg * 4 + f4) * g.K1 + kk] = s;
+        }
       }
     }
     if (dx) {
@@ -639,7 +658,7 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
                      gr->dw_w, gr->bn1_w, gr->bn1_b, coef1);
   BX_CHECK_LAUNCH("eeg dw bwd finalize");
   if (gr->conv1_w || dx) {
-    const size_t lds = ((size_t)5 * (g.T + 2 * EEG_MAXK) + 1024) * sizeof(float);
+    const size_t lds = ((size_t)5 * ((g.T + 2 * EEG_MAXK + 3) & ~3) + 4096) * sizeof(float);
     BX_REQUIRE(lds <= 160 * 1024 && g.T <= 256 * EEG_DX_MAX, "bx_eeg_features_bwd: T too long (LDS tile %zu bytes, T <= %d)", lds, 256 * EEG_DX_MAX);
     BX_DISPATCH_DTYPE(d->dtype, T,
       if (hipFuncSetAttribute((const void*)k_eeg_conv1_bwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
