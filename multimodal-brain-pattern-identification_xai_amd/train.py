@@ -29,11 +29,15 @@ class FlatAdamW:
     wrapper all-reduces the gradient arena in place.
     """
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, allow_host=False):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatAdamW: no trainable parameters")
         dev = self.params[0].device
+        if dev.type != "cuda" and not allow_host:
+            # no silent CPU fallback: host tensors are only accepted when a test of the data-parallel plumbing
+            # (gloo, no GPU) asks for it explicitly
+            raise RuntimeError("brainxai.FlatAdamW: parameters must live on the GPU (allow_host=True is for the gloo logic tests only)")
         if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
             raise ValueError("FlatAdamW: parameters must be float32 on one device")
         self.n = sum(p.numel() for p in self.params)

@@ -78,7 +78,9 @@ def test_flat_adamw_host_math_matches_torch():
     torch.manual_seed(0)
     ps = [torch.nn.Parameter(torch.randn(7, 3)), torch.nn.Parameter(torch.randn(5))]
     qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
-    mine, ref = brainxai.FlatAdamW(ps, lr=1e-2), torch.optim.AdamW(qs, lr=1e-2)
+    with pytest.raises(RuntimeError, match="GPU"):
+        brainxai.FlatAdamW([torch.nn.Parameter(torch.zeros(2))])
+    mine, ref = brainxai.FlatAdamW(ps, lr=1e-2, allow_host=True), torch.optim.AdamW(qs, lr=1e-2)
     for _ in range(4):
         for p, q in zip(ps, qs):
             g = torch.randn_like(p)

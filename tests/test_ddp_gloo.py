@@ -32,7 +32,7 @@ def _worker(rank, world, port, outdir, flat):
         net = _net(100 + rank)                       # ranks start from DIFFERENT weights
         ddp = brainxai.DataParallel(net)
         after_bcast = torch.cat([p.detach().flatten() for p in net.parameters()])
-        opt = brainxai.FlatAdamW(net.parameters(), lr=1e-2) if flat else torch.optim.AdamW(net.parameters(), lr=1e-2)
+        opt = brainxai.FlatAdamW(net.parameters(), lr=1e-2, allow_host=True) if flat else torch.optim.AdamW(net.parameters(), lr=1e-2)
         g = torch.Generator().manual_seed(7)
         x = torch.randn(8, 12, generator=g)
         y = torch.softmax(torch.randn(8, 6, generator=g), 1)
