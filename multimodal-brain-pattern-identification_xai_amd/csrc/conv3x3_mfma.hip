@@ -13,6 +13,7 @@
 //   [chunk][kstep][cout][32] and come straight from L2 (1 KiB contiguous per wave load).
 //   Each lane ends up with 4 consecutive output channels of one pixel -> 8-byte NHWC stores after the fused
 //   epilogue (bias, ReLU | ReLU-mask of the producing layer, skip-gradient addend).
+#include <stdlib.h>
 #include "bx_common.h"
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
@@ -325,6 +326,137 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
   }
 }
 
+// K-split variant for Ci >= 64 (the MFMA-bound late stages, where maps are small and a workgroup-per-tile kernel is a
+// serial chain stage -> 18*nchunk K-steps -> epilogue on too few workgroups).  A workgroup owns 4 x 16 pixels x 64 output
+// channels; ALL input chunks of its (4+2) x (16+2) halo sit in LDS at once and wave w takes K-steps w, w+4, w+8, ...
+// (a K-step = 32 of the 9*Ci reduction elements), so each wave's dependency chain is a quarter as long and every weight
+// fragment is loaded by exactly one wave.  The four partial accumulators meet in LDS (one barrier); wave r then finishes
+// pixel row r (bias / ReLU / mask / addend epilogue, 8-byte NHWC stores).
+template <int NCHUNK>
+__global__ __launch_bounds__(256) void k_conv_mfma_ks(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+    const bf16_t* __restrict__ mask_src, const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
+    int H, int W, int Co, int relu, int tiles_x, int tiles_y) {
+  constexpr int CK = 64, TH = 4, TW = 16, HWID = TW + 2, HH = TH + 2, NPIX = HH * HWID, CKB = CK * 2, NCH = CK / 8, KS = 18, NC = 4;
+  constexpr int Ci = CK * NCHUNK, KTOT = KS * NCHUNK;
+  constexpr int NU = NPIX * NCH * NCHUNK, NR = (NU + 255) / 256;
+  constexpr int CHUNK_BYTES = NPIX * CKB;
+  extern __shared__ __attribute__((aligned(16))) char lds[];      // max(NCHUNK * CHUNK_BYTES, 64 KiB reduce buffer)
+  const int bid = blockIdx.x;
+  const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, b = bid / (tiles_x * tiles_y);
+  const int y0 = ty * TH, x0 = tx * TW, co_base = blockIdx.y * (NC * 16);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+
+  {  // stage every chunk of the halo tile: all loads first, then the LDS writes
+    uint4 rv[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int u = threadIdx.x + k * 256;
+      const int c = u % NCH, p = (u / NCH) % NPIX, ch = u / (NCH * NPIX);
+      const int iy = y0 + p / HWID - 1, ix = x0 + p % HWID - 1;
+      rv[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (u < NU && iy >= 0 && iy < H && ix >= 0 && ix < W)
+        rv[k] = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * Ci + ch * CK + c * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int u = threadIdx.x + k * 256;
+      if (u < NU) {
+        const int c = u % NCH, p = (u / NCH) % NPIX, ch = u / (NCH * NPIX);
+        *reinterpret_cast<uint4*>(lds + ch * CHUNK_BYTES + p * CKB + 16 * lds_chunk<CK>(c, p)) = rv[k];
+      }
+    }
+  }
+  f32x4 acc[TH][NC];
+#pragma unroll
+  for (int i = 0; i < TH; ++i)
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 a[3][NC];
+  auto load_a = [&](int ks, bf16x8 (&dst)[NC]) {      // packed layout [chunk][s][Co][32] == [ks][Co][32]
+#pragma unroll
+    for (int n = 0; n < NC; ++n)
+      dst[n] = *reinterpret_cast<const bf16x8*>(wp + ((size_t)ks * Co + co_base + n * 16 + li) * 32 + 8 * g);
+  };
+  constexpr int NIT = (KTOT + 3) / 4;                  // K-steps per wave (the last one may be empty for some waves)
+  load_a(wave, a[0]);
+  if (NIT > 1 && wave + 4 < KTOT) load_a(wave + 4, a[1]);
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int ks = wave + 4 * it;
+    if (it + 2 < NIT && ks + 8 < KTOT) load_a(ks + 8, a[(it + 2) % 3]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks < KTOT) {
+      const int chunk = ks / KS, s = ks % KS;
+      const int tap = s >> 1, c = (s & 1) * 4 + g;
+      const int dy = tap / 3, dx = tap - 3 * dy;
+      const char* base = lds + chunk * CHUNK_BYTES;
+#pragma unroll
+      for (int i = 0; i < TH; ++i) {
+        const int p = (i + dy) * HWID + li + dx;
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(base + p * CKB + 16 * lds_chunk<CK>(c, p));
+#pragma unroll
+        for (int n = 0; n < NC; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it % 3][n], bv, acc[i][n], 0, 0, 0);
+      }
+    }
+  }
+  // cross-wave reduction: red[wave][row i][n][reg r][lane]
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int i = 0; i < TH; ++i)
+#pragma unroll
+    for (int n = 0; n < NC; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(((wave * TH + i) * NC + n) * 4 + r) * 64 + lane] = acc[i][n][r];
+  __syncthreads();
+  const int i = wave;                                   // this wave finishes pixel row i
+  const int oy = y0 + i, ox = x0 + li;
+  if (oy >= H || ox >= W) return;
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    const int co = co_base + n * 16 + 4 * g;
+    const size_t o = (((size_t)b * H + oy) * W + ox) * Co + co;
+    const float4 bz = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float v[4] = {bz.x, bz.y, bz.z, bz.w};
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += red[(((w * TH + i) * NC + n) * 4 + r) * 64 + lane];
+    if (relu) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    if (mask_src) {
+      const uint2 mk = *reinterpret_cast<const uint2*>(mask_src + o);
+      const uint32_t mm[4] = {mk.x & 0xffffu, mk.x >> 16, mk.y & 0xffffu, mk.y >> 16};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (mm[r] != 0u && mm[r] < 0x8000u) ? v[r] : 0.f;
+    }
+    if (addend) {
+      const uint2 a2 = *reinterpret_cast<const uint2*>(addend + o);
+      v[0] += __uint_as_float(a2.x << 16); v[1] += __uint_as_float(a2.x & 0xffff0000u);
+      v[2] += __uint_as_float(a2.y << 16); v[3] += __uint_as_float(a2.y & 0xffff0000u);
+    }
+    uint2 out;
+    out.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    out.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(y + o) = out;
+  }
+}
+template <int NCHUNK>
+static int launch_conv_ks(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
+                          int B, int H, int W, int Co, int relu, hipStream_t s) {
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 3) / 4;
+  size_t lds = (size_t)NCHUNK * 6 * 18 * 128;
+  if (lds < 65536) lds = 65536;
+  dim3 grid((unsigned)(tiles_x * tiles_y * B), (unsigned)(Co / 64));
+  hipLaunchKernelGGL((k_conv_mfma_ks<NCHUNK>), grid, dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)mask,
+                     (const bf16_t*)addend, (bf16_t*)y, H, W, Co, relu, tiles_x, tiles_y);
+  BX_CHECK_LAUNCH("bx_conv3x3(mfma k-split)");
+  return BX_OK;
+}
+
 template <int CK, int NC, int TW>
 static int launch_conv(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
                        int B, int H, int W, int Ci, int Co, int relu, hipStream_t s) {
@@ -367,6 +499,13 @@ static int launch_conv_nc(const void* x, const void* wp, const float* bias, cons
 int bx_conv3x3_mfma_launch(const void* x, const void* packed_mfma, const float* bias, const void* relu_mask_src,
                            const void* addend, void* y, int B, int H, int W, int Ci, int Co, int flags, hipStream_t s) {
   const int relu = (flags & BX_EPI_RELU) ? 1 : 0;
+  // K-split variant: measured equal to the tile-per-workgroup kernel on MI355X (round 1: fwd +8 %, dgrad -3 %), so it is
+  // opt-in (BX_KSPLIT=1) until its main loop gets LDS double buffering
+  if (Co % 64 == 0 && getenv("BX_KSPLIT")) {
+    if (Ci == 64)  return launch_conv_ks<1>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Co, relu, s);
+    if (Ci == 128) return launch_conv_ks<2>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Co, relu, s);
+    if (Ci == 256) return launch_conv_ks<4>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Co, relu, s);
+  }
   switch (mfma_ck(Ci)) {
     case 8:  return launch_conv_nc<8>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s);
     case 16: return launch_conv_nc<16>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s);
