@@ -64,6 +64,11 @@ def conv_work(bx, dtype_bytes):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line: library banners (RCCL prints its version to stdout at init) and any
+    # other chatter are routed to stderr for the whole run; the JSON goes to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -74,8 +79,10 @@ def main():
         sys.exit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = os.environ.get("BX_BENCH_FORCE_DIST") == "1"      # exercise the data-parallel path with a 1-rank RCCL group
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import brainxai
@@ -102,19 +109,35 @@ def main():
 
     torch.manual_seed(42)
     model = brainxai.build_multimodal(CHANS, T, CIN, dropout=0.5, compute_dtype=cdt).to(dev).train()
-    ddp = brainxai.DataParallel(model) if world > 1 else None
+    ddp = brainxai.DataParallel(model) if (world > 1 or force_dist) else None
     opt = brainxai.FlatAdamW(model.parameters(), lr=1e-3)
     crit = brainxai.KLDivLoss()
 
+    def fwd_bwd():
+        opt.zero_grad()
+        out = model(eeg, spec)
+        loss = crit(out, labels)
+        loss.backward()
+        return loss.detach()
+
+    def finish():
+        if ddp is not None:
+            ddp.sync_gradients(opt)           # ONE RCCL all-reduce(AVG) of the flat gradient arena
+            opt.step(gathered=True)
+        else:
+            opt.step()
+
     def step():
-        return brainxai.train_step(model, opt, eeg, spec, labels, crit, ddp=ddp)
+        loss = fwd_bwd()
+        finish()
+        return loss, None
 
     for _ in range(args.warmup):
         loss, _ = step()
-    # ---- the whole step (forward, loss, backward, AdamW; ~130 launches) captured once into a hipGraph and replayed:
-    # launch-bound otherwise.  Multi-GPU runs stay eager (the RCCL all-reduce is issued by torch.distributed).
-    graph = None
-    if not args.no_graph and world == 1:
+    # ---- hipGraph: ~130 launches per step are captured once and replayed.  Single GPU: the whole step.  Multi GPU:
+    # forward+backward are replayed, the all-reduce and the fused AdamW (2 launches) are issued eagerly after it.
+    graph, graph_covers_all = None, ddp is None
+    if not args.no_graph:
         try:
             torch.cuda.synchronize()
             side = torch.cuda.Stream()
@@ -125,8 +148,12 @@ def main():
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                g_loss, _ = step()
+                g_loss = fwd_bwd()
+                if graph_covers_all:
+                    finish()
             graph.replay()
+            if not graph_covers_all:
+                finish()
             torch.cuda.synchronize()
         except Exception as exc:                          # noqa: BLE001
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
@@ -139,6 +166,8 @@ def main():
     for _ in range(args.steps):
         if graph is not None:
             graph.replay()
+            if not graph_covers_all:
+                finish()
         else:
             loss, _ = step()
     torch.cuda.synchronize()
@@ -251,8 +280,8 @@ def main():
                 "hip_graph": graph is not None, "final_loss": round(loss_val, 6), "gradcam": gradcam, "stacker_samples_per_sec": round(stacker_sps, 1),
                 "roofline": roofline, "cpu_baseline": cpu}
         line.update(extra)
-        print(json.dumps(line))
-    if world > 1:
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
