@@ -288,3 +288,40 @@ def integrated_gradients(model, inputs, baselines=None, target=None, n_steps=50,
     L.check(lib.bx_mul(_p(acc_e), _p(de), _p(acc_e), acc_e.numel(), _stream()), "bx_mul")
     L.check(lib.bx_mul(_p(acc_s), _p(ds), _p(acc_s), acc_s.numel(), _stream()), "bx_mul")
     return acc_e, acc_s
+
+
+def expected_gradients(model, x, background, nsamples=200, seed=0, max_batch=256):
+    """SHAP GradientExplainer's estimator for a single-input model (the reference explains ``multimodal_model.eeg_model``,
+    XAI_Multimodality.py:2283-2290):  phi_c(x) = E_{b, a}[(x - b) * d f_c/dx (b + a (x - b))], b drawn from ``background``,
+    a ~ U(0,1); draws from numpy's default_rng(seed) in sample-major order.  Returns [B, n_classes, *x.shape[1:]].
+    Interpolants are built with bx_axpby, gradients come from the HIP backward, products/means from bx_mul / bx_axpby."""
+    x = x.detach().float().contiguous()
+    background = background.detach().float().contiguous()
+    rng = np.random.default_rng(seed)
+    B = x.shape[0]
+    lib = L.load()
+    with _eval_frozen(model):
+        with torch.no_grad():
+            n_cls = model(x[:1]).shape[1]
+        out = torch.zeros(B, n_cls, *x.shape[1:], dtype=torch.float32, device=x.device)
+        for i in range(B):
+            idx = rng.integers(0, background.shape[0], size=nsamples)
+            alpha = rng.random(nsamples).astype(np.float32)
+            for k0 in range(0, nsamples, max_batch):
+                ks = range(k0, min(nsamples, k0 + max_batch))
+                base = background[torch.as_tensor(idx[k0:k0 + len(ks)], device=x.device)].contiguous()
+                diff = x[i:i + 1].expand_as(base).contiguous()
+                _axpby(base, diff, -1.0, 1.0)                               # diff = x - b
+                xi = base.clone()
+                for j, k in enumerate(ks):
+                    _axpby(diff[j], xi[j], float(alpha[k]), 1.0)            # b + a (x - b)
+                xi.requires_grad_(True)
+                y = model(xi)
+                for c in range(n_cls):
+                    seed_c = _one_hot_rows(torch.full((len(ks),), c, dtype=torch.int64, device=x.device), n_cls)
+                    (g,) = torch.autograd.grad(y, xi, grad_outputs=seed_c, retain_graph=True)
+                    g = g.contiguous()
+                    L.check(lib.bx_mul(_p(g), _p(diff), _p(g), g.numel(), _stream()), "bx_mul")
+                    for j in range(len(ks)):
+                        _axpby(g[j], out[i, c], 1.0 / nsamples, 1.0)
+    return out

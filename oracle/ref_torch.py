@@ -422,3 +422,30 @@ def summarize(t: torch.Tensor) -> np.ndarray:
     f = t.detach().double().flatten()
     ramp = torch.linspace(0.5, 1.5, f.numel(), dtype=torch.float64)
     return np.array([f.sum(), f.abs().sum(), (f * ramp).sum(), (f * f).sum()], dtype=np.float64)
+
+
+def expected_gradients(model, x, background, nsamples=200, seed=0):
+    """SHAP GradientExplainer's estimator (reference call sites XAI_Multimodality.py:2283-2290; the arithmetic lives in the
+    un-vendored `shap` package -> parity unpinned by the reference, canonical definition used):
+        phi_c(x) = E_{b ~ background, a ~ U(0,1)} [ (x - b) * d f_c / d x (b + a (x - b)) ]
+    Single-input model (the reference explains `multimodal_model.eeg_model`).  The (baseline index, alpha) draws come from
+    numpy's default_rng(seed) in sample-major order, so any implementation can reproduce them.  Returns [B, n_classes, ...]."""
+    was_training = model.training
+    model.eval()
+    rng = np.random.default_rng(seed)
+    B = x.shape[0]
+    with torch.no_grad():
+        n_cls = model(x[:1]).shape[1]
+    out = torch.zeros(B, n_cls, *x.shape[1:])
+    for i in range(B):
+        idx = rng.integers(0, background.shape[0], size=nsamples)
+        alpha = torch.from_numpy(rng.random(nsamples).astype(np.float32))
+        base = background[idx]
+        diff = x[i:i + 1] - base
+        xi = (base + alpha.view(-1, *([1] * (x.dim() - 1))) * diff).requires_grad_(True)
+        y = model(xi)
+        for c in range(n_cls):
+            (g,) = torch.autograd.grad(y[:, c].sum(), xi, retain_graph=True)
+            out[i, c] = (g * diff).mean(0)
+    model.train(was_training)
+    return out

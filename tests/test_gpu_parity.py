@@ -365,3 +365,91 @@ def test_rccl_single_rank_group_matches_plain_training():
             if use_ddp:
                 dist.destroy_process_group()
     assert torch.equal(finals[0], finals[1])
+
+
+def _toy_loader(n_batches, b, seed):
+    out = []
+    for i in range(n_batches):
+        eeg = O.seeded((b, 1, 19, 2000), seed + 10 * i, "randn")
+        spec = O.seeded((b, 4, 32, 64), seed + 10 * i + 1, "rand")
+        lab = F.one_hot(torch.randint(0, 6, (b,), generator=torch.Generator().manual_seed(seed + 10 * i + 2)), 6).float()
+        out.append(((eeg, spec), lab))
+    return out
+
+
+def test_train_and_validate_combined_loop(tmp_path):
+    """row E: the reference's epoch loop (XAI_Multimodality.py:1579-1681): per-epoch bookkeeping, checkpoint layout, resume"""
+    ref, mine = _pair(lambda: O.build_multimodal(19, 2000, 4, dropout=0.0), lambda: brainxai.build_multimodal(19, 2000, 4, dropout=0.0), 71)
+    train, valid = _toy_loader(3, 4, 500), _toy_loader(2, 4, 900)
+    # oracle loop: same arithmetic as the reference (loss.item()*B accumulation, argmax accuracy)
+    opt_r = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+    crit_r = torch.nn.KLDivLoss()
+    want = {"tl": [], "vl": [], "ta": [], "va": []}
+    for _ in range(2):
+        ref.train(); tot = cor = n = 0
+        for (e, s), y in train:
+            opt_r.zero_grad(); out = ref(e, s); loss = crit_r(out, y); loss.backward(); opt_r.step()
+            tot += float(loss) * e.shape[0]; cor += int((out.argmax(1) == y.argmax(1)).sum()); n += e.shape[0]
+        want["tl"].append(tot / n); want["ta"].append(cor / n * 100)
+        ref.eval(); tot = cor = n = 0
+        with torch.no_grad():
+            for (e, s), y in valid:
+                out = ref(e, s); loss = crit_r(out, y)
+                tot += float(loss) * e.shape[0]; cor += int((out.argmax(1) == y.argmax(1)).sum()); n += e.shape[0]
+        want["vl"].append(tot / n); want["va"].append(cor / n * 100)
+    try:
+        opt = brainxai.FlatAdamW(mine.parameters(), lr=1e-3)
+        tl, vl, ta, va = brainxai.train_and_validate_combined(mine, train, valid, 2, opt, brainxai.KLDivLoss(), DEV, str(tmp_path))
+        # epoch 0 sees (almost) the same weights; later epochs follow AdamW trajectories that drift apart (noise-gradient
+        # weights move by +-lr either way, see test_multimodal_train3), so they are only required to stay close
+        np.testing.assert_allclose(tl, want["tl"], rtol=1e-1); np.testing.assert_allclose(vl, want["vl"], rtol=1e-1)
+        assert abs(tl[0] - want["tl"][0]) / want["tl"][0] < 1e-2
+        assert len(ta) == len(va) == 2 and all(0 <= a <= 100 for a in ta + va)
+        ck = torch.load(tmp_path / "combined_checkpoint.pth.tar", map_location="cpu", weights_only=False)
+        assert set(ck) == {"epoch", "state_dict", "optimizer", "train_losses", "valid_losses", "train_accuracies", "valid_accuracies"}
+        assert ck["epoch"] == 2 and list(ck["state_dict"].keys()) == list(ref.state_dict().keys())
+        ref.load_state_dict(ck["state_dict"])          # checkpoints interchange with the reference-layout classes
+        # resume: a third epoch continues from the checkpoint (start_epoch = 2)
+        tl2, *_ = brainxai.train_and_validate_combined(mine, train, valid, 3, opt, brainxai.KLDivLoss(), DEV, str(tmp_path))
+        assert len(tl2) == 3 and tl2[:2] == tl
+    finally:
+        ops.clear_grad_views()
+
+
+def test_train_and_validate_eeg_distributed_single_rank(tmp_path):
+    """row F: reference training_distributed.py loop on a 1-rank RCCL group: DDP wrapper, manual L2 term, module.-prefixed
+    checkpoint with the extra keys the reference's load_checkpoint expects"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.manual_seed(5)
+    net = brainxai.EEGNet(6, Chans=19, Samples=2000, dropoutRate=0.25)
+    net.weight_decay = 1e-4
+    data = [(O.seeded((4, 1, 19, 2000), 70 + i, "randn"), torch.softmax(O.seeded((4, 6), 80 + i, "randn"), 1)) for i in range(3)]
+    net.to(DEV)
+    opt = brainxai.FlatAdamW(net.parameters(), lr=1e-3)
+    try:
+        tl, vl, ta, va = brainxai.train_and_validate_eeg_distributed(net, data, data[:1], 2, opt, brainxai.KLDivLoss("batchmean"), None, DEV,
+                                                                       str(tmp_path), None, 0, 1)
+        assert len(tl) == 2 and np.isfinite(tl).all() and np.isfinite(vl).all() and tl[1] < tl[0] * 1.5
+        ck = torch.load(tmp_path / "eeg_checkpoint.pth.tar", map_location="cpu", weights_only=False)
+        assert all(k.startswith("module.") for k in ck["state_dict"])
+        assert {"lr_scheduler", "regularization_losses"} <= set(ck) and len(ck["regularization_losses"]) == 2
+        assert ck["regularization_losses"][0] > 0
+    finally:
+        brainxai.cleanup()
+        ops.clear_grad_views()
+
+
+def test_expected_gradients_shap_style():
+    """row G (optional SHAP leg): GradientExplainer's estimator on the EEG branch, same (baseline, alpha) draws as the oracle"""
+    ref, mine = _pair(lambda: O.EEGNet(6, Chans=19, Samples=2000, dropoutRate=0.0), lambda: brainxai.EEGNet(6, Chans=19, Samples=2000, dropoutRate=0.0), 31)
+    x = O.seeded((2, 1, 19, 2000), 91, "randn")
+    bg = O.seeded((5, 1, 19, 2000), 92, "randn")
+    want = O.expected_gradients(ref, x, bg, nsamples=12, seed=3)
+    got = brainxai.expected_gradients(mine, x.to(DEV), bg.to(DEV), nsamples=12, seed=3, max_batch=8)
+    assert got.shape == want.shape == (2, 6, 1, 19, 2000)
+    _gclose(got, want, "expected gradients", tol=TOL)
+    # completeness-style sanity: attributions of class c sum to roughly f_c(x) - E_b f_c(b) (exact only in expectation)
+    assert torch.isfinite(got).all()
