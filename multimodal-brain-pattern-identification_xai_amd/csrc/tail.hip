@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ do
 // straight from global as 16-byte vectors.
 template <typename T>
 __global__ __launch_bounds__(256) void k_skip_dxs(const T* __restrict__ dout, const float* __restrict__ w1x1, int Cin,
-                                                   float* __restrict__ dxs, TailGeom g) {
+                                                   float* __restrict__ dxs, T* __restrict__ dx_even, TailGeom g) {
   extern __shared__ float swt[];   // [64][Cin_p]
   const int nci8 = g.Cin_p / 8;
   const long long n = g.npool * nci8;
@@ -351,8 +351,21 @@ __global__ __launch_bounds__(256) void k_skip_dxs(const T* __restrict__ dout, co
       }
   }
   if (live) {
+    if (dx_even) {
+      // H and W even: bilinear-to-half is the 2x2 mean, its transpose spreads dXs/4 over the 2x2 footprint
+      const int ox = (int)(pp % g.Wo);
+      const long long r = pp / g.Wo;
+      const int oy = (int)(r % g.Ho), b = (int)(r / g.Ho);
+      float q[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dxs[(size_t)pp * g.Cin_p + c8 * 8 + j] = acc[j];
+      for (int j = 0; j < 8; ++j) q[j] = 0.25f * acc[j];
+      const size_t base = (((size_t)b * g.H + 2 * oy) * g.W + 2 * ox) * g.Cin_p + c8 * 8;
+      st8(dx_even, base, q); st8(dx_even, base + g.Cin_p, q);
+      st8(dx_even, base + (size_t)g.W * g.Cin_p, q); st8(dx_even, base + (size_t)g.W * g.Cin_p + g.Cin_p, q);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dxs[(size_t)pp * g.Cin_p + c8 * 8 + j] = acc[j];
+    }
   }
 }
 
@@ -501,15 +514,18 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
   }
   if (dx_skip) {
     const long long n1 = g.npool * (g.Cin_p / 8);
+    const bool even = (g.H % 2 == 0) && (g.W % 2 == 0);
     BX_DISPATCH_DTYPE(d->dtype, T,
       hipLaunchKernelGGL((k_skip_dxs<T>), dim3(bx_ceil_div(n1, 256)), dim3(256), (size_t)64 * g.Cin_p * sizeof(float), s,
-                         (const T*)dout, w1x1, Cin, dxs, g));
+                         (const T*)dout, w1x1, Cin, dxs, even ? (T*)dx_skip : (T*)nullptr, g));
     BX_CHECK_LAUNCH("bx_block_tail_bwd(dxs)");
-    const long long n2 = (long long)g.B * g.H * g.W * (g.Cin_p / 8);
-    BX_DISPATCH_DTYPE(d->dtype, T,
-      hipLaunchKernelGGL((k_skip_scatter<T>), dim3(bx_ceil_div(n2, 256) > 4096 ? 4096 : bx_ceil_div(n2, 256)), dim3(256), 0, s,
-                         dxs, (T*)dx_skip, g));
-    BX_CHECK_LAUNCH("bx_block_tail_bwd(scatter)");
+    if (!even) {
+      const long long n2 = (long long)g.B * g.H * g.W * (g.Cin_p / 8);
+      BX_DISPATCH_DTYPE(d->dtype, T,
+        hipLaunchKernelGGL((k_skip_scatter<T>), dim3(bx_ceil_div(n2, 256) > 4096 ? 4096 : bx_ceil_div(n2, 256)), dim3(256), 0, s,
+                           dxs, (T*)dx_skip, g));
+      BX_CHECK_LAUNCH("bx_block_tail_bwd(scatter)");
+    }
   }
   return BX_OK;
 }

@@ -49,6 +49,7 @@ class Block(nn.Module):
         self._preact = 0          # set by explain.grad_cam for targets "blockN.convK"
         self._capture = None
         self._prepacked, self._pack_base = None, 0      # set per forward by Spectrogram_Model (one pack launch for all stages)
+        self._seed = None                               # idem: one dropout seed launch for all stages
 
     def forward(self, x):
         dt = self.compute_dtype
@@ -63,7 +64,7 @@ class Block(nn.Module):
         bn = self.bn
         cfg = ops.block_cfg(pool=self.pool_type, training=self.training, dropout_p=self.dropout.p if self.training else 0.0,
                             eps=bn.eps, momentum=0.1 if bn.momentum is None else bn.momentum, salt=self.salt,
-                            preact=self._preact, capture=self._capture, prepacked=self._prepacked, pack_base=self._pack_base)
+                            preact=self._preact, capture=self._capture, prepacked=self._prepacked, pack_base=self._pack_base, seed=self._seed)
         out = ops.BlockFn.apply(xi, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.conv3.weight,
                                 self.conv3.bias, bn.weight, bn.bias, self.conv1x1.weight, self.conv1x1.bias,
                                 bn.running_mean, bn.running_var, bn.num_batches_tracked, cfg)
@@ -105,12 +106,17 @@ class Spectrogram_Model(nn.Module):
 
     def features(self, x):
         self._pack_all()
+        blocks = [getattr(self, f"block{i}") for i in range(1, 6)]
+        if self.training and x.is_cuda and any(b.dropout.p > 0 for b in blocks):
+            seed = ops.next_seed(x.device)
+            for b in blocks:
+                b._seed = seed
         try:
-            for i in range(1, 6):
-                x = getattr(self, f"block{i}")(x)
+            for b in blocks:
+                x = b(x)
         finally:
-            for i in range(1, 6):
-                getattr(self, f"block{i}")._prepacked = None
+            for b in blocks:
+                b._prepacked, b._seed = None, None
         return x
 
     def forward(self, x):

@@ -320,7 +320,9 @@ class BlockFn(torch.autograd.Function):
         y3 = acts[3]
         B, H, W, Cc = y3.shape
         desc = _tail_desc(x, y3, cfg)
-        seed = next_seed(x.device) if (cfg.training and cfg.dropout_p > 0) else None
+        seed = None
+        if cfg.training and cfg.dropout_p > 0:
+            seed = cfg.seed if cfg.seed is not None else next_seed(x.device)       # the model hands one seed to all stages (salts differ)
         pooled = torch.empty(B, H // 2, W // 2, Cc, dtype=dt, device=x.device)
         out = torch.empty_like(pooled)
         mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
@@ -538,6 +540,6 @@ class EegFeaturesFn(torch.autograd.Function):
 
 def block_cfg(**kw) -> SimpleNamespace:
     base = dict(pool="max", training=False, dropout_p=0.0, eps=1e-5, momentum=0.1, salt=0, preact=0, capture=None,
-                prepacked=None, pack_base=0)
+                prepacked=None, pack_base=0, seed=None)
     base.update(kw)
     return SimpleNamespace(**base)
