@@ -634,34 +634,45 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const bf16_t* __restrict_
       }
     }
   }
-  // ---- ordered cross-wave sum through LDS, then one partial per workgroup
-  float* red = reinterpret_cast<float*>(lds);          // [9*MA*NB*4][64]
-  for (int w = 0; w < 4; ++w) {
-    __syncthreads();
-    if (wave == w) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int m = 0; m < MA; ++m)
-#pragma unroll
-          for (int n = 0; n < NB; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int idx = (((t * MA + m) * NB + n) * 4 + r) * 64 + lane;
-              red[idx] = (w == 0 ? 0.f : red[idx]) + acc[t][m][n][r];
-            }
-    }
-  }
+  // ---- cross-wave sum as a reduce-scatter through LDS: tile i of the 9*MA*NB accumulator tiles is owned by wave i%4.
+  //      In round s every wave hands the tiles owned by wave+s to their owner (float4 per lane, conflict-free) and
+  //      adds what wave-s handed to it; the order per tile is fixed (own, -1, -2, -3), so the result is deterministic.
+  //      Owners then store their tiles in FRAGMENT order ([tile][lane][reg]: 1 KiB coalesced per wave store);
+  //      k_wgrad_reduce3 maps fragments back to OIHW after summing the splits.
+  constexpr int NT = 9 * MA * NB, SLOTS = (NT + 3) / 4;
+  float4* red4 = reinterpret_cast<float4*>(lds);       // [4 writers][SLOTS][64]
   __syncthreads();
-  const size_t per_split = (size_t)9 * Ci_p * Co + Co;
-  float* out = partial + (size_t)blockIdx.x * per_split;
-  for (int idx = wave; idx < 9 * MA * NB * 4; idx += 4) {
-    const int r = idx & 3, n = (idx >> 2) % NB, m = (idx >> 2) / NB % MA, t = (idx >> 2) / (NB * MA);
-    const int cin = ci0 + m * 16 + 4 * g + r, cout = co0 + n * 16 + li;
-    if (cin < Ci_p) out[((size_t)t * Ci_p + cin) * Co + cout] = red[idx * 64 + lane];
-  }
-  if (want_bias) {
+#pragma unroll
+  for (int s = 1; s < 4; ++s) {
+    const int dst = (wave + s) & 3, src = (wave - s) & 3;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+      if ((i & 3) == dst) {
+        const f32x4 v = acc[i / (MA * NB)][(i / NB) % MA][i % NB];
+        red4[(wave * SLOTS + i / 4) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+      }
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+      if ((i & 3) == wave) {
+        const float4 v = red4[(src * SLOTS + i / 4) * 64 + lane];
+        f32x4& a = acc[i / (MA * NB)][(i / NB) % MA][i % NB];
+        a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+      }
+    __syncthreads();
+  }
+  const size_t nfrag = (size_t)gridDim.y * gridDim.z * NT * 256;       // floats of accumulator fragments per split
+  const size_t per_split = nfrag + Co;
+  float* out = partial + (size_t)blockIdx.x * per_split;
+  float4* out4 = reinterpret_cast<float4*>(out) + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * NT * 64;
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+    if ((i & 3) == wave) {
+      const f32x4 v = acc[i / (MA * NB)][(i / NB) % MA][i % NB];
+      out4[i * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  float* red = reinterpret_cast<float*>(lds);
+  if (want_bias) {
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
       float v = bsum[n];
@@ -672,55 +683,62 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const bf16_t* __restrict_
     __syncthreads();
     if (threadIdx.x < COT) {
       const int n = threadIdx.x >> 4, c = threadIdx.x & 15;
-      out[(size_t)9 * Ci_p * Co + co0 + threadIdx.x] =
+      out[nfrag + co0 + threadIdx.x] =
           red[(0 * NB + n) * 16 + c] + red[(1 * NB + n) * 16 + c] + red[(2 * NB + n) * 16 + c] + red[(3 * NB + n) * 16 + c];
     }
   }
 }
 
-// sum the partials in a fixed order.  A workgroup covers NO = 256/S float4 output groups x S split slices (S = 4,
-// 16 or 64: small outputs get many slices so that the chip is filled and no thread walks hundreds of splits);
-// slices are combined through LDS in slice order.  per_split is a multiple of 4 (Co % 16 == 0): float4s are aligned.
-__global__ __launch_bounds__(256) void k_wgrad_reduce2(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
-                                                        int nsplit, int Cin, int Ci_p, int Co, int S) {
+// sum the partials in a fixed order and scatter to OIHW.  A split is [ytiles][ztiles][9*MA*NB tiles][64 lanes][4 regs]
+// accumulator fragments followed by Co bias sums.  A workgroup covers NO = 256/S float4 groups x S split slices
+// (S = 4, 16 or 64: small outputs get many slices so that the chip is filled and no thread walks hundreds of splits);
+// slices are combined through LDS in slice order.
+__global__ __launch_bounds__(256) void k_wgrad_reduce3(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
+                                                        int nsplit, int Cin, int Co, int S, int MA, int NB, int ztiles, int nfrag4) {
   __shared__ float4 sm[256];
-  const size_t per_split = (size_t)9 * Ci_p * Co + Co;
+  const size_t per_split = (size_t)nfrag4 * 4 + Co;
   const int NO = 256 / S;
   const int o = threadIdx.x % NO, part = threadIdx.x / NO;
-  const size_t idx = ((size_t)blockIdx.x * NO + o) * 4;
+  const size_t e4 = (size_t)blockIdx.x * NO + o;          // float4 index inside a split
+  const bool live = e4 * 4 < per_split;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (idx < per_split) {
+  if (live) {
+    const float* src = partial + e4 * 4;
     int c = part;
     for (; c + 3 * S < nsplit; c += 4 * S) {      // four independent loads in flight; adds stay in split order
-      const float4 v0 = *reinterpret_cast<const float4*>(partial + (size_t)c * per_split + idx);
-      const float4 v1 = *reinterpret_cast<const float4*>(partial + (size_t)(c + S) * per_split + idx);
-      const float4 v2 = *reinterpret_cast<const float4*>(partial + (size_t)(c + 2 * S) * per_split + idx);
-      const float4 v3 = *reinterpret_cast<const float4*>(partial + (size_t)(c + 3 * S) * per_split + idx);
+      const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)c * per_split);
+      const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)(c + S) * per_split);
+      const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)(c + 2 * S) * per_split);
+      const float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)(c + 3 * S) * per_split);
       s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
       s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
       s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
       s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
     }
     for (; c < nsplit; c += S) {
-      const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)c * per_split + idx);
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * per_split);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
   }
   sm[threadIdx.x] = s;
   __syncthreads();
-  if (part == 0 && idx < per_split) {
+  if (part == 0 && live) {
     float4 r = sm[o];
     for (int k = 1; k < S; ++k) { const float4 v = sm[k * NO + o]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
     const float rr[4] = {r.x, r.y, r.z, r.w};
+    if (e4 < (size_t)nfrag4) {
+      const int NT = 9 * MA * NB;
+      const int lane = (int)(e4 & 63), tl = (int)(e4 >> 6);
+      const int i = tl % NT, yz = tl / NT, z = yz % ztiles, y = yz / ztiles;
+      const int n = i % NB, m = (i / NB) % MA, t = i / (NB * MA);
+      const int cout = (z * NB + n) * 16 + (lane & 15), cin0 = (y * MA + m) * 16 + 4 * (lane >> 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const size_t i = idx + j;
-      if (i < (size_t)9 * Ci_p * Co) {
-        const int co = (int)(i % Co), ci = (int)((i / Co) % Ci_p), t = (int)(i / ((size_t)Co * Ci_p));
-        if (ci < Cin) dw[((size_t)co * Cin + ci) * 9 + t] = rr[j];
-      } else if (db) {
-        db[i - (size_t)9 * Ci_p * Co] = rr[j];
-      }
+      for (int j = 0; j < 4; ++j)
+        if (cin0 + j < Cin) dw[((size_t)cout * Cin + cin0 + j) * 9 + t] = rr[j];
+    } else if (db) {
+      const size_t b0 = (e4 - nfrag4) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) db[b0 + j] = rr[j];
     }
   }
 }
@@ -734,13 +752,14 @@ static WgradPlan wgrad_plan(int B, int H, int W, int Ci_p, int Co) {
   p.tiles_x = (W + p.tw - 1) / p.tw; p.tiles_y = (H + 7) / 8; p.ntiles = p.tiles_x * p.tiles_y * B;
   p.ytiles = (Ci_p + 16 * p.ma - 1) / (16 * p.ma); p.ztiles = Co / (16 * p.nb);
   // (2,2) tiles run one workgroup per CU (register bound): aim at two rounds of 256; lighter tiles at four
-  int want = (p.ma * p.nb == 4 ? 512 : 1024) / (p.ytiles * p.ztiles);
+  static const int want_env = getenv("BX_WGRAD_WANT") ? atoi(getenv("BX_WGRAD_WANT")) : 0;
+  int want = (want_env ? want_env : (p.ma * p.nb == 4 ? 512 : 1024)) / (p.ytiles * p.ztiles);
   if (want < 1) want = 1;
   if (want > p.ntiles) want = p.ntiles;
   p.tps = (p.ntiles + want - 1) / want;
   p.nsplit = (p.ntiles + p.tps - 1) / p.tps;
   const size_t stage = (size_t)10 * (p.tw + 2) * 32 * p.ma + (size_t)8 * p.tw * 32 * p.nb;
-  const size_t red = (size_t)9 * p.ma * p.nb * 4 * 64 * sizeof(float);
+  const size_t red = (size_t)((9 * p.ma * p.nb + 3) / 4) * 4 * 64 * sizeof(float4);
   p.lds = stage > red ? stage : red;
   return p;
 }
@@ -749,7 +768,7 @@ int bx_wgrad_mfma_supported(int Ci_p, int Co, int dtype) {
 }
 size_t bx_wgrad_mfma_workspace(int B, int H, int W, int Ci_p, int Co) {
   const WgradPlan p = wgrad_plan(B, H, W, Ci_p, Co);
-  return (size_t)p.nsplit * ((size_t)9 * Ci_p * Co + Co) * sizeof(float);
+  return (size_t)p.nsplit * ((size_t)p.ytiles * p.ztiles * 9 * p.ma * p.nb * 256 + Co) * sizeof(float);
 }
 template <int MA, int NB, int TW>
 static void launch_wgrad(const WgradPlan& p, const void* x, const void* dz, float* ws, int H, int W, int Ci_p, int Co, hipStream_t s) {
@@ -770,10 +789,12 @@ int bx_wgrad_mfma_launch(const void* x, const void* dz, float* dw, float* db, in
   else BX_WG(2, 2);
 #undef BX_WG
   BX_CHECK_LAUNCH("bx_conv3x3_wgrad(mfma)");
-  const size_t per_split = (size_t)9 * Ci_p * Co + Co;
+  const int nfrag4 = p.ytiles * p.ztiles * 9 * p.ma * p.nb * 64;
+  const size_t per_split = (size_t)nfrag4 * 4 + Co;
   const int S = per_split >= 65536 ? 4 : per_split >= 8192 ? 16 : 64;
-  const int per_wg = (256 / S) * 4;
-  hipLaunchKernelGGL(k_wgrad_reduce2, dim3((unsigned)((per_split + per_wg - 1) / per_wg)), dim3(256), 0, s, part, dw, db, p.nsplit, Cin, Ci_p, Co, S);
+  const int per_wg = 256 / S;                                // float4 groups per workgroup
+  hipLaunchKernelGGL(k_wgrad_reduce3, dim3((unsigned)((per_split / 4 + per_wg - 1) / per_wg)), dim3(256), 0, s, part, dw, db, p.nsplit, Cin, Co, S,
+                     p.ma, p.nb, p.ztiles, nfrag4);
   BX_CHECK_LAUNCH("bx_conv3x3_wgrad(mfma reduce)");
   return BX_OK;
 }
