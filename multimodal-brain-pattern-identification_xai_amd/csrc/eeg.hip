@@ -59,7 +59,7 @@ static EegWs eeg_ws(const EegGeom& g) {
   const int rows = g.B * g.Ch;
   w.nblk_rows = rows;
   size_t npart = (size_t)w.nblk_rows;
-  const size_t n_dw = (size_t)g.B * ((g.T + 255) / 256), n_sep = (size_t)g.B * ((g.T1 + 63) / 64);
+  const size_t n_dw = (size_t)g.B * ((g.T + 255) / 256), n_sep = (size_t)g.B * ((g.T1 + 255) / 256);
   if (npart < n_dw) npart = n_dw;
   if (npart < n_sep) npart = n_sep;
   if (npart < (size_t)g.B) npart = (size_t)g.B;
@@ -69,7 +69,7 @@ static EegWs eeg_ws(const EegGeom& g) {
   w.off_du2 = o; o += bx_align_up((size_t)g.B * g.FD * g.T * 4, 256);
   w.off_r = o;   o += bx_align_up((size_t)g.B * (g.FD * g.Ch + g.FD) * 4, 256);
   w.off_w1p = o; o += bx_align_up((size_t)rows * g.F1 * g.K1 * 4, 256);
-  w.off_sepp = o; o += bx_align_up((size_t)g.B * g.F2 * g.FD * g.K2 * 4, 256);
+  w.off_sepp = o; o += bx_align_up((size_t)g.B * 4 * g.F2 * g.FD * g.K2 * 4, 256);
   w.off_coef = o; o += bx_align_up((size_t)3 * 3 * EEG_MAXF * 4 + 256, 256);
   w.total = o;
   return w;
@@ -215,42 +215,73 @@ __global__ void k_eeg_bn_elu_pool(const float* __restrict__ in, const float* __r
   }
 }
 
-// E4: dense temporal conv FD -> F2 over K2 taps; thread per (b, t) -> 16 outputs. grid (ceil(T1/64), B), 64 threads
-__global__ __launch_bounds__(64) void k_eeg_sep(const float* __restrict__ p1, const float* __restrict__ ws, float* __restrict__ s,
-                                                 float* __restrict__ partials, EegGeom g, int want_stats) {
-  __shared__ float sp[EEG_MAXF][64 + 16];
-  __shared__ float sw[16 * 16 * 16];
-  const int b = blockIdx.y, t0 = blockIdx.x * 64;
-  for (int i = threadIdx.x; i < g.F2 * g.FD * g.K2; i += 64) sw[i] = ws[i];
-  for (int i = threadIdx.x; i < g.FD * (64 + g.K2 - 1); i += 64) {
-    const int fd = i / (64 + g.K2 - 1), j = i % (64 + g.K2 - 1);
-    const int t = t0 + j - g.padl2;
-    sp[fd][j] = (t >= 0 && t < g.T1) ? p1[((size_t)b * g.FD + fd) * g.T1 + t] : 0.f;
+// E4: dense temporal conv FD -> F2 over K2 = 16 taps.  grid (ceil(T1/256), B), 256 threads: wave w owns outputs
+// 4w..4w+3, a lane owns 4 consecutive time steps -> 16 accumulators.  The input tile [16][256+16] and the weights
+// (transposed to [fd][k][o]) sit in LDS; per input map a lane reads its window as 5 aligned float4s and per tap one
+// wave-uniform float4 of weights (broadcast): 21 LDS reads feed 256 FMAs (the previous thread-per-time-step layout
+// issued 17 reads per 16 FMAs and was LDS bound).  BatchNorm partial sums: one [2][16] row per workgroup.
+#define SEP_TT 256
+__global__ __launch_bounds__(256) void k_eeg_sep(const float* __restrict__ p1, const float* __restrict__ ws, float* __restrict__ s,
+                                                  float* __restrict__ partials, EegGeom g, int want_stats) {
+  constexpr int TP = SEP_TT + 16;
+  __shared__ __attribute__((aligned(16))) float sp[16 * TP];        // index j <-> t = t0 + j - padl2 (zero outside [0, T1))
+  __shared__ __attribute__((aligned(16))) float sw[16 * 16 * 16];   // [fd][k][o]
+  const int b = blockIdx.y, t0 = blockIdx.x * SEP_TT;
+  for (int i = threadIdx.x; i < 4096; i += 256) {
+    const int k = i & 15, fd = (i >> 4) & 15, o = i >> 8;
+    sw[(fd * 16 + k) * 16 + o] = ws[i];
+  }
+  for (int i = threadIdx.x; i < 16 * TP; i += 256) {
+    const int fd = i / TP, j = i % TP;
+    const int tt = t0 + j - g.padl2;
+    sp[i] = (tt >= 0 && tt < g.T1) ? p1[((size_t)b * g.FD + fd) * g.T1 + tt] : 0.f;
   }
   __syncthreads();
-  const int t = t0 + threadIdx.x;
-  float acc[16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tl = 4 * lane;
+  float acc[4][4];
 #pragma unroll
-  for (int o = 0; o < 16; ++o) acc[o] = 0.f;
-  for (int fd = 0; fd < 16; ++fd)
-    for (int k = 0; k < 16; ++k) {
-      const float v = sp[fd][threadIdx.x + k];
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int o = 0; o < 16; ++o) acc[o] = fmaf(sw[(o * 16 + fd) * 16 + k], v, acc[o]);
+    for (int o = 0; o < 4; ++o) acc[j][o] = 0.f;
+  for (int fd = 0; fd < 16; ++fd) {
+    const float* row = sp + fd * TP + tl;
+    float4 cur = *reinterpret_cast<const float4*>(row);
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      const float4 nxt = *reinterpret_cast<const float4*>(row + 4 * (kq + 1));
+      const float win[8] = {cur.x, cur.y, cur.z, cur.w, nxt.x, nxt.y, nxt.z, nxt.w};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float4 wq = *reinterpret_cast<const float4*>(sw + (fd * 16 + 4 * kq + kk) * 16 + 4 * wave);
+        const float wv[4] = {wq.x, wq.y, wq.z, wq.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int o = 0; o < 4; ++o) acc[j][o] = fmaf(wv[o], win[kk + j], acc[j][o]);
+      }
+      cur = nxt;
     }
-  const bool ok = t < g.T1;
+  }
+  float su[4], sq[4];
 #pragma unroll
-  for (int o = 0; o < 16; ++o) {
-    if (ok) s[((size_t)b * g.F2 + o) * g.T1 + t] = acc[o];
-    else acc[o] = 0.f;
+  for (int o = 0; o < 4; ++o) {
+    su[o] = sq[o] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int tt = t0 + tl + j;
+      if (tt < g.T1) {
+        s[((size_t)b * g.F2 + 4 * wave + o) * g.T1 + tt] = acc[j][o];
+        su[o] += acc[j][o]; sq[o] += acc[j][o] * acc[j][o];
+      }
+    }
   }
   if (!want_stats) return;
 #pragma unroll
-  for (int o = 0; o < 16; ++o) {
-    const float su = wave_sum(acc[o]), q = wave_sum(acc[o] * acc[o]);
-    if (threadIdx.x == 0) {
-      partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + o] = su;
-      partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 16 + o] = q;
+  for (int o = 0; o < 4; ++o) {
+    const float a = wave_sum(su[o]), q = wave_sum(sq[o]);
+    if (lane == 0) {
+      partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 4 * wave + o] = a;
+      partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 16 + 4 * wave + o] = q;
     }
   }
 }
@@ -296,8 +327,8 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
                        seed, pdrop, d->salt);
     BX_CHECK_LAUNCH("eeg pool1");
   }
-  dim3 gsep(bx_ceil_div(g.T1, 64), g.B);
-  hipLaunchKernelGGL(k_eeg_sep, gsep, dim3(64), 0, s, p1, p->sep_w, smap, part, g, tr);
+  dim3 gsep(bx_ceil_div(g.T1, SEP_TT), g.B);
+  hipLaunchKernelGGL(k_eeg_sep, gsep, dim3(256), 0, s, p1, p->sep_w, smap, part, g, tr);
   BX_CHECK_LAUNCH("eeg sepconv");
   hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(1024), 0, s, part, (int)(gsep.x * gsep.y), (double)g.B * g.T1, g.F2, tr, p->bn3_w, p->bn3_b,
                      p->bn3_rm, p->bn3_rv, p->bn3_nbt, d->momentum, d->eps, st.sc3, st.sh3, st.mean3, st.inv3);
@@ -372,62 +403,141 @@ __global__ void k_eeg_bn_bwd_apply(float* __restrict__ du, const float* __restri
   }
 }
 
-// sepconv backward: one workgroup per sample; LDS holds ds[16][T1] and p1[16][T1+15]
-// (a) dp1[fd][t] = sum_{o,k} ws[o][fd][k] ds[o][t-k+padl]   (b) partial dws[o][fd][k] = sum_t ds[o][t] p1[fd][t+k-padl]
+// sepconv backward: grid (B, 4); LDS holds the sample's ds[16][.] and p1[16][.] rows (zero halo) and the weights.
+// (a) dp1[fd][t] = sum_{o,k} ws[o][fd][k] ds[o][t-k+padl]: wave w of quarter q owns map fd = 4q+w, a lane 8 consecutive
+//     time steps; per output map o it reads the 23-value window as 6 aligned float4s and 16 weights as 4 broadcast
+//     float4s for 128 FMAs.
+// (b) partial dws[o][fd][k] = sum_t ds[o][t] p1[fd][t+k-padl] over the quarter's time range: thread = (o, fd), 16 tap
+//     accumulators, sliding p1 window: 2 float4 reads per 64 FMAs.
+// Row pitch TP: multiple of 4 with TP/4 odd (the 16 fd rows a wave reads then fall on different bank groups).
+__host__ __device__ inline int eeg_sepb_pitch(int T1) { int tp = ((T1 + 7) & ~7) + 24; if (((tp >> 2) & 1) == 0) tp += 4; return tp; }
 __global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ ds, const float* __restrict__ p1, const float* __restrict__ ws,
                                                       float* __restrict__ dp1, float* __restrict__ wpart, EegGeom g) {
-  extern __shared__ float sm[];
-  const int T1 = g.T1, TP = T1 + 16;
-  float* sds = sm;                 // [16][TP] with padl2.. zero halo on both sides: index t + 8
-  float* sp1 = sm + 16 * TP;       // [16][TP]
-  float* sw = sp1 + 16 * TP;       // [16*16*16]
-  const int b = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int T1 = g.T1, TP = eeg_sepb_pitch(T1);
+  float* sds = sm;                 // [16][TP]  index t + 8
+  float* sp1 = sm + 16 * TP;       // [16][TP]  index t + 7
+  float* sw = sp1 + 16 * TP;       // [o][fd][k]
+  const int b = blockIdx.x, q = blockIdx.y;
   for (int i = threadIdx.x; i < 16 * TP; i += 256) {
-    const int f = i / TP, j = i % TP, t = j - 8;
-    const bool in = t >= 0 && t < T1;
-    sds[i] = in ? ds[((size_t)b * 16 + f) * T1 + t] : 0.f;
-    sp1[i] = in ? p1[((size_t)b * 16 + f) * T1 + t] : 0.f;
+    const int f = i / TP, j = i % TP;
+    const int ta = j - 8, tb = j - 7;
+    sds[i] = (ta >= 0 && ta < T1) ? ds[((size_t)b * 16 + f) * T1 + ta] : 0.f;
+    sp1[i] = (tb >= 0 && tb < T1) ? p1[((size_t)b * 16 + f) * T1 + tb] : 0.f;
   }
   for (int i = threadIdx.x; i < 4096; i += 256) sw[i] = ws[i];
   __syncthreads();
-  // (a)  blockIdx.y selects a quarter of the maps / of the weight-gradient outputs
-  const int qa = blockIdx.y, nq = gridDim.y;
-  for (int i = qa * 256 + threadIdx.x; i < 16 * T1; i += 256 * nq) {
-    const int fd = i / T1, t = i % T1;
-    float acc = 0.f;
-    for (int o = 0; o < 16; ++o)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // (a)
+  {
+    const int fd = 4 * q + wave;
+    for (int t8 = lane; t8 * 8 < T1; t8 += 64) {
+      const int tb = t8 * 8;
+      float acc[8];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) acc = fmaf(sw[(o * 16 + fd) * 16 + k], sds[o * TP + (t - k + g.padl2) + 8], acc);
-    dp1[((size_t)b * 16 + fd) * T1 + t] = acc;
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      for (int o = 0; o < 16; ++o) {
+        float V[24], Wt[16];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const float4 v = *reinterpret_cast<const float4*>(sds + o * TP + tb + 4 * c);   // ds[o][tb - 8 + 4c ..]
+          V[4 * c] = v.x; V[4 * c + 1] = v.y; V[4 * c + 2] = v.z; V[4 * c + 3] = v.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 v = *reinterpret_cast<const float4*>(sw + (o * 16 + fd) * 16 + 4 * c);
+          Wt[4 * c] = v.x; Wt[4 * c + 1] = v.y; Wt[4 * c + 2] = v.z; Wt[4 * c + 3] = v.w;
+        }
+        // ds[o][t - k + padl] with t = tb + j, padl = 7  ->  V[(t - k + 7) - (tb - 8)] = V[15 - k + j]
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = fmaf(Wt[k], V[15 - k + j], acc[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (tb + j < T1) dp1[((size_t)b * 16 + fd) * T1 + tb + j] = acc[j];
+    }
   }
   // (b)
-  for (int i = qa * 256 + threadIdx.x; i < 4096; i += 256 * nq) {
-    const int k = i & 15, fd = (i >> 4) & 15, o = i >> 8;
-    float acc = 0.f;
-    for (int t = 0; t < T1; ++t) acc = fmaf(sds[o * TP + t + 8], sp1[fd * TP + (t + k - g.padl2) + 8], acc);
-    wpart[(size_t)b * 4096 + i] = acc;
+  {
+    const int o = threadIdx.x >> 4, fd = threadIdx.x & 15;
+    const int n4 = (T1 + 3) / 4;
+    const int c0 = n4 * q / 4, c1 = n4 * (q + 1) / 4;
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    const float* prow = sp1 + fd * TP;        // prow[t + k] = p1[fd][t + k - 7]
+    const float* drow = sds + o * TP + 8;
+    float P[20];
+    if (c0 < c1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(prow + 4 * c0 + 4 * c);
+        P[4 * c] = v.x; P[4 * c + 1] = v.y; P[4 * c + 2] = v.z; P[4 * c + 3] = v.w;
+      }
+    }
+    for (int c = c0; c < c1; ++c) {
+      const int tq = 4 * c;
+      const float4 d = *reinterpret_cast<const float4*>(drow + tq);
+      const float4 v = *reinterpret_cast<const float4*>(prow + tq + 16);
+      P[16] = v.x; P[17] = v.y; P[18] = v.z; P[19] = v.w;
+      const float D[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = fmaf(D[i], P[i + k], acc[k]);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) P[k] = P[k + 4];
+    }
+    float4* dst = reinterpret_cast<float4*>(wpart + ((size_t)b * 4 + q) * 4096 + (o * 16 + fd) * 16);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[c] = make_float4(acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
   }
 }
-// depthwise backward pass A: per sample  R[fd][ch] = sum_t dd[fd][t] * c1[f][ch][t],  Sd[fd] = sum_t dd[fd][t]
+// depthwise backward pass A: per sample  R[fd][ch] = sum_t dd[fd][t] * c1[f][ch][t],  Sd[fd] = sum_t dd[fd][t].
+// One wave per (filter f, electrode ch) row of c1: the row is read ONCE for both depth maps fd = 2f, 2f+1 (D == 2),
+// 8 time steps per lane per trip (16-byte c1 loads, float4 gradient loads) when T % 8 == 0; the last FD wave tasks
+// produce Sd.  Shuffle reduce, no workgroup barriers.  grid (B, ceil((F1*Ch + FD)/4)).
 template <typename T>
 __global__ __launch_bounds__(256) void k_eeg_dw_bwd_a(const T* __restrict__ c1, const float* __restrict__ dd, float* __restrict__ rpart, EegGeom g) {
-  // one wave per output: lanes stride over time, shuffle-reduce, no workgroup barriers
   const int b = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nout = g.FD * g.Ch + g.FD;
-  for (int o = blockIdx.y * 4 + wave; o < nout; o += 4 * gridDim.y) {
-    float acc = 0.f;
-    if (o < g.FD * g.Ch) {
-      const int fd = o / g.Ch, ch = o % g.Ch, f = fd / g.D;
-      const float* dr = dd + ((size_t)b * g.FD + fd) * g.T;
-      const size_t cb = (((size_t)b * g.F1 + f) * g.Ch + ch) * g.T;
-      for (int t = lane; t < g.T; t += 64) acc = fmaf(dr[t], ldf(c1, cb + t), acc);
+  const int nrow = g.F1 * g.Ch, nout = g.FD * g.Ch + g.FD;
+  const int task = blockIdx.y * 4 + wave;
+  if (task < nrow) {
+    const int f = task / g.Ch, ch = task % g.Ch;
+    const float* d0 = dd + ((size_t)b * g.FD + 2 * f) * g.T;
+    const float* d1 = d0 + g.T;
+    const size_t cb = (((size_t)b * g.F1 + f) * g.Ch + ch) * g.T;
+    float a0 = 0.f, a1 = 0.f;
+    if ((g.T & 7) == 0) {
+      for (int i = lane; i < g.T / 8; i += 64) {
+        float c[8];
+        ld8(c1, cb + 8 * (size_t)i, c);
+        const float4 u0 = *reinterpret_cast<const float4*>(d0 + 8 * i), u1 = *reinterpret_cast<const float4*>(d0 + 8 * i + 4);
+        const float4 v0 = *reinterpret_cast<const float4*>(d1 + 8 * i), v1 = *reinterpret_cast<const float4*>(d1 + 8 * i + 4);
+        a0 += u0.x * c[0] + u0.y * c[1] + u0.z * c[2] + u0.w * c[3] + u1.x * c[4] + u1.y * c[5] + u1.z * c[6] + u1.w * c[7];
+        a1 += v0.x * c[0] + v0.y * c[1] + v0.z * c[2] + v0.w * c[3] + v1.x * c[4] + v1.y * c[5] + v1.z * c[6] + v1.w * c[7];
+      }
     } else {
-      const float* dr = dd + ((size_t)b * g.FD + (o - g.FD * g.Ch)) * g.T;
-      for (int t = lane; t < g.T; t += 64) acc += dr[t];
+      for (int tt = lane; tt < g.T; tt += 64) {
+        const float c = ldf(c1, cb + tt);
+        a0 = fmaf(d0[tt], c, a0); a1 = fmaf(d1[tt], c, a1);
+      }
     }
+    a0 = wave_sum(a0); a1 = wave_sum(a1);
+    if (lane == 0) {
+      rpart[(size_t)b * nout + (2 * f) * g.Ch + ch] = a0;
+      rpart[(size_t)b * nout + (2 * f + 1) * g.Ch + ch] = a1;
+    }
+  } else if (task < nrow + g.FD) {
+    const int fd = task - nrow;
+    const float* dr = dd + ((size_t)b * g.FD + fd) * g.T;
+    float acc = 0.f;
+    for (int tt = lane; tt < g.T; tt += 64) acc += dr[tt];
     acc = wave_sum(acc);
-    if (lane == 0) rpart[(size_t)b * nout + o] = acc;
+    if (lane == 0) rpart[(size_t)b * nout + g.FD * g.Ch + fd] = acc;
   }
 }
 // finalize of pass A: ddw, dgamma1, dbeta1 and the BN1-backward coefficients
@@ -439,7 +549,15 @@ __global__ void k_eeg_dw_bwd_finalize(const float* __restrict__ rpart, int B, Ee
   const int nout = g.FD * g.Ch + g.FD;
   for (int o = threadIdx.x; o < nout; o += blockDim.x) {
     double s = 0;
-    for (int b = 0; b < B; ++b) s += rpart[(size_t)b * nout + o];
+    int bb = 0;
+    for (; bb + 8 <= B; bb += 8) {             // eight independent loads in flight, added in sample order
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = rpart[(size_t)(bb + j) * nout + o];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; bb < B; ++bb) s += rpart[(size_t)bb * nout + o];
     R[o] = s;
   }
   __syncthreads();
@@ -628,14 +746,14 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
   }
   // separable conv
   {
-    const size_t lds = ((size_t)2 * 16 * (g.T1 + 16) + 4096) * sizeof(float);
+    const size_t lds = ((size_t)2 * 16 * eeg_sepb_pitch(g.T1) + 4096) * sizeof(float);
     BX_REQUIRE(lds <= 160 * 1024, "bx_eeg_features_bwd: T/P1 too long for the LDS tile (%zu bytes)", lds);
     if (hipFuncSetAttribute((const void*)k_eeg_sep_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       BX_FAIL(BX_EHIP, "bx_eeg_features_bwd: cannot reserve %zu bytes of LDS", lds);
     hipLaunchKernelGGL(k_eeg_sep_bwd, dim3(g.B, 4), dim3(256), lds, s, du3, p1, p->sep_w, dp1, sepp, g);
     BX_CHECK_LAUNCH("eeg sep bwd");
     if (gr->sep_w) {
-      BX_SUM_PARTIALS(sepp, gr->sep_w, g.B, 4096, s);
+      BX_SUM_PARTIALS(sepp, gr->sep_w, g.B * 4, 4096, s);
       BX_CHECK_LAUNCH("eeg sep wgrad reduce");
     }
   }
@@ -652,9 +770,9 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
     BX_CHECK_LAUNCH("eeg bn2 bwd apply");
   }
   // depthwise + BN1
-  BX_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((k_eeg_dw_bwd_a<T>), dim3(g.B, (g.FD * g.Ch + g.FD + 3) / 4), dim3(256), 0, s, (const T*)c1, du2, rpart, g));
+  BX_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((k_eeg_dw_bwd_a<T>), dim3(g.B, (g.F1 * g.Ch + g.FD + 3) / 4), dim3(256), 0, s, (const T*)c1, du2, rpart, g));
   BX_CHECK_LAUNCH("eeg dw bwd A");
-  hipLaunchKernelGGL(k_eeg_dw_bwd_finalize, dim3(1), dim3(256), 0, s, rpart, g.B, g, tr, p->dw_w, p->bn1_w, st.mean1, st.inv1, st.sc1, st.sh1,
+  hipLaunchKernelGGL(k_eeg_dw_bwd_finalize, dim3(1), dim3(512), 0, s, rpart, g.B, g, tr, p->dw_w, p->bn1_w, st.mean1, st.inv1, st.sc1, st.sh1,
                      gr->dw_w, gr->bn1_w, gr->bn1_b, coef1);
   BX_CHECK_LAUNCH("eeg dw bwd finalize");
   if (gr->conv1_w || dx) {

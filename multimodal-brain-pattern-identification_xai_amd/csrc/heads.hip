@@ -71,11 +71,14 @@ __global__ __launch_bounds__(256) void k_linear_lsm_bwd_dx(const float* __restri
     }
   }
 }
-// parameter gradients: the workgroup first builds dlogit[b][n] in LDS (B*N values), then thread k accumulates its N
-// outputs over the batch in order (x[b][k] coalesced, dlogit broadcast from LDS); thread 0 of block 0 sums the bias.
+// parameter gradients: the workgroup first builds dlogit[b][n] in LDS (B*N values); a thread owns one input column k
+// of a 16-column slab and every 16th sample (all of its x loads are in flight together -- the batch loop used to be one
+// thread's serial chain of HBM round trips), then the 16 sample groups are summed through LDS in group order.
+// Thread 0.. of block 0 sums the bias.  LDS: B*N + 16*N*16 floats.
 __global__ __launch_bounds__(256) void k_linear_lsm_bwd_w(const float* __restrict__ dlogp, const float* __restrict__ logp,
     const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db, int B, int K, int N) {
-  extern __shared__ float sdl[];   // [B][N]
+  extern __shared__ float sdl[];   // [B][N] | [16 groups][N][16 columns]
+  float* sred = sdl + (size_t)B * N;
   for (int b = threadIdx.x; b < B; b += 256) {
     float dl[HEAD_MAX_N];
     lsm_bwd_row(dlogp + (size_t)b * N, logp + (size_t)b * N, N, dl);
@@ -83,19 +86,30 @@ __global__ __launch_bounds__(256) void k_linear_lsm_bwd_w(const float* __restric
     for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) sdl[b * N + n] = dl[n];
   }
   __syncthreads();
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k < K && dw) {
+  const int kk = threadIdx.x & 15, bg = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + kk;
+  if (dw) {
     float acc[HEAD_MAX_N];
 #pragma unroll
     for (int n = 0; n < HEAD_MAX_N; ++n) acc[n] = 0.f;
+    if (k < K) {
 #pragma unroll 4
-    for (int b = 0; b < B; ++b) {              // independent loads: keep several in flight
-      const float xv = x[(size_t)b * K + k];
+      for (int b = bg; b < B; b += 16) {
+        const float xv = x[(size_t)b * K + k];
 #pragma unroll
-      for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) acc[n] = fmaf(sdl[b * N + n], xv, acc[n]);
+        for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) acc[n] = fmaf(sdl[b * N + n], xv, acc[n]);
+      }
     }
 #pragma unroll
-    for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) dw[(size_t)n * K + k] = acc[n];
+    for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) sred[(bg * N + n) * 16 + kk] = acc[n];
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * 16; i += 256) {
+      const int n = i >> 4, kc = blockIdx.x * 16 + (i & 15);
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) s += sred[(g * N + n) * 16 + (i & 15)];
+      if (kc < K) dw[(size_t)n * K + kc] = s;
+    }
   }
   if (db && blockIdx.x == 0 && (int)threadIdx.x < N) {
     float s = 0.f;
@@ -113,14 +127,14 @@ extern "C" int bx_linear_lsm_fwd(const float* x, const float* w, const float* b,
 extern "C" int bx_linear_lsm_bwd(const float* dlogp, const float* logp, const float* x, const float* w, float* dx,
                                  float* dw, float* db, int B, int K, int N, bxStream stream) {
   BX_REQUIRE(dlogp && logp && x && w && B > 0 && K > 0 && N > 0 && N <= HEAD_MAX_N, "bx_linear_lsm_bwd: bad arguments");
-  BX_REQUIRE((size_t)B * N * sizeof(float) <= 60 * 1024, "bx_linear_lsm_bwd: batch %d too large for the LDS gradient tile (B*N <= 15360)", B);
+  BX_REQUIRE(((size_t)B * N + 256 * N) * sizeof(float) <= 60 * 1024, "bx_linear_lsm_bwd: batch %d too large for the LDS gradient tile ((B+256)*N <= 15360)", B);
   hipStream_t s = (hipStream_t)stream;
   if (dx) {
     hipLaunchKernelGGL((k_linear_lsm_bwd_dx<float, false>), dim3(B), dim3(256), 0, s, dlogp, logp, w, dx, (float*)nullptr, K, N, 1);
     BX_CHECK_LAUNCH("bx_linear_lsm_bwd(dx)");
   }
   if (dw || db) {
-    hipLaunchKernelGGL(k_linear_lsm_bwd_w, dim3(bx_ceil_div(K, 256)), dim3(256), (size_t)B * N * sizeof(float), s, dlogp, logp, x, dw, db, B, K, N);
+    hipLaunchKernelGGL(k_linear_lsm_bwd_w, dim3(bx_ceil_div(K, 16)), dim3(256), ((size_t)B * N + 256 * N) * sizeof(float), s, dlogp, logp, x, dw, db, B, K, N);
     BX_CHECK_LAUNCH("bx_linear_lsm_bwd(w)");
   }
   return BX_OK;
@@ -141,7 +155,7 @@ extern "C" int bx_gap_fc_lsm_bwd(const float* dlogp, const float* logp, const fl
                                  void* dfeat, float* dw, float* db, int B, int HW, int C, int N, int dtype, bxStream stream) {
   BX_DTYPE_OK(dtype);
   BX_REQUIRE(dlogp && logp && gap_out && w && B > 0 && HW > 0 && C > 0 && N > 0 && N <= HEAD_MAX_N, "bx_gap_fc_lsm_bwd: bad arguments");
-  BX_REQUIRE((size_t)B * N * sizeof(float) <= 60 * 1024, "bx_gap_fc_lsm_bwd: batch %d too large for the LDS gradient tile (B*N <= 15360)", B);
+  BX_REQUIRE(((size_t)B * N + 256 * N) * sizeof(float) <= 60 * 1024, "bx_gap_fc_lsm_bwd: batch %d too large for the LDS gradient tile ((B+256)*N <= 15360)", B);
   hipStream_t s = (hipStream_t)stream;
   if (dfeat) {
     BX_DISPATCH_DTYPE(dtype, T,
@@ -149,7 +163,7 @@ extern "C" int bx_gap_fc_lsm_bwd(const float* dlogp, const float* logp, const fl
     BX_CHECK_LAUNCH("bx_gap_fc_lsm_bwd(dfeat)");
   }
   if (dw || db) {
-    hipLaunchKernelGGL(k_linear_lsm_bwd_w, dim3(bx_ceil_div(C, 256)), dim3(256), (size_t)B * N * sizeof(float), s, dlogp, logp, gap_out, dw, db, B, C, N);
+    hipLaunchKernelGGL(k_linear_lsm_bwd_w, dim3(bx_ceil_div(C, 16)), dim3(256), ((size_t)B * N + 256 * N) * sizeof(float), s, dlogp, logp, gap_out, dw, db, B, C, N);
     BX_CHECK_LAUNCH("bx_gap_fc_lsm_bwd(w)");
   }
   return BX_OK;
