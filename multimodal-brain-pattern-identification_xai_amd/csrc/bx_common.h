@@ -88,6 +88,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Cooperative LDS fill: dst[i] = load(i) for i < n.  U loads per thread are issued before the first LDS store, so a fill
+// costs ceil(n / (U * blockDim)) memory round trips instead of one per element (a plain `for (i...) dst[i] = src[..]`
+// loop is compiled into load -> wait -> store per trip).
+template <int U, typename LoadF>
+__device__ __forceinline__ void lds_fill(float* dst, int n, LoadF load) {
+  const int step = (int)blockDim.x;
+  for (int i0 = (int)threadIdx.x; i0 < n; i0 += step * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int i = i0 + u * step; v[u] = i < n ? load(i) : 0.f; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int i = i0 + u * step; if (i < n) dst[i] = v[u]; }
+  }
+}
+
 // PyTorch's area_pixel_compute_source_index for bilinear, align_corners=False.
 __device__ __forceinline__ void bilinear_src(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
   float s = scale * ((float)o + 0.5f) - 0.5f;

@@ -95,11 +95,11 @@ __global__ __launch_bounds__(EEG_TT) void k_eeg_conv1(const float* __restrict__ 
   const int row = blockIdx.x;
   const int b = row / g.Ch, ch = row % g.Ch;
   const float* xr = x + (size_t)row * g.T;
-  for (int i = threadIdx.x; i < g.T + g.K1 + 3; i += EEG_TT) {
-    const int t = i - g.padl1;
-    sx[i] = (t >= 0 && t < g.T) ? xr[t] : 0.f;
+  {
+    const int Tn = g.T, pl = g.padl1, K1 = g.K1;
+    lds_fill<8>(sx, Tn + K1 + 3, [&](int i) { const int t = i - pl; return (t >= 0 && t < Tn) ? xr[t] : 0.f; });
+    lds_fill<2>(swt, 8 * K1, [&](int j) { return w1[(j & 7) * K1 + (j >> 3)]; });          // [k][8 filters]
   }
-  for (int i = threadIdx.x; i < 8 * g.K1; i += EEG_TT) swt[(i % g.K1) * 8 + i / g.K1] = w1[i];
   __syncthreads();
   float s[8], q[8];
 #pragma unroll
@@ -227,14 +227,11 @@ __global__ __launch_bounds__(256) void k_eeg_sep(const float* __restrict__ p1, c
   __shared__ __attribute__((aligned(16))) float sp[16 * TP];        // index j <-> t = t0 + j - padl2 (zero outside [0, T1))
   __shared__ __attribute__((aligned(16))) float sw[16 * 16 * 16];   // [fd][k][o]
   const int b = blockIdx.y, t0 = blockIdx.x * SEP_TT;
-  for (int i = threadIdx.x; i < 4096; i += 256) {
-    const int k = i & 15, fd = (i >> 4) & 15, o = i >> 8;
-    sw[(fd * 16 + k) * 16 + o] = ws[i];
-  }
-  for (int i = threadIdx.x; i < 16 * TP; i += 256) {
-    const int fd = i / TP, j = i % TP;
-    const int tt = t0 + j - g.padl2;
-    sp[i] = (tt >= 0 && tt < g.T1) ? p1[((size_t)b * g.FD + fd) * g.T1 + tt] : 0.f;
+  {
+    const int T1 = g.T1, pl = g.padl2;
+    const float* pb = p1 + (size_t)b * g.FD * T1;
+    lds_fill<16>(sw, 4096, [&](int j) { return ws[((j & 15) * 16 + (j >> 8)) * 16 + ((j >> 4) & 15)]; });   // [fd][k][o] <- [o][fd][k]
+    lds_fill<17>(sp, 16 * TP, [&](int i) { const int fd = i / TP, tt = t0 + i % TP - pl; return (tt >= 0 && tt < T1) ? pb[(size_t)fd * T1 + tt] : 0.f; });
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tl = 4 * lane;
@@ -419,13 +416,39 @@ __global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ d
   float* sp1 = sm + 16 * TP;       // [16][TP]  index t + 7
   float* sw = sp1 + 16 * TP;       // [o][fd][k]
   const int b = blockIdx.x, q = blockIdx.y;
-  for (int i = threadIdx.x; i < 16 * TP; i += 256) {
-    const int f = i / TP, j = i % TP;
-    const int ta = j - 8, tb = j - 7;
-    sds[i] = (ta >= 0 && ta < T1) ? ds[((size_t)b * 16 + f) * T1 + ta] : 0.f;
-    sp1[i] = (tb >= 0 && tb < T1) ? p1[((size_t)b * 16 + f) * T1 + tb] : 0.f;
+  {
+    const float* dsb = ds + (size_t)b * 16 * T1;
+    const float* p1b = p1 + (size_t)b * 16 * T1;
+    if ((T1 & 3) == 0) {
+      // zero the halos, then copy the rows as float4s (8 + 8 loads in flight per thread)
+      float4* z = reinterpret_cast<float4*>(sm);
+      for (int i = threadIdx.x; i < 2 * 16 * TP / 4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      __syncthreads();
+      const int n4 = T1 / 4, tot = 16 * n4;
+      for (int i0 = threadIdx.x; i0 < tot; i0 += 256 * 8) {
+        float4 a[8], p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * 256;
+          if (i < tot) { a[u] = reinterpret_cast<const float4*>(dsb)[i]; p[u] = reinterpret_cast<const float4*>(p1b)[i]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * 256;
+          if (i < tot) {
+            const int f = i / n4, c = i % n4;
+            *reinterpret_cast<float4*>(sds + f * TP + 8 + 4 * c) = a[u];
+            float* q = sp1 + f * TP + 7 + 4 * c;
+            q[0] = p[u].x; q[1] = p[u].y; q[2] = p[u].z; q[3] = p[u].w;
+          }
+        }
+      }
+    } else {
+      lds_fill<16>(sds, 16 * TP, [&](int i) { const int f = i / TP, ta = i % TP - 8; return (ta >= 0 && ta < T1) ? dsb[(size_t)f * T1 + ta] : 0.f; });
+      lds_fill<16>(sp1, 16 * TP, [&](int i) { const int f = i / TP, tb = i % TP - 7; return (tb >= 0 && tb < T1) ? p1b[(size_t)f * T1 + tb] : 0.f; });
+    }
+    lds_fill<16>(sw, 4096, [&](int i) { return ws[i]; });
   }
-  for (int i = threadIdx.x; i < 4096; i += 256) sw[i] = ws[i];
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // (a)
@@ -601,7 +624,10 @@ __global__ __launch_bounds__(256) void k_eeg_conv1_bwd(const T* __restrict__ c1,
   float* comb = sxr + TX;          // [256][4]
   const int row = blockIdx.x, b = row / g.Ch, ch = row % g.Ch;
   for (int i = threadIdx.x; i < 4 * TX; i += 256) sdc[i] = 0.f;
-  for (int i = threadIdx.x; i < TX; i += 256) { const int t = i - EEG_MAXK; sxr[i] = (t >= 0 && t < Tn) ? x[(size_t)row * Tn + t] : 0.f; }
+  {
+    const float* xrow = x + (size_t)row * Tn;
+    lds_fill<8>(sxr, TX, [&](int i) { const int t = i - EEG_MAXK; return (t >= 0 && t < Tn) ? xrow[t] : 0.f; });
+  }
   float dxa[EEG_DX_MAX];
 #pragma unroll
   for (int k = 0; k < EEG_DX_MAX; ++k) dxa[k] = 0.f;
@@ -617,11 +643,22 @@ __global__ __launch_bounds__(256) void k_eeg_conv1_bwd(const T* __restrict__ c1,
       const float* d0 = dd + ((size_t)b * g.FD + f * 2) * Tn;
       const float* d1 = d0 + Tn;
       const size_t cb = (((size_t)b * g.F1 + f) * g.Ch + ch) * Tn;
-#pragma unroll 4
-      for (int t = threadIdx.x; t < Tn; t += 256) {
-        const float dbn = fmaf(w1d, d1[t], w0 * d0[t]);
-        const float xh = (ldf(c1, cb + t) - mu) * is;
-        sdc[f4 * TX + t + EEG_MAXK] = ca * (dbn - k1 - xh * k2);
+      for (int tb = threadIdx.x; tb < Tn; tb += 256 * 8) {       // 24 loads in flight per thread
+        float va[8], vb[8], vc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = tb + u * 256;
+          if (t < Tn) { va[u] = d0[t]; vb[u] = d1[t]; vc[u] = ldf(c1, cb + t); }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = tb + u * 256;
+          if (t < Tn) {
+            const float dbn = fmaf(w1d, vb[u], w0 * va[u]);
+            const float xh = (vc[u] - mu) * is;
+            sdc[f4 * TX + t + EEG_MAXK] = ca * (dbn - k1 - xh * k2);
+          }
+        }
       }
     }
     __syncthreads();

@@ -27,6 +27,11 @@ static int make_geom(const bxTailDesc* d, TailGeom* g) {
   g->sy = (float)d->H / (float)g->Ho; g->sx = (float)d->W / (float)g->Wo;
   return 0;
 }
+// kernels without per-workgroup partials take one pixel group per workgroup (no serial grid-stride trips)
+static int tail_blocks_all(const TailGeom& g) {
+  long long nb = (g.npool + g.slots - 1) / g.slots;
+  return (int)(nb > 65535 ? 65535 : nb);
+}
 static int tail_blocks(const TailGeom& g) {
   long long nb = (g.npool + g.slots - 1) / g.slots;
   return (int)(nb > TAIL_MAX_BLOCKS ? TAIL_MAX_BLOCKS : nb);
@@ -57,31 +62,46 @@ __global__ __launch_bounds__(256) void k_pool_stats(const T* __restrict__ y3, T*
                                                      float* __restrict__ wT) {
   __shared__ float lds[2048];
   if (blockIdx.x == 0)                                  // wT[ci][c] = W1x1[c][ci] (zero rows for padded inputs): read by k_tail_apply
-    for (int i = threadIdx.x; i < g.Cin_p * g.C; i += 256) {
-      const int ci = i / g.C, c = i % g.C;
-      wT[i] = ci < Cin ? w1x1[(size_t)c * Cin + ci] : 0.f;
-    }
+    lds_fill<8>(wT, g.Cin_p * g.C, [&](int i) { const int ci = i / g.C, c = i % g.C; return ci < Cin ? w1x1[(size_t)c * Cin + ci] : 0.f; });
   const int cg = threadIdx.x % g.ncg, slot = threadIdx.x / g.ncg;
   float acc[2][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.f;
-  for (long long pp = (long long)blockIdx.x * g.slots + slot; pp < g.npool; pp += (long long)gridDim.x * g.slots) {
-    const int ox = (int)(pp % g.Wo);
-    const long long r = pp / g.Wo;
-    const int oy = (int)(r % g.Ho), b = (int)(r / g.Ho);
-    const size_t base = (((size_t)b * g.H + 2 * oy) * g.W + 2 * ox) * g.C + cg * 8;
-    float a[8], bq[8], c[8], dq[8], v[8];
-    ld8(y3, base, a); ld8(y3, base + g.C, bq);
-    ld8(y3, base + (size_t)g.W * g.C, c); ld8(y3, base + (size_t)g.W * g.C + g.C, dq);
+  // two pooled pixels per trip: all eight window loads are issued before the first use (the trips of a grid-stride
+  // loop are otherwise serial memory round trips)
+  const long long stride = (long long)gridDim.x * g.slots;
+  for (long long pp0 = (long long)blockIdx.x * g.slots + slot; pp0 < g.npool; pp0 += 2 * stride) {
+    float w[2][4][8];
+    bool ok[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      v[j] = pool == BX_POOL_MAX ? fmaxf(fmaxf(a[j], bq[j]), fmaxf(c[j], dq[j])) : 0.25f * (a[j] + bq[j] + c[j] + dq[j]);
-    st8(pooled, (size_t)pp * g.C + cg * 8, v);
-    if (want_stats) {
+    for (int h = 0; h < 2; ++h) {
+      const long long pp = pp0 + h * stride;
+      ok[h] = pp < g.npool;
+      if (ok[h]) {
+        const int ox = (int)(pp % g.Wo);
+        const long long r = pp / g.Wo;
+        const int oy = (int)(r % g.Ho), b = (int)(r / g.Ho);
+        const size_t base = (((size_t)b * g.H + 2 * oy) * g.W + 2 * ox) * g.C + cg * 8;
+        ld8(y3, base, w[h][0]); ld8(y3, base + g.C, w[h][1]);
+        ld8(y3, base + (size_t)g.W * g.C, w[h][2]); ld8(y3, base + (size_t)g.W * g.C + g.C, w[h][3]);
+      }
+    }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {          // statistics of the values as stored (bf16-rounded if bf16)
-        const float q = round_as(pooled, v[j]);
-        acc[0][j] += q; acc[1][j] += q * q;
+    for (int h = 0; h < 2; ++h) {
+      if (!ok[h]) continue;
+      const long long pp = pp0 + h * stride;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[j] = pool == BX_POOL_MAX ? fmaxf(fmaxf(w[h][0][j], w[h][1][j]), fmaxf(w[h][2][j], w[h][3][j]))
+                                   : 0.25f * (w[h][0][j] + w[h][1][j] + w[h][2][j] + w[h][3][j]);
+      st8(pooled, (size_t)pp * g.C + cg * 8, v);
+      if (want_stats) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {          // statistics of the values as stored (bf16-rounded if bf16)
+          const float q = round_as(pooled, v[j]);
+          acc[0][j] += q; acc[1][j] += q * q;
+        }
       }
     }
   }
@@ -149,12 +169,20 @@ __global__ __launch_bounds__(256) void k_tail_apply(const T* __restrict__ pooled
       if (dropout_p > 0.f) v *= bx_dropout_scale(sd, salt, (uint64_t)pp * g.C + cg * 8 + j, dropout_p, inv_keep);
       acc[j] = v + bb[j];
     }
-    for (int ci = 0; ci < Cin; ++ci) {
-      const float xv = xs[slot * xstride + ci];
-      const float4 wa = *reinterpret_cast<const float4*>(wT + (size_t)ci * g.C + cg * 8);
-      const float4 wb = *reinterpret_cast<const float4*>(wT + (size_t)ci * g.C + cg * 8 + 4);
-      acc[0] = fmaf(wa.x, xv, acc[0]); acc[1] = fmaf(wa.y, xv, acc[1]); acc[2] = fmaf(wa.z, xv, acc[2]); acc[3] = fmaf(wa.w, xv, acc[3]);
-      acc[4] = fmaf(wb.x, xv, acc[4]); acc[5] = fmaf(wb.y, xv, acc[5]); acc[6] = fmaf(wb.z, xv, acc[6]); acc[7] = fmaf(wb.w, xv, acc[7]);
+    // wT has Cin_p rows (zero beyond Cin) and Cin_p % 8 == 0: eight rows (16 loads) in flight per trip
+    for (int c0 = 0; c0 < g.Cin_p; c0 += 8) {
+      float4 wa[8], wb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        wa[u] = *reinterpret_cast<const float4*>(wT + (size_t)(c0 + u) * g.C + cg * 8);
+        wb[u] = *reinterpret_cast<const float4*>(wT + (size_t)(c0 + u) * g.C + cg * 8 + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float xv = xs[slot * xstride + c0 + u];
+        acc[0] = fmaf(wa[u].x, xv, acc[0]); acc[1] = fmaf(wa[u].y, xv, acc[1]); acc[2] = fmaf(wa[u].z, xv, acc[2]); acc[3] = fmaf(wa[u].w, xv, acc[3]);
+        acc[4] = fmaf(wb[u].x, xv, acc[4]); acc[5] = fmaf(wb[u].y, xv, acc[5]); acc[6] = fmaf(wb[u].z, xv, acc[6]); acc[7] = fmaf(wb[u].w, xv, acc[7]);
+      }
     }
     st8(out, (size_t)pp * g.C + cg * 8, acc);
   }
@@ -204,7 +232,7 @@ extern "C" int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void
                      running_mean, running_var, num_batches_tracked, d->momentum, d->eps, scale, shift, save_mean, save_invstd);
   BX_CHECK_LAUNCH("bx_block_tail_fwd(finalize)");
   BX_DISPATCH_DTYPE(d->dtype, T,
-    hipLaunchKernelGGL((k_tail_apply<T>), dim3(nblk), dim3(256), xs_bytes, s, (const T*)pooled, (const T*)x, wT, Cin, b1x1,
+    hipLaunchKernelGGL((k_tail_apply<T>), dim3(tail_blocks_all(g)), dim3(256), xs_bytes, s, (const T*)pooled, (const T*)x, wT, Cin, b1x1,
                        scale, shift, seed, p, d->salt, (T*)out, g));
   BX_CHECK_LAUNCH("bx_block_tail_fwd(apply)");
   return BX_OK;
@@ -224,17 +252,28 @@ __global__ __launch_bounds__(256) void k_tail_bwd_reduce(const T* __restrict__ d
   float mu[8], is[8], acc[3][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { mu[j] = mean[cg * 8 + j]; is[j] = invstd[cg * 8 + j]; acc[0][j] = acc[1][j] = acc[2][j] = 0.f; }
-  for (long long pp = (long long)blockIdx.x * g.slots + slot; pp < g.npool; pp += (long long)gridDim.x * g.slots) {
-    float go[8], pv[8];
-    ld8(dout, (size_t)pp * g.C + cg * 8, go);
-    ld8(pooled, (size_t)pp * g.C + cg * 8, pv);
+  const long long stride = (long long)gridDim.x * g.slots;
+  for (long long pp0 = (long long)blockIdx.x * g.slots + slot; pp0 < g.npool; pp0 += 2 * stride) {   // two pixels per trip
+    float go[2][8], pv[2][8];
+    bool ok[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float dd = go[j];
-      if (dropout_p > 0.f) dd *= bx_dropout_scale(sd, salt, (uint64_t)pp * g.C + cg * 8 + j, dropout_p, inv_keep);
-      acc[0][j] += dd;
-      acc[1][j] += dd * (pv[j] - mu[j]) * is[j];
-      acc[2][j] += go[j];
+    for (int h = 0; h < 2; ++h) {
+      const long long pp = pp0 + h * stride;
+      ok[h] = pp < g.npool;
+      if (ok[h]) { ld8(dout, (size_t)pp * g.C + cg * 8, go[h]); ld8(pooled, (size_t)pp * g.C + cg * 8, pv[h]); }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (!ok[h]) continue;
+      const long long pp = pp0 + h * stride;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float dd = go[h][j];
+        if (dropout_p > 0.f) dd *= bx_dropout_scale(sd, salt, (uint64_t)pp * g.C + cg * 8 + j, dropout_p, inv_keep);
+        acc[0][j] += dd;
+        acc[1][j] += dd * (pv[h][j] - mu[j]) * is[j];
+        acc[2][j] += go[h][j];
+      }
     }
   }
   float red[3];
@@ -321,7 +360,7 @@ __global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ do
 template <typename T>
 __global__ __launch_bounds__(256) void k_skip_dxs(const T* __restrict__ dout, const float* __restrict__ w1x1, int Cin,
                                                    float* __restrict__ dxs, T* __restrict__ dx_even, TailGeom g) {
-  extern __shared__ float swt[];   // [64][Cin_p]
+  extern __shared__ __attribute__((aligned(16))) float swt[];   // [64][Cin_p]
   const int nci8 = g.Cin_p / 8;
   const long long n = g.npool * nci8;
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -332,9 +371,21 @@ __global__ __launch_bounds__(256) void k_skip_dxs(const T* __restrict__ dout, co
   for (int cb = 0; cb < g.C; cb += 64) {
     const int nc = g.C - cb < 64 ? g.C - cb : 64;
     __syncthreads();
-    for (int i = threadIdx.x; i < nc * g.Cin_p; i += 256) {
-      const int c = i / g.Cin_p, ci = i % g.Cin_p;
-      swt[i] = ci < Cin ? w1x1[(size_t)(cb + c) * Cin + ci] : 0.f;
+    if (Cin == g.Cin_p) {
+      // contiguous slab: 16-byte copies, 8 in flight per thread
+      const float4* src = reinterpret_cast<const float4*>(w1x1 + (size_t)cb * Cin);
+      float4* dst = reinterpret_cast<float4*>(swt);
+      const int n4 = nc * g.Cin_p / 4;
+      for (int i0 = threadIdx.x; i0 < n4; i0 += 256 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; if (i < n4) v[u] = src[i]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; if (i < n4) dst[i] = v[u]; }
+      }
+    } else {
+      const int cinp = g.Cin_p;
+      lds_fill<8>(swt, nc * cinp, [&](int i) { const int c = i / cinp, ci = i % cinp; return ci < Cin ? w1x1[(size_t)(cb + c) * Cin + ci] : 0.f; });
     }
     __syncthreads();
     if (live)
@@ -485,7 +536,7 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
                      save_invstd, coef, d_bn_weight, d_bn_bias, d_b1x1);
   BX_CHECK_LAUNCH("bx_block_tail_bwd(finalize)");
   BX_DISPATCH_DTYPE(d->dtype, T,
-    hipLaunchKernelGGL((k_tail_bwd_apply<T>), dim3(nblk), dim3(256), 0, s, (const T*)dout, (const T*)pooled, (const T*)y3, save_mean,
+    hipLaunchKernelGGL((k_tail_bwd_apply<T>), dim3(tail_blocks_all(g)), dim3(256), 0, s, (const T*)dout, (const T*)pooled, (const T*)y3, save_mean,
                        save_invstd, coef, seed, p, d->salt, d->pool, (T*)dz3, g));
   BX_CHECK_LAUNCH("bx_block_tail_bwd(apply)");
   if (d_w1x1) {
