@@ -63,26 +63,48 @@ void bx_conv3x3_mfma_pack_launch(const float* w_oihw, void* packed, int Cout, in
 // Many pack jobs in ONE launch (all 3x3 convolutions of the model, forward and data-gradient operands): the job
 // table lives in device memory and is built once by the host (parameter pointers are stable under FlatAdamW).
 __global__ __launch_bounds__(256) void k_pack_mfma_many(const bxPackJob* __restrict__ jobs, int njobs) {
-  int j = 0;
-  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block_begin) ++j;
+  // job lookup in one memory round trip: lanes compare their job's first block with this block, ballot counts them
+  __shared__ int sj;
+  if (threadIdx.x < 64) {
+    int cnt = 0;
+    for (int j0 = 0; j0 < njobs; j0 += 64) {
+      const int j = j0 + (int)threadIdx.x;
+      const bool le = j < njobs && jobs[j].block_begin <= (int)blockIdx.x;
+      cnt += __popcll(__ballot(le));
+    }
+    if (threadIdx.x == 0) sj = cnt - 1;
+  }
+  __syncthreads();
+  const int j = sj;
   const bxPackJob jb = jobs[j];
   const int ck = jb.I_p < 64 ? jb.I_p : 64, ks = (9 * ck + 31) / 32;
   const size_t n = (size_t)(jb.I_p / ck) * ks * jb.O_p * 32;
   const float* __restrict__ w = (const float*)jb.w_oihw;
   bf16_t* __restrict__ wp = (bf16_t*)jb.packed_mfma;
   const int nblk = (j + 1 < njobs ? jobs[j + 1].block_begin : (int)gridDim.x) - jb.block_begin;
-  for (size_t idx = (size_t)(blockIdx.x - jb.block_begin) * 256 + threadIdx.x; idx < n; idx += (size_t)nblk * 256) {
-    const int kk = (int)(idx & 31);
-    const int o = (int)((idx >> 5) % jb.O_p);
-    const int s = (int)((idx / ((size_t)32 * jb.O_p)) % ks);
-    const int chunk = (int)(idx / ((size_t)32 * jb.O_p * ks));
-    const int q = s * 32 + kk, tap = q / ck, i = chunk * ck + q % ck;
-    float v = 0.f;
-    if (tap < 9) {
-      if (!jb.transpose_flip) { if (i < jb.Cin && o < jb.Cout) v = w[((size_t)o * jb.Cin + i) * 9 + tap]; }
-      else                    { if (i < jb.Cout && o < jb.Cin) v = w[((size_t)i * jb.Cin + o) * 9 + (8 - tap)]; }
+  for (size_t i0 = (size_t)(blockIdx.x - jb.block_begin) * 2048 + threadIdx.x; i0 < n; i0 += (size_t)nblk * 2048) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {                 // eight gathers in flight
+      const size_t idx = i0 + u * 256;
+      v[u] = 0.f;
+      if (idx < n) {
+        const int kk = (int)(idx & 31);
+        const int o = (int)((idx >> 5) % jb.O_p);
+        const int s = (int)((idx / ((size_t)32 * jb.O_p)) % ks);
+        const int chunk = (int)(idx / ((size_t)32 * jb.O_p * ks));
+        const int q = s * 32 + kk, tap = q / ck, i = chunk * ck + q % ck;
+        if (tap < 9) {
+          if (!jb.transpose_flip) { if (i < jb.Cin && o < jb.Cout) v[u] = w[((size_t)o * jb.Cin + i) * 9 + tap]; }
+          else                    { if (i < jb.Cout && o < jb.Cin) v[u] = w[((size_t)i * jb.Cin + o) * 9 + (8 - tap)]; }
+        }
+      }
     }
-    wp[idx] = f2bf(v);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t idx = i0 + u * 256;
+      if (idx < n) wp[idx] = f2bf(v[u]);
+    }
   }
 }
 extern "C" int bx_conv3x3_pack_many(const bxPackJob* jobs_device, int njobs, int total_blocks, bxStream stream) {

@@ -643,22 +643,11 @@ __global__ __launch_bounds__(256) void k_eeg_conv1_bwd(const T* __restrict__ c1,
       const float* d0 = dd + ((size_t)b * g.FD + f * 2) * Tn;
       const float* d1 = d0 + Tn;
       const size_t cb = (((size_t)b * g.F1 + f) * g.Ch + ch) * Tn;
-      for (int tb = threadIdx.x; tb < Tn; tb += 256 * 8) {       // 24 loads in flight per thread
-        float va[8], vb[8], vc[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int t = tb + u * 256;
-          if (t < Tn) { va[u] = d0[t]; vb[u] = d1[t]; vc[u] = ldf(c1, cb + t); }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int t = tb + u * 256;
-          if (t < Tn) {
-            const float dbn = fmaf(w1d, vb[u], w0 * va[u]);
-            const float xh = (vc[u] - mu) * is;
-            sdc[f4 * TX + t + EEG_MAXK] = ca * (dbn - k1 - xh * k2);
-          }
-        }
+#pragma unroll 4
+      for (int t = threadIdx.x; t < Tn; t += 256) {
+        const float dbn = fmaf(w1d, d1[t], w0 * d0[t]);
+        const float xh = (ldf(c1, cb + t) - mu) * is;
+        sdc[f4 * TX + t + EEG_MAXK] = ca * (dbn - k1 - xh * k2);
       }
     }
     __syncthreads();

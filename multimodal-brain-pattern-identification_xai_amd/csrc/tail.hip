@@ -61,8 +61,12 @@ __global__ __launch_bounds__(256) void k_pool_stats(const T* __restrict__ y3, T*
                                                      TailGeom g, int pool, int want_stats, const float* __restrict__ w1x1, int Cin,
                                                      float* __restrict__ wT) {
   __shared__ float lds[2048];
-  if (blockIdx.x == 0)                                  // wT[ci][c] = W1x1[c][ci] (zero rows for padded inputs): read by k_tail_apply
-    lds_fill<8>(wT, g.Cin_p * g.C, [&](int i) { const int ci = i / g.C, c = i % g.C; return ci < Cin ? w1x1[(size_t)c * Cin + ci] : 0.f; });
+  {                                                     // wT[ci][c] = W1x1[c][ci] (zero rows for padded inputs): read by k_tail_apply
+    const int nw = g.Cin_p * g.C, per = (nw + (int)gridDim.x - 1) / (int)gridDim.x;     // each workgroup transposes a slice
+    const int lo = (int)blockIdx.x * per, cnt = nw - lo < per ? nw - lo : per;
+    if (cnt > 0)
+      lds_fill<4>(wT + lo, cnt, [&](int k) { const int i = lo + k, ci = i / g.C, c = i % g.C; return ci < Cin ? w1x1[(size_t)c * Cin + ci] : 0.f; });
+  }
   const int cg = threadIdx.x % g.ncg, slot = threadIdx.x / g.ncg;
   float acc[2][8];
 #pragma unroll
@@ -195,7 +199,7 @@ extern "C" size_t bx_block_tail_workspace(const bxTailDesc* d) {
   size_t fwd = ((size_t)TAIL_MAX_BLOCKS * 2 + 2) * d->C * sizeof(float) + (size_t)d->Cin_p * d->C * sizeof(float);
   size_t bwd = ((size_t)TAIL_MAX_BLOCKS * 3 + 3) * d->C * sizeof(float)                 // partials + coefficients
              + bx_align_up((size_t)d->B * Ho * Wo * d->Cin_p * sizeof(float), 256)       // dXs (half-res, fp32)
-             + (size_t)1024 * 256 * sizeof(float) + (size_t)65 * d->C * d->Cin_p * sizeof(float);   // conv1x1 weight-grad partials (+1 slab for compaction)
+             + (size_t)2048 * 256 * sizeof(float) + (size_t)65 * d->C * d->Cin_p * sizeof(float);   // conv1x1 weight-grad partials (+1 slab for compaction)
   return bx_align_up(fwd > bwd ? fwd : bwd, 256);
 }
 
@@ -370,6 +374,10 @@ __global__ __launch_bounds__(256) void k_skip_dxs(const T* __restrict__ dout, co
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int cb = 0; cb < g.C; cb += 64) {
     const int nc = g.C - cb < 64 ? g.C - cb : 64;
+    float go[8][8];                                       // this pixel's dOut over the slab: all loads issued up front
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (live && q * 8 < nc) ld8(dout, (size_t)pp * g.C + cb + q * 8, go[q]);
     __syncthreads();
     if (Cin == g.Cin_p) {
       // contiguous slab: 16-byte copies, 8 in flight per thread
@@ -388,18 +396,20 @@ __global__ __launch_bounds__(256) void k_skip_dxs(const T* __restrict__ dout, co
       lds_fill<8>(swt, nc * cinp, [&](int i) { const int c = i / cinp, ci = i % cinp; return ci < Cin ? w1x1[(size_t)(cb + c) * Cin + ci] : 0.f; });
     }
     __syncthreads();
-    if (live)
-      for (int c0 = 0; c0 < nc; c0 += 8) {
-        float go[8];
-        ld8(dout, (size_t)pp * g.C + cb + c0, go);
+    if (live) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (q * 8 >= nc) break;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const float4 wa = *reinterpret_cast<const float4*>(swt + (c0 + k) * g.Cin_p + c8 * 8);
-          const float4 wb = *reinterpret_cast<const float4*>(swt + (c0 + k) * g.Cin_p + c8 * 8 + 4);
-          acc[0] = fmaf(wa.x, go[k], acc[0]); acc[1] = fmaf(wa.y, go[k], acc[1]); acc[2] = fmaf(wa.z, go[k], acc[2]); acc[3] = fmaf(wa.w, go[k], acc[3]);
-          acc[4] = fmaf(wb.x, go[k], acc[4]); acc[5] = fmaf(wb.y, go[k], acc[5]); acc[6] = fmaf(wb.z, go[k], acc[6]); acc[7] = fmaf(wb.w, go[k], acc[7]);
+          const float gv = go[q][k];
+          const float4 wa = *reinterpret_cast<const float4*>(swt + (q * 8 + k) * g.Cin_p + c8 * 8);
+          const float4 wb = *reinterpret_cast<const float4*>(swt + (q * 8 + k) * g.Cin_p + c8 * 8 + 4);
+          acc[0] = fmaf(wa.x, gv, acc[0]); acc[1] = fmaf(wa.y, gv, acc[1]); acc[2] = fmaf(wa.z, gv, acc[2]); acc[3] = fmaf(wa.w, gv, acc[3]);
+          acc[4] = fmaf(wb.x, gv, acc[4]); acc[5] = fmaf(wb.y, gv, acc[5]); acc[6] = fmaf(wb.z, gv, acc[6]); acc[7] = fmaf(wb.w, gv, acc[7]);
         }
       }
+    }
   }
   if (live) {
     if (dx_even) {
@@ -471,30 +481,35 @@ __global__ __launch_bounds__(256) void k_w1x1_grad(const T* __restrict__ dout, c
   const long long p_begin = (long long)blockIdx.x * pix_per_chunk;
   long long p_end = p_begin + pix_per_chunk;
   if (p_end > g.npool) p_end = g.npool;
-  for (long long p0 = p_begin; p0 < p_end; p0 += 64) {
-    __syncthreads();
-    if (threadIdx.x < 128) {            // 64 pixels x 2 halves of dOut
-      const int px = threadIdx.x >> 1, half = threadIdx.x & 1;
-      const long long pp = p0 + px;
-      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (pp < p_end) ld8(dout, (size_t)pp * g.C + c0 + half * 8, v);
+  // threads 0..127 stage 64 pixels x 2 halves of dOut, threads 128..255 the bilinear-sampled input; the next trip's
+  // values are fetched into registers while the current trip is multiplied
+  const int st = threadIdx.x & 127, px = st >> 1, half = st & 1;
+  const bool is_d = threadIdx.x < 128;
+  float v[8];
+  auto fetch = [&](long long p0) {
+    const long long pp = p0 + px;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sd[px][half * 8 + j] = v[j];
-    } else {                            // 64 pixels x 2 halves of the bilinear-sampled input
-      const int t = threadIdx.x - 128, px = t >> 1, half = t & 1;
-      const long long pp = p0 + px;
-      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (pp < p_end && ci0 + half * 8 < g.Cin_p) {
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (pp < p_end) {
+      if (is_d) {
+        ld8(dout, (size_t)pp * g.C + c0 + half * 8, v);
+      } else if (ci0 + half * 8 < g.Cin_p) {
         const int ox = (int)(pp % g.Wo);
         const long long r = pp / g.Wo;
         skip_sample(x, g, (int)(r / g.Ho), (int)(r % g.Ho), ox, ci0 + half * 8, v);
       }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) sxs[px][half * 8 + j] = v[j];
     }
+  };
+  if (p_begin < p_end) fetch(p_begin);
+  for (long long p0 = p_begin; p0 < p_end; p0 += 64) {
     __syncthreads();
+    float* dst = is_d ? &sd[px][half * 8] : &sxs[px][half * 8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j] = v[j];
+    __syncthreads();
+    if (p0 + 64 < p_end) fetch(p0 + 64);
 #pragma unroll 8
-    for (int px = 0; px < 64; ++px) acc = fmaf(sd[px][c], sxs[px][ci], acc);
+    for (int q = 0; q < 64; ++q) acc = fmaf(sd[q][c], sxs[q][ci], acc);
   }
   if (ci0 + ci < g.Cin_p) partial[((size_t)blockIdx.x * g.C + c0 + c) * g.Cin_p + ci0 + ci] = acc;
 }
@@ -540,12 +555,12 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
                        save_invstd, coef, seed, p, d->salt, d->pool, (T*)dz3, g));
   BX_CHECK_LAUNCH("bx_block_tail_bwd(apply)");
   if (d_w1x1) {
-    // ~1024 workgroups in total; partial buffer = nchunk * C * Cin_p floats <= 1024*256 + 64*C*Cin_p (workspace formula)
+    // up to ~4096 workgroups in total; partial buffer = nchunk * C * Cin_p floats <= 2048*256 + 64*C*Cin_p (workspace formula)
     const int otiles = (g.C / 16) * ((g.Cin_p + 15) / 16);
     int nchunk = (int)((g.npool + 63) / 64);
-    int cap = 1024 / otiles;
+    int cap = 4096 / otiles;
     if (cap < 64) cap = 64;
-    while ((size_t)cap * g.C * g.Cin_p > (size_t)1024 * 256 + (size_t)64 * g.C * g.Cin_p) cap /= 2;
+    while ((size_t)cap * g.C * g.Cin_p > (size_t)2048 * 256 + (size_t)64 * g.C * g.Cin_p) cap /= 2;
     if (nchunk > cap) nchunk = cap;
     int ppc = (int)((g.npool + nchunk - 1) / nchunk);
     ppc = (ppc + 63) / 64 * 64;

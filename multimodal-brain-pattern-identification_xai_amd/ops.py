@@ -245,7 +245,7 @@ class PackPlan:
             view = self.buf.narrow(0, o, nb)
             self.views[(i, flip)] = (None, view, ip, op)
             jobs[j] = L.PackJob(w.data_ptr(), view.data_ptr(), co, ci, ip, op, 1 if flip else 0, blk)
-            blk += max(1, min(64, (nb // 2 + 1023) // 1024))
+            blk += max(1, (nb // 2 + 2047) // 2048)            # 2048 packed elements (8 per thread) per workgroup
         self.njobs, self.nblocks = len(entries), blk
         raw = bytes(memoryview(jobs)) if entries else b"\0" * 8
         self.jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
