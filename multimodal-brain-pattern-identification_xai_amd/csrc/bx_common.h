@@ -51,6 +51,16 @@ __device__ __forceinline__ void ld8(const bf16_t* p, size_t i, float v[8]) {
     v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
   }
 }
+// 4-element vector load (p + i must be 4-element aligned)
+__device__ __forceinline__ void ld4(const float* p, size_t i, float v[4]) {
+  const float4 a = *reinterpret_cast<const float4*>(p + i);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+__device__ __forceinline__ void ld4(const bf16_t* p, size_t i, float v[4]) {
+  const uint2 r = *reinterpret_cast<const uint2*>(p + i);
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
 __device__ __forceinline__ void st8(float* p, size_t i, const float v[8]) {
   *reinterpret_cast<float4*>(p + i) = make_float4(v[0], v[1], v[2], v[3]);
   *reinterpret_cast<float4*>(p + i + 4) = make_float4(v[4], v[5], v[6], v[7]);

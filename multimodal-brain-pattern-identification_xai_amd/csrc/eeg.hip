@@ -635,19 +635,69 @@ __global__ __launch_bounds__(256) void k_eeg_conv1_bwd(const T* __restrict__ c1,
   const int ff = tid >> 4, k0 = (tid & 15) * 4;
   for (int fg = 0; fg < 2; ++fg) {
     __syncthreads();
+    if ((Tn & 3) == 0) {
+      // all four filters of the group per trip, four consecutive time steps per thread: 24 vector loads in flight, so the
+      // group's rebuild is one memory round trip (a per-filter scalar loop exposes one per trip)
+      float w0[4], w1d[4], mu[4], is[4], ca[4], k1[4], k2[4];
 #pragma unroll
-    for (int f4 = 0; f4 < 4; ++f4) {
-      const int f = fg * 4 + f4;
-      const float w0 = dw[(f * 2) * g.Ch + ch], w1d = dw[(f * 2 + 1) * g.Ch + ch];      // D == 2 (eeg_geom enforces it)
-      const float mu = mean1[f], is = inv1[f], ca = coef[f], k1 = coef[EEG_MAXF + f], k2 = coef[2 * EEG_MAXF + f];
-      const float* d0 = dd + ((size_t)b * g.FD + f * 2) * Tn;
-      const float* d1 = d0 + Tn;
-      const size_t cb = (((size_t)b * g.F1 + f) * g.Ch + ch) * Tn;
+      for (int f4 = 0; f4 < 4; ++f4) {
+        const int f = fg * 4 + f4;
+        w0[f4] = dw[(f * 2) * g.Ch + ch]; w1d[f4] = dw[(f * 2 + 1) * g.Ch + ch];      // D == 2 (eeg_geom enforces it)
+        mu[f4] = mean1[f]; is[f4] = inv1[f]; ca[f4] = coef[f]; k1[f4] = coef[EEG_MAXF + f]; k2[f4] = coef[2 * EEG_MAXF + f];
+      }
+      const int nq = Tn / 4;
+      for (int q0 = threadIdx.x; q0 < nq; q0 += 512) {
+        float4 a0[2][4], a1[2][4];
+        float cv[2][4][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int q = q0 + u * 256;
+          if (q < nq) {
+#pragma unroll
+            for (int f4 = 0; f4 < 4; ++f4) {
+              const int f = fg * 4 + f4;
+              const float* d0 = dd + ((size_t)b * g.FD + f * 2) * Tn;
+              a0[u][f4] = reinterpret_cast<const float4*>(d0)[q];
+              a1[u][f4] = reinterpret_cast<const float4*>(d0 + Tn)[q];
+              ld4(c1, (((size_t)b * g.F1 + f) * g.Ch + ch) * Tn + 4 * (size_t)q, cv[u][f4]);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int q = q0 + u * 256;
+          if (q < nq) {
+#pragma unroll
+            for (int f4 = 0; f4 < 4; ++f4) {
+              const float e0[4] = {a0[u][f4].x, a0[u][f4].y, a0[u][f4].z, a0[u][f4].w};
+              const float e1[4] = {a1[u][f4].x, a1[u][f4].y, a1[u][f4].z, a1[u][f4].w};
+              float o[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float dbn = fmaf(w1d[f4], e1[j], w0[f4] * e0[j]);
+                const float xh = (cv[u][f4][j] - mu[f4]) * is[f4];
+                o[j] = ca[f4] * (dbn - k1[f4] - xh * k2[f4]);
+              }
+              *reinterpret_cast<float4*>(sdc + f4 * TX + EEG_MAXK + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int f4 = 0; f4 < 4; ++f4) {
+        const int f = fg * 4 + f4;
+        const float w0 = dw[(f * 2) * g.Ch + ch], w1d = dw[(f * 2 + 1) * g.Ch + ch];
+        const float mu = mean1[f], is = inv1[f], ca = coef[f], k1 = coef[EEG_MAXF + f], k2 = coef[2 * EEG_MAXF + f];
+        const float* d0 = dd + ((size_t)b * g.FD + f * 2) * Tn;
+        const float* d1 = d0 + Tn;
+        const size_t cb = (((size_t)b * g.F1 + f) * g.Ch + ch) * Tn;
 #pragma unroll 4
-      for (int t = threadIdx.x; t < Tn; t += 256) {
-        const float dbn = fmaf(w1d, d1[t], w0 * d0[t]);
-        const float xh = (ldf(c1, cb + t) - mu) * is;
-        sdc[f4 * TX + t + EEG_MAXK] = ca * (dbn - k1 - xh * k2);
+        for (int t = threadIdx.x; t < Tn; t += 256) {
+          const float dbn = fmaf(w1d, d1[t], w0 * d0[t]);
+          const float xh = (ldf(c1, cb + t) - mu) * is;
+          sdc[f4 * TX + t + EEG_MAXK] = ca * (dbn - k1 - xh * k2);
+        }
       }
     }
     __syncthreads();
