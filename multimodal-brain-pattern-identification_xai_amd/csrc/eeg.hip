@@ -613,6 +613,7 @@ __global__ void k_eeg_dw_bwd_finalize(const float* __restrict__ rpart, int B, Ee
 // 4 consecutive taps x one time quarter, sliding x window: 1 dc1 + 1 x LDS read per 4 FMAs) and, optionally,
 // dx[t] = sum_{f,k} w1[f][k] dc1[f][t-k+padl].
 #define EEG_DX_MAX 16          // dx values a thread can own: T <= 256*16
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <typename T>
 __global__ __launch_bounds__(256) void k_eeg_conv1_bwd(const T* __restrict__ c1, const float* __restrict__ dd, const float* __restrict__ x,
     const float* __restrict__ dw, const float* __restrict__ w1, const float* __restrict__ mean1, const float* __restrict__ inv1,
@@ -716,6 +717,9 @@ __global__ __launch_bounds__(256) void k_eeg_conv1_bwd(const T* __restrict__ c1,
         const float* dc1 = dc0 + TX;
         const float* xr = sxr + EEG_MAXK + kb - g.padl1;         // xr[t + j] = x[t + kb + j - padl]
         float win[12];                                          // x window xr[t .. t+10]
+        f32x2 acc2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc2[j] = (f32x2){0.f, 0.f};
         int t = tb;
 #pragma unroll
         for (int j = 0; j < 8; ++j) win[j] = xr[t + j];
@@ -723,14 +727,20 @@ __global__ __launch_bounds__(256) void k_eeg_conv1_bwd(const T* __restrict__ c1,
           const float4 d0 = *reinterpret_cast<const float4*>(dc0 + t);
           const float4 d1 = *reinterpret_cast<const float4*>(dc1 + t);
           win[8] = xr[t + 8]; win[9] = xr[t + 9]; win[10] = xr[t + 10]; win[11] = xr[t + 11];
-          const float dv0[4] = {d0.x, d0.y, d0.z, d0.w}, dv1[4] = {d1.x, d1.y, d1.z, d1.w};
+          // the two filters of the pair ride in one packed fp32 FMA (v_pk_fma_f32: twice the scalar FMA rate)
+          const f32x2 dv[4] = {{d0.x, d1.x}, {d0.y, d1.y}, {d0.z, d1.z}, {d0.w, d1.w}};
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { acc[0][j] = fmaf(dv0[i], win[i + j], acc[0][j]); acc[1][j] = fmaf(dv1[i], win[i + j], acc[1][j]); }
+            for (int j = 0; j < 8; ++j) {
+              const f32x2 xw = {win[i + j], win[i + j]};
+              acc2[j] = dv[i] * xw + acc2[j];
+            }
 #pragma unroll
           for (int j = 0; j < 8; ++j) win[j] = win[j + 4];
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[0][j] = acc2[j].x; acc[1][j] = acc2[j].y; }
         for (; t < te; ++t) {
           const float v0 = dc0[t], v1 = dc1[t];
 #pragma unroll
