@@ -147,20 +147,37 @@ extern "C" int bx_mul(const float* a, const float* b, float* out, size_t n, bxSt
 // AdamW (decoupled weight decay), torch.optim.AdamW semantics:
 //   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
 //   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
-__global__ void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+__device__ __forceinline__ void adamw_one(float& pi, float gi, float& mi, float& vi, float lr, float b1, float b2, float eps, float wd,
+                                          float gscale, float step_size, float inv_sqrt_bc2) {
+  gi *= gscale;
+  pi *= (1.f - lr * wd);
+  mi = b1 * mi + (1.f - b1) * gi;
+  vi = b2 * vi + (1.f - b2) * gi * gi;
+  pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+}
+// one float4 per thread and one trip per thread (a capped grid-stride loop made every trip a serial HBM round trip);
+// the arenas are 16-byte aligned, the n % 4 tail goes to the first threads of block 0
+__global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                         size_t n, float lr, float b1, float b2, float eps, float wd, float gscale, const float* __restrict__ step) {
   const float t = step[0];
   const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
   const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) {
-    const float gi = g[i] * gscale;
-    float pi = p[i] * (1.f - lr * wd);
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
-    p[i] = pi; m[i] = mi; v[i] = vi;
+  const size_t n4 = n / 4;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) {
+    float4 pv = reinterpret_cast<float4*>(p)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    adamw_one(pv.x, gv.x, mv.x, vv.x, lr, b1, b2, eps, wd, gscale, step_size, inv_sqrt_bc2);
+    adamw_one(pv.y, gv.y, mv.y, vv.y, lr, b1, b2, eps, wd, gscale, step_size, inv_sqrt_bc2);
+    adamw_one(pv.z, gv.z, mv.z, vv.z, lr, b1, b2, eps, wd, gscale, step_size, inv_sqrt_bc2);
+    adamw_one(pv.w, gv.w, mv.w, vv.w, lr, b1, b2, eps, wd, gscale, step_size, inv_sqrt_bc2);
+    reinterpret_cast<float4*>(p)[i] = pv; reinterpret_cast<float4*>(m)[i] = mv; reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t j = n4 * 4 + threadIdx.x;
+    float pj = p[j], mj = m[j], vj = v[j];
+    adamw_one(pj, g[j], mj, vj, lr, b1, b2, eps, wd, gscale, step_size, inv_sqrt_bc2);
+    p[j] = pj; m[j] = mj; v[j] = vj;
   }
 }
 __global__ void k_step_inc(float* t) { t[0] += 1.f; }
@@ -169,7 +186,9 @@ extern "C" int bx_adamw_step(float* p, const float* g, float* m, float* v, size_
   BX_REQUIRE(p && g && m && v && step_count, "bx_adamw_step: null pointer");
   if (n == 0) return BX_OK;
   hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step_count);
-  hipLaunchKernelGGL(k_adamw, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+  BX_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "bx_adamw_step: arenas must be 16-byte aligned");
+  const size_t nblk = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(k_adamw, dim3((unsigned)(nblk ? nblk : 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
                      weight_decay, grad_scale, step_count);
   BX_CHECK_LAUNCH("bx_adamw_step");
   return BX_OK;

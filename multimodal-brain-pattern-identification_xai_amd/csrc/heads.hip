@@ -15,7 +15,15 @@ __global__ __launch_bounds__(256) void k_gap(const T* __restrict__ feat, float* 
   const float inv = 1.f / (float)HW;
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = 0.f;
-    for (int p = 0; p < HW; ++p) s += ldf(feat, ((size_t)b * HW + p) * C + c);
+    int p = 0;
+    for (; p + 8 <= HW; p += 8) {              // eight pixel loads in flight, added in pixel order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ldf(feat, ((size_t)b * HW + p + u) * C + c);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; p < HW; ++p) s += ldf(feat, ((size_t)b * HW + p) * C + c);
     gap[(size_t)b * C + c] = s * inv;
   }
 }
@@ -27,7 +35,15 @@ __global__ __launch_bounds__(256) void k_linear_lsm_fwd(const float* __restrict_
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int n = wave; n < N; n += 4) {
     float s = 0.f;
-    for (int k = lane; k < K; k += 64) s = fmaf(w[(size_t)n * K + k], x[(size_t)b * K + k], s);
+    const float* wr = w + (size_t)n * K;
+    const float* xr = x + (size_t)b * K;
+    int k = lane;
+    for (; k + 192 < K; k += 256) {          // eight loads in flight per trip; the adds keep k order
+      const float w0 = wr[k], w1 = wr[k + 64], w2 = wr[k + 128], w3 = wr[k + 192];
+      const float x0 = xr[k], x1 = xr[k + 64], x2 = xr[k + 128], x3 = xr[k + 192];
+      s = fmaf(w0, x0, s); s = fmaf(w1, x1, s); s = fmaf(w2, x2, s); s = fmaf(w3, x3, s);
+    }
+    for (; k < K; k += 64) s = fmaf(wr[k], xr[k], s);
     s = wave_sum(s);
     if (lane == 0) logit[n] = s + bias[n];
   }
@@ -59,7 +75,7 @@ __global__ __launch_bounds__(256) void k_linear_lsm_bwd_dx(const float* __restri
   const int b = blockIdx.x;
   float dl[HEAD_MAX_N];
   lsm_bwd_row(dlogp + (size_t)b * N, logp + (size_t)b * N, N, dl);
-  for (int k = threadIdx.x; k < K; k += 256) {
+  for (int k = blockIdx.y * 256 + threadIdx.x; k < K; k += 256 * gridDim.y) {
     float s = 0.f;
 #pragma unroll
     for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) s = fmaf(dl[n], w[(size_t)n * K + k], s);
@@ -130,7 +146,7 @@ extern "C" int bx_linear_lsm_bwd(const float* dlogp, const float* logp, const fl
   BX_REQUIRE(((size_t)B * N + 256 * N) * sizeof(float) <= 60 * 1024, "bx_linear_lsm_bwd: batch %d too large for the LDS gradient tile ((B+256)*N <= 15360)", B);
   hipStream_t s = (hipStream_t)stream;
   if (dx) {
-    hipLaunchKernelGGL((k_linear_lsm_bwd_dx<float, false>), dim3(B), dim3(256), 0, s, dlogp, logp, w, dx, (float*)nullptr, K, N, 1);
+    hipLaunchKernelGGL((k_linear_lsm_bwd_dx<float, false>), dim3(B, bx_ceil_div(K, 256)), dim3(256), 0, s, dlogp, logp, w, dx, (float*)nullptr, K, N, 1);
     BX_CHECK_LAUNCH("bx_linear_lsm_bwd(dx)");
   }
   if (dw || db) {
@@ -181,6 +197,7 @@ __global__ void k_fusion_fwd(const float* __restrict__ e, const float* __restric
   __syncthreads();
   if (j < Hd) {
     float s = b1[j];
+#pragma unroll 4
     for (int i = 0; i < 2 * N; ++i) s = fmaf(w1[(size_t)j * 2 * N + i], z[i], s);
     s = fmaxf(s, 0.f);
     h[j] = s;
@@ -189,6 +206,7 @@ __global__ void k_fusion_fwd(const float* __restrict__ e, const float* __restric
   __syncthreads();
   if (j < N) {
     float s = b2[j];
+#pragma unroll 8
     for (int k = 0; k < Hd; ++k) s = fmaf(w2[(size_t)j * Hd + k], h[k], s);
     logit[j] = s;
   }
@@ -219,6 +237,7 @@ __global__ void k_fusion_bwd_in(const float* __restrict__ dlogp, const float* __
   __syncthreads();
   if (j < 2 * N) {
     float s = 0.f;
+#pragma unroll 8
     for (int k = 0; k < Hd; ++k) s = fmaf(sm[k], w1[(size_t)k * 2 * N + j], s);
     if (j < N) { if (de) de[(size_t)b * N + j] = s; }
     else if (dsp) dsp[(size_t)b * N + (j - N)] = s;
