@@ -106,6 +106,16 @@ def main():
         brainxai.stack_eeg(raw)
     torch.cuda.synchronize()
     stacker_sps = 3 * B / (time.perf_counter() - t0)
+    # the notebook's native montage chain, raw frames [B,10000,20] -> [B,1,37,3000]
+    frames = torch.randn(B, 10000, 20, device=dev) * 50
+    brainxai.stack_eeg_montage(frames)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        brainxai.stack_eeg_montage(frames)
+    torch.cuda.synchronize()
+    montage_sps = 3 * B / (time.perf_counter() - t0)
+    del frames
 
     torch.manual_seed(42)
     model = brainxai.build_multimodal(CHANS, T, CIN, dropout=0.5, compute_dtype=cdt).to(dev).train()
@@ -239,7 +249,28 @@ def main():
             dt = float(tt)
         gradcam = {"maps_per_sec": round(world * reps * maps.shape[0] * maps.shape[1] / dt, 1),
                    "samples_per_sec": round(world * reps * B / dt, 1), "classes": int(maps.shape[1]), "target": "spectrogram_model.block5"}
+        # configs[4]-style integrated gradients (n_steps=50, zero baselines) on 8 samples of the batch: 50 fwd + dgrad sweeps
+        ig_in = (eeg[:8], spec[:8])
+        brainxai.integrated_gradients(model, ig_in, None, n_steps=50)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        brainxai.integrated_gradients(model, ig_in, None, n_steps=50)
+        torch.cuda.synchronize()
+        gradcam["ig50_samples_per_sec"] = round(8 / (time.perf_counter() - t0), 2)
         model.train()
+
+    # ---- measured device-to-device copy rate (quote the box's own streaming rate next to the 8 TB/s spec)
+    if rank == 0:
+        src = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record(); torch.cuda.synchronize()
+        extra["measured_copy_GBps"] = round(10 * 2 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)   # read + write bytes
+        del src, dst
 
     # ---- CPU baseline: the oracle (a port of the reference's PyTorch path) on this box's host cores, rank 0, N=1 only
     cpu = None
@@ -268,6 +299,11 @@ def main():
             t0 = time.perf_counter()
             O.grad_cam(ref, ce[:16], cs[:16], class_idx="all")
             cpu["gradcam_maps_per_sec"] = round(16 * 6 / (time.perf_counter() - t0), 2)
+        fr = O.synthetic_frames(batch=4, seed=3)
+        t0 = time.perf_counter()
+        for f in fr:
+            O.montage_transform(f)
+        cpu["montage_stacker_samples_per_sec"] = round(4 / (time.perf_counter() - t0), 2)     # one host core, numpy/scipy
 
     if rank == 0:
         line = {"metric": "samples/sec train (multimodal SpectrogramCNN+EEGNet fusion, B=64/GPU, 4x128x256 spectro + 10000x19 EEG)",
@@ -277,7 +313,7 @@ def main():
                 "config": {"workload": "configs[1]: multimodal train step, B=64 per GPU, spec [64,4,128,256] + EEG [64,1,19,2000] (stacked from [64,10000,19])",
                            "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": "AdamW(1e-3) fused flat arena",
                            "loss": "KLDivLoss(mean)", "dropout": 0.5, "params": sum(p.numel() for p in model.parameters())},
-                "hip_graph": graph is not None, "final_loss": round(loss_val, 6), "gradcam": gradcam, "stacker_samples_per_sec": round(stacker_sps, 1),
+                "hip_graph": graph is not None, "final_loss": round(loss_val, 6), "gradcam": gradcam, "stacker_samples_per_sec": round(stacker_sps, 1), "montage_stacker_samples_per_sec": round(montage_sps, 1),
                 "roofline": roofline, "cpu_baseline": cpu}
         line.update(extra)
         os.write(real_stdout, (json.dumps(line) + "\n").encode())

@@ -209,6 +209,20 @@ int bx_eeg_stack_iir(const float* raw, const int* channel_index, float* out, int
                      const double* b_host, const double* a_host, int order, int step, float clip, float scale,
                      bxStream stream);
 
+/* ---- native-pipeline EEG montage stacker (CombinedDataset.process_eeg, NB:1148-1164,1211-1276) ---- */
+/* raw fp32 [B,L,Craw] (eeg.values of each frame); output row r is built from raw column row_a[r], minus column row_b[r]
+ * when row_b[r] >= 0 (device int32[R] each, values < Craw).  Per raw column: lfilter(b1,a1) in fp64, NaN -> the row's
+ * nanmean; per output row: (difference,) lfilter(b2,a2), mean of 4 consecutive samples at every 4th column of [0,L-1),
+ * z-score with population std and eps, zero-padded / truncated to out_len.  out fp32 [B,R,out_len].
+ * b*, a* = host double[order+1] (transfer-function coefficients, order <= 12).  L % 4 must be 0 or 1.
+ * status: device int32[1], set to 1 when some raw row is NaN from its first sample (the reference drops such rows and
+ * then mis-indexes; here the row is treated as all-zero after the first filter and the caller is told).
+ * The mirror augmentation (cfg.AUGMENT) is a column permutation the caller applies through row_a/row_b. */
+size_t bx_eeg_montage_workspace(int B, int L, int Craw, int R);
+int bx_eeg_montage_stack(const float* raw, const int* row_a, const int* row_b, float* out, int B, int L, int Craw, int R,
+                         int out_len, const double* b1, const double* a1, int order1, const double* b2, const double* a2,
+                         int order2, float eps, int* status, void* workspace, size_t workspace_bytes, bxStream stream);
+
 /* ---- optimiser over the flat parameter arena (torch.optim.AdamW, NB:1988) ------------------------ */
 /* p, g, m, v fp32 [n]; step_count device float[1]: incremented by this call, then used as t. */
 int bx_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,

@@ -7,9 +7,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbrainxai.so")
-SOURCES = ["core.hip", "conv3x3.hip", "conv3x3_mfma.hip", "tail.hip", "heads.hip", "eeg.hip", "attrib.hip"]
+SOURCES = ["core.hip", "conv3x3.hip", "conv3x3_mfma.hip", "tail.hip", "heads.hip", "eeg.hip", "attrib.hip", "montage.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
+# per-file additions (later flags win): the montage IIR must round every product and sum separately, as scipy's C loop does
+EXTRA_FLAGS = {"montage.hip": ["-ffp-contract=off"]}
 
 
 def _digest():
@@ -19,7 +21,7 @@ def _digest():
         if os.path.isfile(p) and (p.endswith(".hip") or p.endswith(".h")):
             h.update(name.encode())
             h.update(open(p, "rb").read())
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
     return h.hexdigest()
 
 
@@ -34,7 +36,7 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
     for src, p in procs:

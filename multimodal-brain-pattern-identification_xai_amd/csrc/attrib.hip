@@ -133,17 +133,25 @@ __global__ void k_eeg_stack_iir(const float* __restrict__ raw, const int* __rest
   double z[IIR_MAX_ORDER];
 #pragma unroll
   for (int i = 0; i < IIR_MAX_ORDER; ++i) z[i] = 0.0;
-  for (int n = 0; n < L; ++n) {
-    float xv = src[(size_t)n * Craw];
-    xv = fminf(fmaxf(xv, -clip), clip);            // np.clip keeps NaN; fminf/fmaxf drop it -> handle below
-    if (src[(size_t)n * Craw] != src[(size_t)n * Craw]) xv = 0.f;  // np.nan_to_num(nan=0)
-    const double x = (double)(xv * inv_scale);
-    const double y = z[0] + k.b[0] * x;
+  for (int n0 = 0; n0 < L; n0 += 8) {               // eight samples per trip: their loads are in flight together
+    float raw8[8];
 #pragma unroll
-    for (int i = 0; i < IIR_MAX_ORDER - 1; ++i)
-      if (i < order - 1) z[i] = z[i + 1] + k.b[i + 1] * x - k.a[i + 1] * y;
-    z[order - 1] = k.b[order] * x - k.a[order] * y;
-    if (n % step == 0) dst[n / step] = (float)y;
+    for (int j = 0; j < 8; ++j) raw8[j] = n0 + j < L ? src[(size_t)(n0 + j) * Craw] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int n = n0 + j;
+      if (n < L) {
+        float xv = fminf(fmaxf(raw8[j], -clip), clip);   // np.clip keeps NaN; fminf/fmaxf drop it -> handle below
+        if (raw8[j] != raw8[j]) xv = 0.f;                // np.nan_to_num(nan=0)
+        const double x = (double)(xv * inv_scale);
+        const double y = z[0] + k.b[0] * x;
+#pragma unroll
+        for (int i = 0; i < IIR_MAX_ORDER - 1; ++i)
+          if (i < order - 1) z[i] = z[i + 1] + k.b[i + 1] * x - k.a[i + 1] * y;
+        z[order - 1] = k.b[order] * x - k.a[order] * y;
+        if (n % step == 0) dst[n / step] = (float)y;
+      }
+    }
   }
 }
 extern "C" int bx_eeg_stack_iir(const float* raw, const int* channel_index, float* out, int B, int L, int Craw, int C,

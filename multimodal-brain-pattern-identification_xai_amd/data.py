@@ -1,4 +1,8 @@
-"""GPU EEG stacker: raw windows [B, L, C_raw] -> EEGNet input [B, 1, 19, L/5].
+"""GPU EEG stackers.
+
+``EEGStacker`` / ``stack_eeg``: raw windows [B, L, C_raw] -> EEGNet input [B, 1, 19, L/5] (the benchmark path).
+``EEGMontageStacker`` / ``stack_eeg_montage``: raw frames [B, L, 20] -> [B, 1, 37, 3000], the notebook's native
+multimodal pipeline (band-pass, NaN fill, bipolar montage, denoise, z-score, pad).
 
 Replaces ``_EEGTransformer.transform`` + ``EEGDataset.__getitem__`` of the reference
 (root/src/data/dataset.py:73-104,125-131,213-228): select the 19 canonical channels, clip to +-1024,
@@ -14,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .ops import _p, _stream
+from .ops import _p, _stream, workspace
 
 # reference root/src/utils/cfg_utils.py:92-95
 CHANNEL_FEATS = ["Fp1", "F3", "C3", "P3", "F7", "T3", "T5", "O1", "Fz", "Cz", "Pz",
@@ -68,3 +72,82 @@ def stack_eeg(raw: torch.Tensor) -> torch.Tensor:
     if _DEFAULT is None:
         _DEFAULT = EEGStacker()
     return _DEFAULT(raw)
+
+
+# reference XAI_Multimodality.py:115-120 (column order of the parquet frames) and :211-218 (bipolar pairs)
+EEG_COLUMNS = ["Fp1", "F3", "C3", "P3", "F7", "T3", "T5", "O1", "Fz", "Cz", "Pz", "Fp2", "F4", "C4", "P4", "F8", "T4", "T6", "O2", "EKG"]
+MAP_FEATURES = [("Fp1", "F7"), ("F7", "T3"), ("T3", "T5"), ("T5", "O1"), ("Fp1", "F3"), ("F3", "C3"), ("C3", "P3"), ("P3", "O1"),
+                ("Fp2", "F8"), ("F8", "T4"), ("T4", "T6"), ("T6", "O2"), ("Fp2", "F4"), ("F4", "C4"), ("C4", "P4"), ("P4", "O2"),
+                ("Fz", "Cz"), ("Cz", "Pz")]
+
+
+class EEGMontageStacker:
+    """``CombinedDataset.process_eeg`` (reference XAI_Multimodality.py:1148-1164) for a whole batch on the GPU.
+
+    raw: CUDA float tensor [B, L, 20], columns in ``EEG_COLUMNS`` order (``eeg.values`` of each frame).
+    Returns [B, 1, 37, fixed_length] float32.  ``reference_row_selection=True`` keeps the reference's row choice
+    (:1126-1127, :1271-1276: the bipolar rows are stacked after all 20 raw rows but selected from index 19, so the
+    output is 19 EEG channels + EKG + the first 17 differences); ``False`` gives the 19 channels + all 18 differences.
+    ``mirror=True`` applies ``mirror_eeg`` (:1278-1282, cfg.AUGMENT): left and right electrode columns swapped.
+    ``last_status`` (device int32) is 1 when a raw row was NaN from its first sample (the reference drops such rows).
+    """
+
+    def __init__(self, low=0.5, high=20.0, sampling_rate=200.0, fixed_length=3000, eps=1e-6, reference_row_selection=True,
+                 mirror=False):
+        from scipy.signal import butter
+        nyq = 0.5 * sampling_rate
+        self.b1, self.a1 = (np.ascontiguousarray(v, dtype=np.float64) for v in butter(5, [low / nyq, high / nyq], btype="band"))
+        self.b2, self.a2 = (np.ascontiguousarray(v, dtype=np.float64) for v in butter(6, [low / nyq, high / nyq], btype="band"))
+        self.fixed_length, self.eps = int(fixed_length), float(eps)
+        idx = {n: i for i, n in enumerate(EEG_COLUMNS)}
+        col = list(range(20))
+        if mirror:
+            left = ["Fp1", "F3", "C3", "P3", "F7", "T3", "T5", "O1"]
+            right = ["Fp2", "F4", "C4", "P4", "F8", "T4", "T6", "O2"]
+            for a, b in zip(left, right):
+                col[idx[a]], col[idx[b]] = idx[b], idx[a]
+        rows = [(col[i], -1) for i in range(19)]
+        pairs = [(col[idx[a]], col[idx[b]]) for a, b in MAP_FEATURES]
+        rows += ([(col[19], -1)] + pairs[:17]) if reference_row_selection else pairs
+        self.rows = rows
+        self._dev = {}
+        self.last_status = None
+
+    def __call__(self, raw: torch.Tensor) -> torch.Tensor:
+        if not raw.is_cuda:
+            raise RuntimeError("brainxai.EEGMontageStacker: raw EEG must be a CUDA tensor; there is no CPU path")
+        if raw.dim() != 3 or raw.shape[2] != 20:
+            raise RuntimeError(f"expected raw EEG frames [B, L, 20], got {tuple(raw.shape)}")
+        raw = raw.contiguous().float()
+        B, Lr, Craw = raw.shape
+        R = len(self.rows)
+        if B == 0:
+            return torch.empty(0, 1, R, self.fixed_length, device=raw.device)
+        key = raw.device.index
+        if key not in self._dev:
+            self._dev[key] = (torch.tensor([r[0] for r in self.rows], dtype=torch.int32, device=raw.device),
+                              torch.tensor([r[1] for r in self.rows], dtype=torch.int32, device=raw.device))
+        ra, rb = self._dev[key]
+        lib = L.load()
+        out = torch.empty(B, 1, R, self.fixed_length, dtype=torch.float32, device=raw.device)
+        status = torch.empty(1, dtype=torch.int32, device=raw.device)
+        need = lib.bx_eeg_montage_workspace(B, Lr, Craw, R)
+        ws = workspace(need, raw.device)
+        dbl = C.POINTER(C.c_double)
+        L.check(lib.bx_eeg_montage_stack(_p(raw), _p(ra), _p(rb), _p(out), B, Lr, Craw, R, self.fixed_length,
+                                         self.b1.ctypes.data_as(dbl), self.a1.ctypes.data_as(dbl), len(self.b1) - 1,
+                                         self.b2.ctypes.data_as(dbl), self.a2.ctypes.data_as(dbl), len(self.b2) - 1,
+                                         self.eps, _p(status), _p(ws), ws.numel(), _stream()), "bx_eeg_montage_stack")
+        self.last_status = status
+        return out
+
+
+_MONTAGE = None
+
+
+def stack_eeg_montage(raw: torch.Tensor) -> torch.Tensor:
+    """Reference defaults: [B, L, 20] raw frames -> [B, 1, 37, 3000]."""
+    global _MONTAGE
+    if _MONTAGE is None:
+        _MONTAGE = EEGMontageStacker()
+    return _MONTAGE(raw)

@@ -332,6 +332,52 @@ def gen_stacker():
     save("stacker_2x10000x19", out=outs, b=b, a=a)
 
 
+def gen_montage(NB):
+    """8(f) rank 3: the notebook's CombinedDataset EEG chain, method by method, on synthetic frames (with NaNs)."""
+    from scipy.signal import butter, lfilter
+
+    class _Base:
+        pass
+    ns = {"np": np, "torch": torch, "Dataset": _Base, "butter": butter, "lfilter": lfilter, "CFG": None}
+    tree = ast.parse(open(NB).read())
+    node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "CombinedDataset"][-1]      # NB:1113 (the multimodal cell)
+    node.body = [m for m in node.body if isinstance(m, ast.FunctionDef) and m.name in
+                 ("butter_bandpass", "butter_bandpass_filter", "handle_nan", "calculate_differential_signals", "denoise_filter",
+                  "normalize", "select_and_map_channels", "pad_or_truncate")]
+    for d in node.bases:
+        pass
+    node.bases, node.keywords = [], []
+    exec(compile(ast.Module([node], []), "nb", "exec"), ns)
+    ds = ns["CombinedDataset"]()
+
+    class cfg:
+        bandpass_filter = {"low": 0.5, "high": 20, "order": 2}
+        sampling_rate = 200
+        map_features = O.MAP_FEATURES
+        eeg_features = O.EEG_COLUMNS[:19]
+        feature_to_index = {x: y for x, y in zip(O.EEG_COLUMNS[:19], range(19))}
+        fixed_length = 3000
+        in_channels = 4
+    ds.cfg, ds.feature_to_index, ds.differential_channels_start_index = cfg, cfg.feature_to_index, len(cfg.feature_to_index)
+    frames = O.synthetic_frames(batch=2, seed=7)
+    outs = []
+    for fr in frames:
+        waves = fr.T                                                    # eeg.values.T
+        waves = ds.butter_bandpass_filter(waves, 0.5, 20, 200)
+        waves = ds.handle_nan(waves)
+        waves = ds.calculate_differential_signals(waves)
+        waves = ds.denoise_filter(waves)
+        waves = ds.normalize(waves)
+        waves = ds.select_and_map_channels(waves, cfg.eeg_features, cfg.feature_to_index)
+        waves = ds.pad_or_truncate(waves, cfg.fixed_length)
+        outs.append(torch.tensor(waves[np.newaxis, ...], dtype=torch.float32).numpy())
+    outs = np.stack(outs)                                               # [2, 1, 37, 3000]
+    mine = np.stack([O.montage_transform(fr) for fr in frames])
+    note("montage", mine, outs)
+    save("montage_2x10000x20", **{f"row{r}": outs[:, 0, r, :2560] for r in (0, 7, 18, 19, 20, 28, 36)},
+         full=outs, nan_count=np.array([int(np.isnan(frames).sum())]))
+
+
 def gen_manifest(M, MM):
     man = {}
     for name, net in {"Block(4,16)": M.Block(4, 16), "Spectrogram_Model": M.Spectrogram_Model(6),
@@ -355,6 +401,7 @@ if __name__ == "__main__":
     print("multimodal"); gen_multimodal(M, MM)
     print("attribution"); gen_attribution(M, MM, NB)
     print("stacker"); gen_stacker()
+    print("montage stacker"); gen_montage(NB)
     gen_manifest(M, MM)
     REPORT["_meta"] = {"torch": torch.__version__, "note": "max |oracle - reference| / max|reference| on full tensors"}
     json.dump(REPORT, open(os.path.join(OUT, "PIN_REPORT.json"), "w"), indent=1, sort_keys=True)

@@ -359,6 +359,80 @@ def stack_eeg_batch(raw: np.ndarray) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------
+# 8(f) rank 3 -- native-pipeline EEG montage stacker: raw [L, 20] frame -> [1, 37, 3000]
+# (reference XAI_Multimodality.py: CombinedDataset.process_eeg :1148-1164 and its helpers :1211-1276, CFG :115-241)
+# --------------------------------------------------------------------------------------
+EEG_COLUMNS = ["Fp1", "F3", "C3", "P3", "F7", "T3", "T5", "O1", "Fz", "Cz", "Pz", "Fp2", "F4", "C4", "P4", "F8", "T4", "T6", "O2", "EKG"]
+MAP_FEATURES = [("Fp1", "F7"), ("F7", "T3"), ("T3", "T5"), ("T5", "O1"), ("Fp1", "F3"), ("F3", "C3"), ("C3", "P3"), ("P3", "O1"),
+                ("Fp2", "F8"), ("F8", "T4"), ("T4", "T6"), ("T6", "O2"), ("Fp2", "F4"), ("F4", "C4"), ("C4", "P4"), ("P4", "O2"),
+                ("Fz", "Cz"), ("Cz", "Pz")]
+
+
+def montage_coeffs(low=0.5, high=20.0, fs=200.0):
+    """(b5, a5), (b6, a6): Butterworth band-pass designs of order 5 (first pass) and 6 (denoise pass) -- NB:1245-1253,1264."""
+    from scipy.signal import butter
+    nyq = 0.5 * fs
+    return butter(5, [low / nyq, high / nyq], btype="band"), butter(6, [low / nyq, high / nyq], btype="band")
+
+
+def montage_rows():
+    """(a, b) source rows of the 37 selected output rows; b = -1 for a plain channel.  Reproduces the reference's
+    off-by-one (NB:1126-1127,1271-1276): the bipolar rows are appended AFTER all 20 raw rows (EKG included) but are
+    selected from index 19 = len(feature_to_index), so the output is 19 EEG channels + EKG + the first 17 differences."""
+    idx = {n: i for i, n in enumerate(EEG_COLUMNS[:19])}
+    rows = [(i, -1) for i in range(19)] + [(19, -1)]
+    rows += [(idx[a], idx[b]) for a, b in MAP_FEATURES[:17]]
+    return rows
+
+
+def montage_transform(frame: np.ndarray, fixed_length=3000) -> np.ndarray:
+    """frame: float32 [L, 20] (columns in EEG_COLUMNS order, as ``eeg.values``).  Returns float32 [1, 37, fixed_length].
+    band-pass(order 5, lfilter) -> NaN -> row nanmean -> append 18 bipolar differences -> band-pass(order 6) ->
+    4-tap forward mean (np.roll over the FLATTENED array, as the reference writes it) -> every 4th column of [0, L-1) ->
+    per-row z-score (population std, eps 1e-6) -> select 19 + rows 19..36 -> zero-pad / truncate."""
+    from scipy.signal import lfilter
+    (b5, a5), (b6, a6) = montage_coeffs()
+    waves = frame.T
+    waves = lfilter(b5, a5, waves, axis=1)
+    data = waves[~np.isnan(waves).all(axis=1)]                                   # handle_nan (NB:1211-1221)
+    if data.size == 0:
+        raise ValueError("every row is NaN")                                     # reference substitutes a mis-sized zero array
+    where_nan = np.isnan(data)
+    mean_values = np.nanmean(data, axis=1, keepdims=True) if where_nan.any() else np.zeros((data.shape[0], 1))
+    mean_values[np.isnan(mean_values)] = 0
+    data[where_nan] = np.take(mean_values, np.where(where_nan)[0])
+    idx = {n: i for i, n in enumerate(EEG_COLUMNS[:19])}
+    diff = np.zeros((len(MAP_FEATURES), data.shape[1]))
+    for i, (fa, fb) in enumerate(MAP_FEATURES):
+        diff[i] = data[idx[fa]] - data[idx[fb]]
+    data = np.vstack((data, diff))
+    y = lfilter(b6, a6, data, axis=1)                                            # denoise_filter (NB:1263-1267)
+    y = (y + np.roll(y, -1) + np.roll(y, -2) + np.roll(y, -3)) / 4
+    y = y[:, 0:-1:4]
+    y = (y - np.mean(y, axis=1, keepdims=True)) / (np.std(y, axis=1, keepdims=True) + 1e-6)
+    sel = list(range(19)) + list(range(19, 19 + len(MAP_FEATURES)))
+    y = y[sel]
+    if y.shape[1] < fixed_length:
+        y = np.hstack((y, np.zeros((y.shape[0], fixed_length - y.shape[1]))))
+    else:
+        y = y[:, :fixed_length]
+    return y[np.newaxis].astype(np.float32)
+
+
+def synthetic_frames(batch=2, length=10000, seed=7, nan_rate=1e-4):
+    """raw frames [B, L, 20] like the Kaggle parquet (microvolt scale, slow drift + 10 Hz rhythm + noise, a few NaNs
+    that never sit at t = 0, so no row is NaN from the start)."""
+    g = np.random.default_rng(seed)
+    t = np.arange(length)[None, :, None] / 200.0
+    x = 40 * g.standard_normal((batch, length, 20)) + 60 * np.sin(2 * np.pi * 10 * t + g.uniform(0, 6, (batch, 1, 20))) + 200 * g.standard_normal((batch, 1, 20))
+    x = x.astype(np.float32)
+    m = g.random((batch, length, 20)) < nan_rate
+    m[:, :64] = False
+    x[m] = np.nan
+    return x
+
+
+# --------------------------------------------------------------------------------------
 # Synthetic inputs of SURVEY.md section 8(d) -- shared by tests, smoke and bench
 # --------------------------------------------------------------------------------------
 def synthetic_batch(batch=64, in_channels=4, height=128, width=256, chans=19, raw_len=10000, seed=42,

@@ -265,6 +265,36 @@ def test_stacker():
     assert brainxai.stack_eeg(raw[:0].to(DEV)).shape[0] == 0
 
 
+def test_montage_stacker():
+    """8(f) rank 3: the notebook's native EEG chain (NB:1148-1164) -> [B,1,37,3000]; fixture from the reference's own methods"""
+    fix = load("montage_2x10000x20")
+    frames = O.synthetic_frames(batch=2, seed=7)
+    assert int(np.isnan(frames).sum()) == int(fix["nan_count"][0]) > 0
+    st = brainxai.EEGMontageStacker()
+    got = st(torch.from_numpy(frames).to(DEV))
+    assert got.shape == (2, 1, 37, 3000) and int(st.last_status.item()) == 0
+    for r in (0, 7, 18, 19, 20, 28, 36):
+        check(fix, f"row{r}", got[:, 0, r, :2560].cpu(), tol=2e-5)
+    check(fix, "full", got.cpu(), tol=2e-5)
+    assert float(got[:, :, :, 2500:].abs().max()) == 0.0                      # zero padding beyond the 2500 kept samples
+    # a different batch / length (L % 4 == 1), the non-reference row selection and the mirror augmentation vs the oracle
+    fr2 = O.synthetic_frames(batch=3, length=4001, seed=9, nan_rate=5e-4)
+    want = np.stack([O.montage_transform(f) for f in fr2])
+    assert _sync_err(brainxai.stack_eeg_montage(torch.from_numpy(fr2).to(DEV)), want) < 2e-5
+    left = [0, 1, 2, 3, 4, 5, 6, 7]; right = [11, 12, 13, 14, 15, 16, 17, 18]
+    mir = fr2.copy(); mir[:, :, left], mir[:, :, right] = fr2[:, :, right], fr2[:, :, left]
+    want_m = np.stack([O.montage_transform(f) for f in mir])
+    assert _sync_err(brainxai.EEGMontageStacker(mirror=True)(torch.from_numpy(fr2).to(DEV)), want_m) < 2e-5
+    allp = brainxai.EEGMontageStacker(reference_row_selection=False)(torch.from_numpy(fr2).to(DEV))
+    assert _sync_err(allp[:, :, :19], want[:, :, :19]) < 2e-5 and _sync_err(allp[:, :, 19:36], want[:, :, 20:37]) < 2e-5
+    # a row that is NaN from t = 0 is reported, not silently mis-indexed
+    bad = fr2[:1].copy(); bad[0, 0, 5] = np.nan
+    st(torch.from_numpy(bad).to(DEV)); assert int(st.last_status.item()) == 1
+    with pytest.raises(RuntimeError, match="L % 4"):
+        st(torch.from_numpy(np.concatenate([fr2, fr2[:, :1]], axis=1)).to(DEV))          # L = 4002
+    assert st(torch.from_numpy(fr2[:0]).to(DEV)).shape == (0, 1, 37, 3000)
+
+
 def test_dropout_statistics_and_determinism():
     torch.manual_seed(0)
     blk = brainxai.Block(8, 16, "max", (2, 2), dropout_p=0.5).to(DEV).train()

@@ -153,3 +153,16 @@ def test_state_dict_manifest():
         assert {k: list(v.shape) for k, v in net.state_dict().items()} == man[name], name
         assert sum(p.numel() for p in net.parameters()) == man[name + "#params"]
     assert man["MultimodalModel(bench)#params"] == 2025074
+
+
+def test_montage_stacker():
+    """8(f) rank 3: oracle restatement of CombinedDataset.process_eeg against vectors made by the reference's own methods"""
+    fix = load("montage_2x10000x20")
+    frames = O.synthetic_frames(batch=2, seed=7)
+    assert int(np.isnan(frames).sum()) == int(fix["nan_count"][0])
+    got = np.stack([O.montage_transform(f) for f in frames])
+    for r in (0, 7, 18, 19, 20, 28, 36):
+        check(fix, f"row{r}", got[:, 0, r, :2560], tol=1e-6)
+    check(fix, "full", got, tol=1e-6)
+    rows = O.montage_rows()
+    assert len(rows) == 37 and rows[19] == (19, -1) and rows[20] == (0, 4) and rows[36] == (8, 9)
