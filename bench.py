@@ -116,6 +116,16 @@ def main():
     torch.cuda.synchronize()
     montage_sps = 3 * B / (time.perf_counter() - t0)
     del frames
+    # the notebook's native spectrogram chain, parquet values [B,320,400] -> [B,3,400,300]
+    sframes = torch.rand(B, 320, 400, device=dev) * 40
+    brainxai.preprocess_spectrograms(sframes)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        brainxai.preprocess_spectrograms(sframes)
+    torch.cuda.synchronize()
+    specprep_sps = 3 * B / (time.perf_counter() - t0)
+    del sframes
 
     torch.manual_seed(42)
     model = brainxai.build_multimodal(CHANS, T, CIN, dropout=0.5, compute_dtype=cdt).to(dev).train()
@@ -304,6 +314,11 @@ def main():
         for f in fr:
             O.montage_transform(f)
         cpu["montage_stacker_samples_per_sec"] = round(4 / (time.perf_counter() - t0), 2)     # one host core, numpy/scipy
+        sf = O.synthetic_spectrogram_frames(batch=4, seed=3).astype("float64")
+        t0 = time.perf_counter()
+        for f in sf:
+            O.spectrogram_transform(f)
+        cpu["spectrogram_prep_samples_per_sec"] = round(4 / (time.perf_counter() - t0), 2)
 
     if rank == 0:
         line = {"metric": "samples/sec train (multimodal SpectrogramCNN+EEGNet fusion, B=64/GPU, 4x128x256 spectro + 10000x19 EEG)",
@@ -313,7 +328,7 @@ def main():
                 "config": {"workload": "configs[1]: multimodal train step, B=64 per GPU, spec [64,4,128,256] + EEG [64,1,19,2000] (stacked from [64,10000,19])",
                            "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": "AdamW(1e-3) fused flat arena",
                            "loss": "KLDivLoss(mean)", "dropout": 0.5, "params": sum(p.numel() for p in model.parameters())},
-                "hip_graph": graph is not None, "final_loss": round(loss_val, 6), "gradcam": gradcam, "stacker_samples_per_sec": round(stacker_sps, 1), "montage_stacker_samples_per_sec": round(montage_sps, 1),
+                "hip_graph": graph is not None, "final_loss": round(loss_val, 6), "gradcam": gradcam, "stacker_samples_per_sec": round(stacker_sps, 1), "montage_stacker_samples_per_sec": round(montage_sps, 1), "spectrogram_prep_samples_per_sec": round(specprep_sps, 1),
                 "roofline": roofline, "cpu_baseline": cpu}
         line.update(extra)
         os.write(real_stdout, (json.dumps(line) + "\n").encode())

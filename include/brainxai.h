@@ -223,6 +223,19 @@ int bx_eeg_montage_stack(const float* raw, const int* row_a, const int* row_b, f
                          int out_len, const double* b1, const double* a1, int order1, const double* b2, const double* a2,
                          int order2, float eps, int* status, void* workspace, size_t workspace_bytes, bxStream stream);
 
+/* ---- native-pipeline spectrogram pre-processing (CombinedDataset.process_spectrogram, NB:1166-1204) ---- */
+/* raw fp32 [B,Trows,Ccols] (the parquet frame's values without the time column, NaNs allowed); offsets: device int32[B]
+ * (spectrogram_label_offset_seconds; the reference windows `sel` COLUMNS from offset//2) or NULL; out fp32 [B,3,R,W].
+ * Chain: transpose -> pad/truncate to R x W -> NaN -> row nanmean -> subtract column means -> filtfilt(notch_b, notch_a)
+ * along the rows (odd extension, 9 samples; notch_zi = scipy.signal.lfilter_zi) -> separable gaussian (gauss_w: 9 symmetric
+ * weights, 'reflect' boundary) -> min-max with eps -> 3 identical channels.  The reference's final skimage resize is to
+ * the array's own shape (identity).  status: device int32[1]; bit 0 = some row was entirely NaN (the reference drops it
+ * and then really resamples: not reproduced), bit 1 = NaN after filtering. */
+size_t bx_spec_preprocess_workspace(int B, int R, int W);
+int bx_spec_preprocess(const float* raw, const int* offsets, float* out, int B, int Trows, int Ccols, int R, int W, int sel,
+                       const double* notch_b, const double* notch_a, const double* notch_zi, const double* gauss_w,
+                       float eps, int* status, void* workspace, size_t workspace_bytes, bxStream stream);
+
 /* ---- optimiser over the flat parameter arena (torch.optim.AdamW, NB:1988) ------------------------ */
 /* p, g, m, v fp32 [n]; step_count device float[1]: incremented by this call, then used as t. */
 int bx_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,

@@ -7,7 +7,8 @@ from . import _lib, ops                                                       # 
 from .models import (Block, EEGNet, KLDivLoss, MultimodalModel, Spectrogram_Model,   # noqa: F401
                      build_multimodal, set_compute_dtype)
 from .explain import expected_gradients, generate_saliency_maps, grad_cam, integrated_gradients, saliency   # noqa: F401
-from .data import EEGStacker, stack_eeg, EEGMontageStacker, stack_eeg_montage                                        # noqa: F401
+from .data import (EEGStacker, stack_eeg, EEGMontageStacker, stack_eeg_montage,          # noqa: F401
+                   SpectrogramPreprocessor, preprocess_spectrograms)                                        # noqa: F401
 from .train import (FlatAdamW, DataParallel, train_and_validate_combined, train_and_validate_eeg_distributed,   # noqa: F401
                     train_step, setup, cleanup, create_ddp_model)
 

@@ -83,6 +83,9 @@ SIGNATURES = {
     "bx_eeg_montage_workspace": (sz, [i32, i32, i32, i32]),
     "bx_eeg_montage_stack": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, P(C.c_double), P(C.c_double), i32, P(C.c_double), P(C.c_double),
                                    i32, f32, vp, vp, sz, vp]),
+    "bx_spec_preprocess_workspace": (sz, [i32, i32, i32]),
+    "bx_spec_preprocess": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_double),
+                                 f32, vp, vp, sz, vp]),
     "bx_adamw_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, f32, vp, vp]),
     "bx_sumsq": (i32, [vp, sz, vp, vp]),
     "bx_seed_next": (i32, [vp, vp, vp]),

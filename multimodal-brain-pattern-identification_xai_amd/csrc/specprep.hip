@@ -1,0 +1,150 @@
+// Native-pipeline spectrogram pre-processing: parquet values [B, Trows, C] -> [B, 3, R, W] fp32.
+// Replaces the per-sample numpy/scipy chain of the reference's CombinedDataset.process_spectrogram
+// (root/jupyter_notebooks/XAI_Multimodality.py:1166-1204 with helpers :1211-1243,1288-1307):
+//   (offset//2 column window of `sel` columns, zero padded) -> transpose -> pad/truncate to R x W (400 x 300) ->
+//   NaN -> the row's nanmean -> subtract column means -> notch filtfilt along the rows (scipy.signal.filtfilt: odd
+//   extension by 3*max(len(a),len(b)) samples, lfilter_zi initial state, forward and backward pass, fp64) ->
+//   gaussian_filter sigma=1 (separable 9-tap correlate1d, 'reflect' boundary, rows then columns) -> min-max to [0,1) ->
+//   resize to its own shape (identity) -> three identical channels.
+// One workgroup per sample walks the phases over an fp64 plane in the caller's workspace (L2-resident, 2.9 MB per
+// sample); phases that need other threads' results are separated by workgroup barriers.
+#include "bx_common.h"
+
+struct SpecPrepCoef { double b[3], a[3], zi[2], gw[5]; };     // gw[d] = gaussian weight at distance d (radius 4)
+#define SP_PAD 9
+
+__device__ __forceinline__ int sp_reflect(int i, int n) {     // scipy.ndimage 'reflect': (d c b a | a b c d | d c b a)
+  if (i < 0) i = -i - 1;
+  if (i >= n) i = 2 * n - 1 - i;
+  return i;
+}
+
+__global__ __launch_bounds__(256) void k_spec_preprocess(const float* __restrict__ raw, const int* __restrict__ offsets, float* __restrict__ out,
+                                                         double* __restrict__ scratch, int* __restrict__ status, int Trows, int Ccols,
+                                                         int R, int W, int sel, SpecPrepCoef k, double eps) {
+  __shared__ double smin[256], smax[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const size_t plane = (size_t)R * W;
+  double* A = scratch + (size_t)b * (2 * plane + (size_t)(R + 2 * SP_PAD) * W);
+  double* Bp = A + plane;
+  double* E = Bp + plane;                                      // [R + 18][W] forward-pass output of filtfilt
+  const float* src = raw + (size_t)b * Trows * Ccols;
+  const int o = offsets ? offsets[b] / 2 : 0;
+  const int nrows_src = offsets ? sel : Ccols;                 // rows of basic.T before padding to R
+  // ---- phase 1: gather + transpose + pad, NaN -> row nanmean
+  for (int i = tid; i < R; i += 256) {
+    const bool row_live = i < nrows_src && o + i < Ccols && o + i >= 0;
+    const int jn = Trows < W ? Trows : W;
+    double sum = 0.0;
+    int cnt = 0, nnan = 0;
+    for (int j0 = 0; j0 < W; j0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (row_live && j0 + u < jn) ? src[(size_t)(j0 + u) * Ccols + o + i] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (j0 + u < W) {
+          const double d = (double)v[u];
+          A[(size_t)i * W + j0 + u] = d;
+          if (d == d) { sum += d; ++cnt; } else ++nnan;
+        }
+    }
+    if (nnan) {
+      if (cnt == 0) atomicOr(status, 1);                       // an all-NaN row: the reference drops it and really resamples
+      const double m = cnt ? sum / (double)cnt : 0.0;
+      for (int j = 0; j < W; ++j) { const double d = A[(size_t)i * W + j]; if (d != d) A[(size_t)i * W + j] = m; }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2 + 3: per column: subtract the column mean, then filtfilt along the rows
+  for (int j = tid; j < W; j += 256) {
+    double s = 0.0;
+    for (int i = 0; i < R; ++i) s += A[(size_t)i * W + j];
+    const double mean = s / (double)R;
+    for (int i = 0; i < R; ++i) A[(size_t)i * W + j] -= mean;
+    auto ext = [&](int n) -> double {                          // odd extension by SP_PAD samples at both ends
+      if (n < SP_PAD) return 2.0 * A[j] - A[(size_t)(SP_PAD - n) * W + j];
+      if (n < SP_PAD + R) return A[(size_t)(n - SP_PAD) * W + j];
+      return 2.0 * A[(size_t)(R - 1) * W + j] - A[(size_t)(R - 2 - (n - SP_PAD - R)) * W + j];
+    };
+    const int N = R + 2 * SP_PAD;
+    const double x0 = ext(0);
+    double z0 = k.zi[0] * x0, z1 = k.zi[1] * x0, y = 0.0;
+    for (int n = 0; n < N; ++n) {
+      const double x = ext(n);
+      y = z0 + k.b[0] * x;
+      z0 = (z1 + x * k.b[1]) - y * k.a[1];
+      z1 = x * k.b[2] - y * k.a[2];
+      E[(size_t)n * W + j] = y;
+    }
+    z0 = k.zi[0] * y; z1 = k.zi[1] * y;                        // y = last forward output
+    for (int n = N - 1; n >= 0; --n) {
+      const double x = E[(size_t)n * W + j];
+      const double w = z0 + k.b[0] * x;
+      z0 = (z1 + x * k.b[1]) - w * k.a[1];
+      z1 = x * k.b[2] - w * k.a[2];
+      if (n >= SP_PAD && n < SP_PAD + R) A[(size_t)(n - SP_PAD) * W + j] = w;
+    }
+  }
+  __syncthreads();
+  // ---- phase 4: gaussian along the rows (axis 0), A -> Bp; scipy's symmetric correlate1d order: centre, then pairs far -> near
+  for (size_t e = tid; e < plane; e += 256) {
+    const int i = (int)(e / W), j = (int)(e % W);
+    double t = A[e] * k.gw[0];
+#pragma unroll
+    for (int d = 4; d >= 1; --d) t += (A[(size_t)sp_reflect(i - d, R) * W + j] + A[(size_t)sp_reflect(i + d, R) * W + j]) * k.gw[d];
+    Bp[e] = t;
+  }
+  __syncthreads();
+  // ---- phase 5: gaussian along the columns (axis 1), Bp -> A, and the plane's min / max
+  double mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;
+  for (size_t e = tid; e < plane; e += 256) {
+    const int i = (int)(e / W), j = (int)(e % W);
+    const double* row = Bp + (size_t)i * W;
+    double t = row[j] * k.gw[0];
+#pragma unroll
+    for (int d = 4; d >= 1; --d) t += (row[sp_reflect(j - d, W)] + row[sp_reflect(j + d, W)]) * k.gw[d];
+    A[e] = t;
+    if (t != t) has_nan = true;
+    mn = t < mn ? t : mn; mx = t > mx ? t : mx;
+  }
+  if (has_nan) atomicOr(status, 2);                            // nan_to_num(nan=nanmean) would be needed: not expected after the fill
+  smin[tid] = mn; smax[tid] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { smin[tid] = smin[tid + s] < smin[tid] ? smin[tid + s] : smin[tid]; smax[tid] = smax[tid + s] > smax[tid] ? smax[tid + s] : smax[tid]; }
+    __syncthreads();
+  }
+  mn = smin[0]; mx = smax[0];
+  const double den = (mx - mn) + eps;
+  float* dst = out + (size_t)b * 3 * plane;
+  for (size_t e = tid; e < plane; e += 256) {
+    const float v = (float)((A[e] - mn) / den);
+    dst[e] = v; dst[plane + e] = v; dst[2 * plane + e] = v;
+  }
+}
+
+extern "C" size_t bx_spec_preprocess_workspace(int B, int R, int W) {
+  if (B <= 0 || R <= SP_PAD || W <= 0) return 0;
+  return (size_t)B * (2 * (size_t)R * W + (size_t)(R + 2 * SP_PAD) * W) * sizeof(double);
+}
+extern "C" int bx_spec_preprocess(const float* raw, const int* offsets, float* out, int B, int Trows, int Ccols, int R, int W, int sel,
+                                  const double* notch_b, const double* notch_a, const double* notch_zi, const double* gauss_w,
+                                  float eps, int* status, void* workspace, size_t workspace_bytes, bxStream stream) {
+  BX_REQUIRE(raw && out && notch_b && notch_a && notch_zi && gauss_w && status, "bx_spec_preprocess: null pointer");
+  BX_REQUIRE(B > 0 && Trows > 0 && Ccols > 0 && W > 4 && sel > 0, "bx_spec_preprocess: bad sizes");
+  BX_REQUIRE(R > SP_PAD + 1, "bx_spec_preprocess: R must exceed filtfilt's pad length (%d)", SP_PAD);
+  BX_REQUIRE(notch_a[0] != 0.0, "bx_spec_preprocess: a[0] == 0");
+  const size_t need = bx_spec_preprocess_workspace(B, R, W);
+  if (!workspace || workspace_bytes < need) BX_FAIL(BX_EWORKSPACE, "bx_spec_preprocess: workspace %zu < %zu", workspace_bytes, need);
+  SpecPrepCoef k;
+  for (int i = 0; i < 3; ++i) { k.b[i] = notch_b[i] / notch_a[0]; k.a[i] = notch_a[i] / notch_a[0]; }
+  k.zi[0] = notch_zi[0]; k.zi[1] = notch_zi[1];
+  for (int d = 0; d < 5; ++d) k.gw[d] = gauss_w[4 + d];        // gauss_w: the 9 symmetric weights, centre at index 4
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(status, 0, sizeof(int), s) != hipSuccess) BX_FAIL(BX_EHIP, "bx_spec_preprocess: memset failed");
+  hipLaunchKernelGGL(k_spec_preprocess, dim3(B), dim3(256), 0, s, raw, offsets, out, (double*)workspace, status, Trows, Ccols, R, W, sel, k, (double)eps);
+  BX_CHECK_LAUNCH("bx_spec_preprocess");
+  return BX_OK;
+}

@@ -151,3 +151,64 @@ def stack_eeg_montage(raw: torch.Tensor) -> torch.Tensor:
     if _MONTAGE is None:
         _MONTAGE = EEGMontageStacker()
     return _MONTAGE(raw)
+
+
+class SpectrogramPreprocessor:
+    """``CombinedDataset.process_spectrogram`` (reference XAI_Multimodality.py:1166-1204) for a whole batch on the GPU.
+
+    raw: CUDA float tensor [B, Trows, C] -- each frame's ``to_numpy()`` without the time column (NaNs allowed).
+    offsets: optional int tensor/list [B] (``spectrogram_label_offset_seconds``; the reference takes 300 COLUMNS from
+    ``offset // 2``).  Returns [B, 3, 400, 300] float32 with three identical channels.  ``last_status`` (device int32):
+    bit 0 = a row was entirely NaN (the reference drops it and resamples with scikit-image: not reproduced here).
+    """
+
+    def __init__(self, image_size=(400, 300), window=300, notch_freq=60.0, fs=200.0, quality=30.0, sigma=1.0, eps=1e-6):
+        from scipy.signal import iirnotch, lfilter_zi
+        b, a = iirnotch(notch_freq, quality, fs)
+        self.b, self.a = np.ascontiguousarray(b, dtype=np.float64), np.ascontiguousarray(a, dtype=np.float64)
+        self.zi = np.ascontiguousarray(lfilter_zi(b, a), dtype=np.float64)
+        radius = int(4.0 * float(sigma) + 0.5)
+        if radius != 4:
+            raise ValueError("the kernel is built for the 9-tap (sigma = 1) gaussian of the reference")
+        x = np.arange(-radius, radius + 1)
+        phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+        self.gw = np.ascontiguousarray(phi / phi.sum(), dtype=np.float64)
+        self.rows, self.cols, self.window, self.eps = int(image_size[0]), int(image_size[1]), int(window), float(eps)
+        self.last_status = None
+
+    def __call__(self, raw: torch.Tensor, offsets=None) -> torch.Tensor:
+        if not raw.is_cuda:
+            raise RuntimeError("brainxai.SpectrogramPreprocessor: raw spectrograms must be a CUDA tensor; there is no CPU path")
+        if raw.dim() != 3:
+            raise RuntimeError(f"expected raw spectrogram frames [B, Trows, C], got {tuple(raw.shape)}")
+        raw = raw.contiguous().float()
+        B, Trows, Cc = raw.shape
+        if B == 0:
+            return torch.empty(0, 3, self.rows, self.cols, device=raw.device)
+        off = None
+        if offsets is not None:
+            off = torch.as_tensor(offsets, dtype=torch.int32).to(raw.device).contiguous()
+            if off.numel() != B or int(off.min()) < 0:
+                raise RuntimeError("offsets must be B non-negative integers")
+        lib = L.load()
+        out = torch.empty(B, 3, self.rows, self.cols, dtype=torch.float32, device=raw.device)
+        status = torch.empty(1, dtype=torch.int32, device=raw.device)
+        ws = workspace(lib.bx_spec_preprocess_workspace(B, self.rows, self.cols), raw.device)
+        dbl = C.POINTER(C.c_double)
+        L.check(lib.bx_spec_preprocess(_p(raw), _p(off), _p(out), B, Trows, Cc, self.rows, self.cols, self.window,
+                                       self.b.ctypes.data_as(dbl), self.a.ctypes.data_as(dbl), self.zi.ctypes.data_as(dbl),
+                                       self.gw.ctypes.data_as(dbl), self.eps, _p(status), _p(ws), ws.numel(), _stream()),
+                "bx_spec_preprocess")
+        self.last_status = status
+        return out
+
+
+_SPECPREP = None
+
+
+def preprocess_spectrograms(raw: torch.Tensor, offsets=None) -> torch.Tensor:
+    """Reference defaults: [B, Trows, 400] parquet values -> [B, 3, 400, 300]."""
+    global _SPECPREP
+    if _SPECPREP is None:
+        _SPECPREP = SpectrogramPreprocessor()
+    return _SPECPREP(raw, offsets)

@@ -378,6 +378,61 @@ def gen_montage(NB):
          full=outs, nan_count=np.array([int(np.isnan(frames).sum())]))
 
 
+def gen_spectrogram_prep(NB):
+    """8(f) rank 2: the notebook's CombinedDataset spectrogram chain, method by method.  ``resize`` (scikit-image, not
+    installed) is replaced by an identity that asserts it is asked for the array's own shape."""
+    from scipy.signal import filtfilt, iirnotch
+    from scipy.ndimage import gaussian_filter
+
+    def resize(sig, target_shape, mode="reflect", anti_aliasing=True):
+        assert tuple(sig.shape) == tuple(target_shape), "a real resample would need scikit-image"
+        return sig
+
+    class _Base:
+        pass
+    ns = {"np": np, "torch": torch, "Dataset": _Base, "filtfilt": filtfilt, "iirnotch": iirnotch, "gaussian_filter": gaussian_filter,
+          "resize": resize, "CFG": None}
+    tree = ast.parse(open(NB).read())
+    node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "CombinedDataset"][-1]
+    node.body = [m for m in node.body if isinstance(m, ast.FunctionDef) and m.name in
+                 ("handle_nan", "pad_or_truncate", "baseline_correction", "normalize_signal", "apply_notch_filter", "smooth_spectrogram",
+                  "resample_spectrogram")]
+    node.bases, node.keywords = [], []
+    exec(compile(ast.Module([node], []), "nb", "exec"), ns)
+    ds = ns["CombinedDataset"]()
+
+    class cfg:
+        image_size = (400, 300)
+        in_channels = 4
+        map_features = O.MAP_FEATURES
+        fixed_length = 3000
+    ds.cfg = cfg
+    frames = O.synthetic_spectrogram_frames(batch=2, seed=5)
+    outs, mine = [], []
+    for fr, off in zip(frames, (None, 60)):
+        raw = fr.astype(np.float64)                                   # DataFrame.to_numpy() of float columns
+        if off is not None:                                           # NB:1173-1180
+            o = off // 2
+            basic = raw[:, o:o + 300]
+            basic = np.pad(basic, ((0, 0), (0, max(0, 300 - basic.shape[1]))), mode="constant")
+        else:
+            basic = raw
+        sp = basic.T
+        sp = ds.pad_or_truncate(sp, cfg.image_size)
+        sp = ds.handle_nan(sp)
+        sp = ds.baseline_correction(sp)
+        sp = ds.apply_notch_filter(sp)
+        sp = ds.smooth_spectrogram(sp)
+        sp = ds.normalize_signal(sp)
+        sp = ds.resample_spectrogram(sp, cfg.image_size)
+        sp = np.tile(sp[..., None], (1, 1, 3)).astype(np.float32)
+        outs.append(torch.tensor(sp).permute(2, 0, 1).float().numpy())
+        mine.append(O.spectrogram_transform(raw, off))
+    outs, mine = np.stack(outs), np.stack(mine)
+    note("spectrogram_prep", mine, outs)
+    save("specprep_2x320x400", plane=outs[:, 0, ::8, ::6], full=outs, nan_count=np.array([int(np.isnan(frames).sum())]))
+
+
 def gen_manifest(M, MM):
     man = {}
     for name, net in {"Block(4,16)": M.Block(4, 16), "Spectrogram_Model": M.Spectrogram_Model(6),
@@ -402,6 +457,7 @@ if __name__ == "__main__":
     print("attribution"); gen_attribution(M, MM, NB)
     print("stacker"); gen_stacker()
     print("montage stacker"); gen_montage(NB)
+    print("spectrogram pre-processing"); gen_spectrogram_prep(NB)
     gen_manifest(M, MM)
     REPORT["_meta"] = {"torch": torch.__version__, "note": "max |oracle - reference| / max|reference| on full tensors"}
     json.dump(REPORT, open(os.path.join(OUT, "PIN_REPORT.json"), "w"), indent=1, sort_keys=True)

@@ -433,6 +433,71 @@ def synthetic_frames(batch=2, length=10000, seed=7, nan_rate=1e-4):
 
 
 # --------------------------------------------------------------------------------------
+# 8(f) rank 2 -- native-pipeline spectrogram pre-processing: parquet values [Trows, 400] -> [3, 400, 300]
+# (reference XAI_Multimodality.py: CombinedDataset.process_spectrogram :1166-1204 with helpers :1211-1243,1288-1307)
+# skimage.transform.resize (:1305-1307) is called with the array's own shape (400, 300): zoom factor 1, anti-aliasing
+# sigma 0 -> the identity.  scikit-image is not installed here, so that step is NOT pinned by execution.
+# --------------------------------------------------------------------------------------
+def notch_coeffs(freq=60.0, fs=200.0, quality=30.0):
+    from scipy.signal import iirnotch, lfilter_zi
+    b, a = iirnotch(freq, quality, fs)
+    return b, a, lfilter_zi(b, a)
+
+
+def gaussian_weights(sigma=1.0, truncate=4.0):
+    """scipy.ndimage._filters._gaussian_kernel1d(sigma, 0, radius) with radius = int(truncate * sigma + 0.5)."""
+    radius = int(truncate * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return phi / phi.sum()
+
+
+def spectrogram_transform(raw: np.ndarray, offset=None, image_size=(400, 300)) -> np.ndarray:
+    """raw: float [Trows, C] = ``load_train_spectr_frame(id).to_numpy()`` without the time column.  float32 [3, 400, 300].
+    (offset // 2 column window of 300, zero padded) -> transpose -> pad/truncate to 400 x 300 -> drop all-NaN rows, NaN ->
+    row nanmean -> subtract column means -> 60 Hz notch filtfilt along axis 0 -> gaussian sigma 1 -> NaN -> nanmean,
+    min-max to [0, 1) -> resize to its own shape (identity) -> 3 identical channels."""
+    from scipy.ndimage import gaussian_filter
+    from scipy.signal import filtfilt
+    x = np.asarray(raw, dtype=np.float64) if raw.dtype != np.float32 else raw
+    if offset is not None:
+        o = offset // 2
+        basic = x[:, o:o + 300]
+        basic = np.pad(basic, ((0, 0), (0, max(0, 300 - basic.shape[1]))), mode="constant")
+    else:
+        basic = x
+    s = basic.T
+    rows, cols = image_size
+    s = np.vstack((s, np.zeros((rows - s.shape[0], s.shape[1])))) if s.shape[0] < rows else s[:rows, :]
+    s = np.hstack((s, np.zeros((s.shape[0], cols - s.shape[1])))) if s.shape[1] < cols else s[:, :cols]
+    s = s[~np.isnan(s).all(axis=1)]
+    if s.shape[0] != rows:
+        raise ValueError("a row is entirely NaN: the reference drops it and really resamples afterwards (needs scikit-image)")
+    where_nan = np.isnan(s)
+    if where_nan.any():
+        mv = np.nanmean(s, axis=1, keepdims=True)
+        mv[np.isnan(mv)] = 0
+        s = s.copy()
+        s[where_nan] = np.take(mv, np.where(where_nan)[0])
+    s = s - np.mean(s, axis=0)
+    b, a, _ = notch_coeffs()
+    s = filtfilt(b, a, s, axis=0)
+    s = gaussian_filter(s, sigma=1.0)
+    s = np.nan_to_num(s, nan=np.nanmean(s))
+    s = (s - np.min(s)) / (np.max(s) - np.min(s) + 1e-6)
+    return np.tile(s[..., None], (1, 1, 3)).astype(np.float32).transpose(2, 0, 1)
+
+
+def synthetic_spectrogram_frames(batch=2, trows=320, seed=5, nan_rate=2e-3):
+    """parquet-like spectrogram values [B, Trows, 400]: positive, heavy-tailed power values with a few NaNs (never a whole column)."""
+    g = np.random.default_rng(seed)
+    x = np.exp(g.standard_normal((batch, trows, 400)) * 1.5 + np.linspace(2, -2, 400)[None, None, :]).astype(np.float32)
+    m = g.random(x.shape) < nan_rate
+    x[m] = np.nan
+    return x
+
+
+# --------------------------------------------------------------------------------------
 # Synthetic inputs of SURVEY.md section 8(d) -- shared by tests, smoke and bench
 # --------------------------------------------------------------------------------------
 def synthetic_batch(batch=64, in_channels=4, height=128, width=256, chans=19, raw_len=10000, seed=42,

@@ -295,6 +295,34 @@ def test_montage_stacker():
     assert st(torch.from_numpy(fr2[:0]).to(DEV)).shape == (0, 1, 37, 3000)
 
 
+def test_spectrogram_preprocessing():
+    """8(f) rank 2: the notebook's native spectrogram chain (NB:1166-1204) -> [B,3,400,300]; fixture from the reference's own
+    methods (resize at the array's own shape replaced by the identity: scikit-image is not installed)"""
+    fix = load("specprep_2x320x400")
+    frames = O.synthetic_spectrogram_frames(batch=2, seed=5)
+    assert int(np.isnan(frames).sum()) == int(fix["nan_count"][0]) > 0
+    pre = brainxai.SpectrogramPreprocessor()
+    got = pre(torch.from_numpy(frames).to(DEV), offsets=None)
+    assert got.shape == (2, 3, 400, 300) and int(pre.last_status.item()) == 0
+    want0 = O.spectrogram_transform(frames[0].astype(np.float64), None)
+    assert _sync_err(got[0], want0) < 2e-5
+    assert torch.equal(got[:, 0], got[:, 1]) and torch.equal(got[:, 0], got[:, 2])
+    # the fixture's two samples: no offset / offset 60 (the reference windows 300 COLUMNS from offset // 2)
+    g1 = pre(torch.from_numpy(frames[1:]).to(DEV), offsets=[60])
+    both = torch.cat([got[:1], g1])
+    check(fix, "plane", both[:, 0, ::8, ::6].cpu(), tol=2e-5)
+    check(fix, "full", both.cpu(), tol=2e-5)
+    assert float(both.min()) >= 0.0 and float(both.max()) <= 1.0
+    # short frames (zero padding in time), a window that runs past the last column, long frames (truncation)
+    for trows, off in ((120, 0), (300, 700), (512, 131)):
+        fr = O.synthetic_spectrogram_frames(batch=2, trows=trows, seed=trows)
+        want = np.stack([O.spectrogram_transform(f.astype(np.float64), off) for f in fr])
+        assert _sync_err(brainxai.preprocess_spectrograms(torch.from_numpy(fr).to(DEV), [off, off]), want) < 2e-5, (trows, off)
+    bad = frames[:1].copy(); bad[0, :, 7] = np.nan                       # column 7 -> row 7 after the transpose: all NaN
+    pre(torch.from_numpy(bad).to(DEV)); assert int(pre.last_status.item()) & 1
+    assert pre(torch.from_numpy(frames[:0]).to(DEV)).shape == (0, 3, 400, 300)
+
+
 def test_dropout_statistics_and_determinism():
     torch.manual_seed(0)
     blk = brainxai.Block(8, 16, "max", (2, 2), dropout_p=0.5).to(DEV).train()

@@ -166,3 +166,15 @@ def test_montage_stacker():
     check(fix, "full", got, tol=1e-6)
     rows = O.montage_rows()
     assert len(rows) == 37 and rows[19] == (19, -1) and rows[20] == (0, 4) and rows[36] == (8, 9)
+
+
+def test_spectrogram_preprocessing():
+    """8(f) rank 2: oracle restatement of CombinedDataset.process_spectrogram against vectors made by the reference's own methods"""
+    fix = load("specprep_2x320x400")
+    frames = O.synthetic_spectrogram_frames(batch=2, seed=5)
+    assert int(np.isnan(frames).sum()) == int(fix["nan_count"][0])
+    got = np.stack([O.spectrogram_transform(f.astype(np.float64), off) for f, off in zip(frames, (None, 60))])
+    check(fix, "plane", got[:, 0, ::8, ::6], tol=1e-6)
+    check(fix, "full", got, tol=1e-6)
+    w = O.gaussian_weights()
+    assert len(w) == 9 and abs(w.sum() - 1) < 1e-15 and w[4] == w.max()
