@@ -323,6 +323,31 @@ def test_spectrogram_preprocessing():
     assert pre(torch.from_numpy(frames[:0]).to(DEV)).shape == (0, 3, 400, 300)
 
 
+def test_native_pipeline_end_to_end():
+    """The literal reference multimodal configuration (NB:1132-1146 + NB:1932-1935): raw EEG frames and parquet spectrogram values
+    -> GPU pre-processing (8(f) ranks 2 and 3) -> MultimodalModel(EEGNet(6, 37, 3000), Spectrogram_Model(6)) forward, loss,
+    gradients, all on the GPU, against the oracle fed with the oracle's own pre-processing"""
+    frames = O.synthetic_frames(batch=2, seed=21)
+    sfr = O.synthetic_spectrogram_frames(batch=2, seed=22)
+    eeg_ref = torch.from_numpy(np.stack([O.montage_transform(f) for f in frames]))                 # [2,1,37,3000]
+    spec_ref = torch.from_numpy(np.stack([O.spectrogram_transform(f.astype(np.float64)) for f in sfr]))   # [2,3,400,300]
+    eeg = brainxai.stack_eeg_montage(torch.from_numpy(frames).to(DEV))
+    spec = brainxai.preprocess_spectrograms(torch.from_numpy(sfr).to(DEV))
+    assert _sync_err(eeg, eeg_ref) < 2e-5 and _sync_err(spec, spec_ref) < 2e-5
+    ref, mine = _pair(lambda: O.build_multimodal(37, 3000, 3, dropout=0.0), lambda: brainxai.build_multimodal(37, 3000, 3, dropout=0.0), 51)
+    labels = torch.softmax(O.seeded((2, 6), 52, "randn"), 1)
+    ref.train(); mine.train()
+    out_r = ref(eeg_ref, spec_ref); loss_r = O.kl_div(out_r, labels); loss_r.backward()
+    try:
+        out = mine(eeg, spec); loss = brainxai.KLDivLoss()(out, labels.to(DEV)); loss.backward()
+        assert _sync_err(out, out_r.detach()) < TOL and abs(float(loss) - float(loss_r)) < TOL * abs(float(loss_r))
+        fl = _gscale(ref)
+        for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+            _gclose(p.grad, q.grad, f"native e2e d{n}", tol=TOL, floor=fl)
+    finally:
+        ops.clear_grad_views()
+
+
 def test_dropout_statistics_and_determinism():
     torch.manual_seed(0)
     blk = brainxai.Block(8, 16, "max", (2, 2), dropout_p=0.5).to(DEV).train()
