@@ -228,8 +228,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
         v[2] += __uint_as_float(a2.y << 16); v[3] += __uint_as_float(a2.y & 0xffff0000u);
       }
       uint2 out;
-      out.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-      out.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      out.x = pack2bf(v[0], v[1]);
+      out.y = pack2bf(v[2], v[3]);
       *reinterpret_cast<uint2*>(y + o) = out;
     }
   }
@@ -340,8 +340,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
           v[2] += __uint_as_float(a2.y << 16); v[3] += __uint_as_float(a2.y & 0xffff0000u);
         }
         uint2 out;
-        out.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        out.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        out.x = pack2bf(v[0], v[1]);
+        out.y = pack2bf(v[2], v[3]);
         *reinterpret_cast<uint2*>(y + o) = out;
       }
     }
@@ -461,8 +461,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma_ks(const bf16_t* __restrict__
       v[2] += __uint_as_float(a2.y << 16); v[3] += __uint_as_float(a2.y & 0xffff0000u);
     }
     uint2 out;
-    out.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-    out.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    out.x = pack2bf(v[0], v[1]);
+    out.y = pack2bf(v[2], v[3]);
     *reinterpret_cast<uint2*>(y + o) = out;
   }
 }

@@ -14,6 +14,13 @@
 #define EEG_MAXF 16          // F1*D and F2 upper bound
 #define EEG_MAXCH 64
 
+// eeg_mfma.hip
+size_t bx_eeg_conv1_mfma_lds(int T);
+int bx_eeg_conv1_mfma_launch(const float* x, const float* w1, void* c1, float* partials, int B, int Ch, int T, int want_stats, hipStream_t s);
+size_t bx_eeg_conv1_wgrad_mfma_lds(int T);
+int bx_eeg_conv1_wgrad_mfma_launch(const void* c1, const float* dd, const float* x, const float* dw, const float* mean1, const float* inv1,
+                                   const float* coef, float* w1part, int B, int Ch, int T, int FD, int coef_stride, hipStream_t s);
+
 struct EegGeom {
   int B, Ch, T, F1, D, FD, F2, K1, K2, P1, P2, T1, T2, padl1, padl2;
   size_t off_c1, off_d, off_p1, off_s, off_stats, total;   // saved arena (bytes)
@@ -305,8 +312,15 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
   const float pdrop = tr ? d->dropout_p : 0.f;
   BX_REQUIRE(pdrop == 0.f || seed, "bx_eeg_features_fwd: dropout needs a device seed");
 
-  BX_DISPATCH_DTYPE(d->dtype, T,
-    hipLaunchKernelGGL((k_eeg_conv1<T>), dim3(w.nblk_rows), dim3(EEG_TT), (size_t)(8 * EEG_MAXK + g.T + g.K1 + 8) * sizeof(float), s, x, p->conv1_w, (T*)c1, part, g, tr));
+  // bf16 storage with the reference's 64-tap kernel: the temporal convolution runs on the matrix cores (eeg_mfma.hip)
+  const bool no_mfma = getenv("BX_EEG_NO_MFMA") != nullptr;          // read per call: tests flip it to compare both paths
+  if (d->dtype == BX_BF16 && g.K1 == 64 && !no_mfma && bx_eeg_conv1_mfma_lds(g.T) <= 150 * 1024) {
+    const int rc = bx_eeg_conv1_mfma_launch(x, p->conv1_w, c1, part, g.B, g.Ch, g.T, tr, s);
+    BX_REQUIRE(rc == 0, "bx_eeg_features_fwd: MFMA temporal convolution launch failed (code %d)", rc);
+  } else {
+    BX_DISPATCH_DTYPE(d->dtype, T,
+      hipLaunchKernelGGL((k_eeg_conv1<T>), dim3(w.nblk_rows), dim3(EEG_TT), (size_t)(8 * EEG_MAXK + g.T + g.K1 + 8) * sizeof(float), s, x, p->conv1_w, (T*)c1, part, g, tr));
+  }
   BX_CHECK_LAUNCH("eeg conv1");
   hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(1024), 0, s, part, w.nblk_rows, (double)g.B * g.Ch * g.T, g.F1, tr, p->bn1_w, p->bn1_b,
                      p->bn1_rm, p->bn1_rv, p->bn1_nbt, d->momentum, d->eps, st.sc1, st.sh1, st.mean1, st.inv1);
@@ -861,7 +875,15 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
   hipLaunchKernelGGL(k_eeg_dw_bwd_finalize, dim3(1), dim3(512), 0, s, rpart, g.B, g, tr, p->dw_w, p->bn1_w, st.mean1, st.inv1, st.sc1, st.sh1,
                      gr->dw_w, gr->bn1_w, gr->bn1_b, coef1);
   BX_CHECK_LAUNCH("eeg dw bwd finalize");
-  if (gr->conv1_w || dx) {
+  const bool no_mfma = getenv("BX_EEG_NO_MFMA") != nullptr;
+  if (gr->conv1_w && !dx && d->dtype == BX_BF16 && g.K1 == 64 && !no_mfma && bx_eeg_conv1_wgrad_mfma_lds(g.T) <= 150 * 1024) {
+    // bf16 storage, no input gradient wanted (training): the weight gradient runs on the matrix cores (eeg_mfma.hip)
+    const int rc = bx_eeg_conv1_wgrad_mfma_launch(c1, du2, x, p->dw_w, st.mean1, st.inv1, coef1, w1part, g.B, g.Ch, g.T, g.FD, EEG_MAXF, s);
+    BX_REQUIRE(rc == 0, "bx_eeg_features_bwd: MFMA weight-gradient launch failed (code %d)", rc);
+    BX_CHECK_LAUNCH("eeg conv1 wgrad (mfma)");
+    BX_SUM_PARTIALS(w1part, gr->conv1_w, g.B * g.Ch, 8 * g.K1, s);
+    BX_CHECK_LAUNCH("eeg conv1 wgrad reduce");
+  } else if (gr->conv1_w || dx) {
     const size_t lds = ((size_t)5 * ((g.T + 2 * EEG_MAXK + 3) & ~3) + 4096) * sizeof(float);
     BX_REQUIRE(lds <= 160 * 1024 && g.T <= 256 * EEG_DX_MAX, "bx_eeg_features_bwd: T too long (LDS tile %zu bytes, T <= %d)", lds, 256 * EEG_DX_MAX);
     BX_DISPATCH_DTYPE(d->dtype, T,

@@ -389,6 +389,45 @@ def test_bf16_storage_close_to_fp32_oracle(tag, cfg):
             assert float(cos) > 0.85, (n, float(cos))      # bf16 activations + gradients through 15 conv layers
 
 
+@pytest.mark.parametrize("chans,samples", [(19, 2000), (37, 3000), (5, 1000)])
+def test_eegnet_bf16_mfma_temporal_conv(chans, samples):
+    """bf16 storage runs the 64-tap temporal convolution on the matrix cores (eeg_mfma.hip).  Checked (a) against the VALU
+    kernels of the same storage type (BX_EEG_NO_MFMA=1: the only difference is bf16 rounding of x and of the conv1 weights) and
+    (b) against the fp32 oracle evaluated on bf16-rounded x / conv1 weights, at bf16 resolution"""
+    import os
+    ref, mine = _pair(lambda: O.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0),
+                      lambda: brainxai.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0), 31)
+    brainxai.set_compute_dtype(mine, torch.bfloat16)
+    x = O.seeded((4, 1, chans, samples), 32, "randn")
+    labels = torch.softmax(O.seeded((4, 6), 33, "randn"), 1)
+    with torch.no_grad():
+        w_bf = ref.conv1.weight.bfloat16().float()
+        ref.conv1.weight.copy_(w_bf); mine.conv1.weight.copy_(w_bf.to(DEV))
+    xb = x.bfloat16().float()                       # exactly representable: both GPU paths and the oracle see the same numbers
+    ref.train(); mine.train()
+    out_r = ref(xb); O.kl_div(out_r, labels).backward()
+
+    def run():
+        mine.zero_grad(set_to_none=True)
+        out = mine(xb.to(DEV)); brainxai.KLDivLoss()(out, labels.to(DEV)).backward()
+        return out.detach().float().cpu(), {n: p.grad.detach().float().cpu().clone() for n, p in mine.named_parameters()}
+    try:
+        os.environ["BX_EEG_NO_MFMA"] = "1"
+        out_v, g_v = run()
+        del os.environ["BX_EEG_NO_MFMA"]
+        out_m, g_m = run()
+    finally:
+        os.environ.pop("BX_EEG_NO_MFMA", None)
+        ops.clear_grad_views()
+    assert float((out_m - out_v).abs().max()) < 2e-3 * float(out_v.abs().max()), "MFMA vs VALU forward (same bf16 operands)"
+    assert _sync_err(out_m, out_r.detach()) < 2e-2
+    for n in g_m:
+        if n.startswith("batchnorm1."):
+            continue                                # exactly zero in train mode: pure rounding noise
+        cos = F.cosine_similarity(g_m[n].flatten().double(), g_v[n].flatten().double(), dim=0)
+        assert float(cos) > 0.995, ("mfma vs valu", n, float(cos))
+
+
 def test_full_size_properties():
     """BASELINE shapes (B=64, 4x128x256 + 19x2000): size-independent checks instead of an oracle run."""
     torch.manual_seed(3)
