@@ -76,12 +76,16 @@ __device__ __forceinline__ void st8(bf16_t* p, size_t i, const float v[8]) {
 }
 
 // ---- counter-based dropout mask: keep iff hash(seed, salt, idx) maps above p --------------------
+// 32-bit mixing (murmur3 finaliser over a Weyl sequence of the element index keyed by seed and salt): ~10 VALU
+// instructions per element.  The previous 64-bit splitmix hash cost ~45 (three 64-bit multiplies) and made the pooled-map
+// kernels of the block tail VALU-bound; mask quality for dropout is the same.
 __device__ __forceinline__ uint32_t bx_hash(uint64_t seed, uint32_t salt, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + ((uint64_t)salt << 32 | salt);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (uint32_t)(z >> 32);
+  uint32_t h = (uint32_t)idx * 0x9E3779B1u + (uint32_t)seed;
+  h ^= ((uint32_t)(seed >> 32) + salt * 0x85EBCA77u) ^ ((uint32_t)(idx >> 32) * 0x27D4EB2Fu);
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
 }
 // returns the multiplier applied to an element: 0 or 1/(1-p)
 __device__ __forceinline__ float bx_dropout_scale(uint64_t seed, uint32_t salt, uint64_t idx, float p, float inv_keep) {

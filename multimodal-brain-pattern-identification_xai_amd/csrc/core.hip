@@ -18,9 +18,11 @@ extern "C" const char* bx_last_error_string(void) { return g_err; }
 // each 8-channel group of the pixel is written with 16-byte stores; channels C..Cp-1 are zero.
 template <typename T>
 __global__ void k_nchw_to_nhwc(const float* __restrict__ src, T* __restrict__ dst, int C, int Cp, long long HW, long long npix) {
-  long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= npix) return;
-  const long long b = p / HW, r = p - b * HW;
+  // grid (ceil(HW/256), B): the sample index comes from blockIdx.y, no 64-bit division per thread
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (r >= HW) return;
+  const long long p = b * HW + r;
+  (void)npix;
   for (int c0 = 0; c0 < Cp; c0 += 8) {
     float v[8];
 #pragma unroll
@@ -31,9 +33,10 @@ __global__ void k_nchw_to_nhwc(const float* __restrict__ src, T* __restrict__ ds
 
 template <typename T>
 __global__ void k_nhwc_to_nchw(const T* __restrict__ src, float* __restrict__ dst, int C, int Cs, long long HW, long long npix) {
-  long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= npix) return;
-  const long long b = p / HW, r = p - b * HW;
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (r >= HW) return;
+  const long long p = b * HW + r;
+  (void)npix;
   for (int c0 = 0; c0 < C; c0 += 8) {
     float v[8];
     ld8(src, (size_t)p * Cs + c0, v);
@@ -48,21 +51,21 @@ extern "C" int bx_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H,
   BX_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "bx_nchw_to_nhwc: bad arguments");
   BX_REQUIRE(Cp % 8 == 0 && C <= Cp, "bx_nchw_to_nhwc: Cp must be a multiple of 8 and >= C (C=%d Cp=%d)", C, Cp);
   const long long HW = (long long)H * W, npix = HW * B;
-  const int grid = bx_ceil_div(npix, 256);
+  BX_REQUIRE(B <= 65535, "bx_nchw_to_nhwc: batch %d exceeds the grid's y extent", B);
   hipStream_t s = (hipStream_t)stream;
   BX_DISPATCH_DTYPE(dtype, T,
-    hipLaunchKernelGGL((k_nchw_to_nhwc<T>), dim3(grid), dim3(256), 0, s, src, (T*)dst, C, Cp, HW, npix));
+    hipLaunchKernelGGL((k_nchw_to_nhwc<T>), dim3(bx_ceil_div(HW, 256), B), dim3(256), 0, s, src, (T*)dst, C, Cp, HW, npix));
   BX_CHECK_LAUNCH("bx_nchw_to_nhwc");
   return BX_OK;
 }
 
 extern "C" int bx_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int Cs, int dtype, bxStream stream) {
   BX_DTYPE_OK(dtype);
-  BX_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cs % 8 == 0 && C <= Cs, "bx_nhwc_to_nchw: bad arguments");
+  BX_REQUIRE(src && dst && B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0 && Cs % 8 == 0 && C <= Cs, "bx_nhwc_to_nchw: bad arguments");
   const long long HW = (long long)H * W, npix = HW * B;
   hipStream_t s = (hipStream_t)stream;
   BX_DISPATCH_DTYPE(dtype, T,
-    hipLaunchKernelGGL((k_nhwc_to_nchw<T>), dim3(bx_ceil_div(npix, 256)), dim3(256), 0, s, (const T*)src, dst, C, Cs, HW, npix));
+    hipLaunchKernelGGL((k_nhwc_to_nchw<T>), dim3(bx_ceil_div(HW, 256), B), dim3(256), 0, s, (const T*)src, dst, C, Cs, HW, npix));
   BX_CHECK_LAUNCH("bx_nhwc_to_nchw");
   return BX_OK;
 }

@@ -209,9 +209,10 @@ __global__ void k_eeg_bn_elu_pool(const float* __restrict__ in, const float* __r
   const uint64_t sd = (dropout_p > 0.f && seed) ? seed[0] : 0;
   const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const int to = (int)(i % Tout);
-    const long long bf = i / Tout;
-    const int f = (int)(bf % F);
+    const unsigned i32 = (unsigned)i, bfu = i32 / (unsigned)Tout;      // n < 2^31: 32-bit divisions
+    const int to = (int)(i32 - bfu * (unsigned)Tout);
+    const long long bf = (long long)bfu;
+    const int f = (int)(bfu % (unsigned)F);
     const float a = sc[f], c = sh[f];
     const float* src = in + bf * Tin + (size_t)to * P;
     float s = 0.f;
@@ -409,7 +410,7 @@ __global__ void k_eeg_bn_bwd_finalize(const float* __restrict__ partials, int nb
 __global__ void k_eeg_bn_bwd_apply(float* __restrict__ du, const float* __restrict__ pre, const float* __restrict__ mean,
                                    const float* __restrict__ inv, const float* __restrict__ coef, int F, int Tin, long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const int f = (int)((i / Tin) % F);
+    const int f = (int)(((unsigned)i / (unsigned)Tin) % (unsigned)F);
     du[i] = coef[f] * (du[i] - coef[EEG_MAXF + f] - (pre[i] - mean[f]) * inv[f] * coef[2 * EEG_MAXF + f]);
   }
 }

@@ -22,6 +22,7 @@ static int make_geom(const bxTailDesc* d, TailGeom* g) {
   if (d->B <= 0 || g->Ho <= 0 || g->Wo <= 0) return -1;
   if (d->C % 8 || d->C > 256 || 256 % (d->C / 8)) return -2;
   if (d->Cin_p % 8 || d->Cin_p <= 0) return -3;
+  if ((long long)d->B * d->H * d->W * ((d->Cin_p > d->C ? d->Cin_p : d->C) / 8) >= (1ll << 31)) return -4;   // 32-bit pixel-group indices
   g->ncg = d->C / 8; g->slots = 256 / g->ncg;
   g->npool = (long long)d->B * g->Ho * g->Wo;
   g->sy = (float)d->H / (float)g->Ho; g->sx = (float)d->W / (float)g->Wo;
@@ -35,6 +36,17 @@ static int tail_blocks_all(const TailGeom& g) {
 static int tail_blocks(const TailGeom& g) {
   long long nb = (g.npool + g.slots - 1) / g.slots;
   return (int)(nb > TAIL_MAX_BLOCKS ? TAIL_MAX_BLOCKS : nb);
+}
+
+// pooled-pixel index -> (sample, row, column) with 32-bit unsigned divisions (the launchers check B*H*W < 2^31): the
+// 64-bit / and % these kernels used compile to ~70 VALU instructions each, four per pixel
+__device__ __forceinline__ void px_decode(long long pp, int Wn, int Hn, int& xx, int& yy, int& b) {
+  const unsigned p = (unsigned)pp;
+  const unsigned r = p / (unsigned)Wn;
+  xx = (int)(p - r * (unsigned)Wn);
+  const unsigned bb = r / (unsigned)Hn;
+  yy = (int)(r - bb * (unsigned)Hn);
+  b = (int)bb;
 }
 
 // fixed-order column reduction of NV per-thread 8-vectors through LDS; result for channel c in thread c (< C)
@@ -82,9 +94,8 @@ __global__ __launch_bounds__(256) void k_pool_stats(const T* __restrict__ y3, T*
       const long long pp = pp0 + h * stride;
       ok[h] = pp < g.npool;
       if (ok[h]) {
-        const int ox = (int)(pp % g.Wo);
-        const long long r = pp / g.Wo;
-        const int oy = (int)(r % g.Ho), b = (int)(r / g.Ho);
+        int ox, oy, b;
+        px_decode(pp, g.Wo, g.Ho, ox, oy, b);
         const size_t base = (((size_t)b * g.H + 2 * oy) * g.W + 2 * ox) * g.C + cg * 8;
         ld8(y3, base, w[h][0]); ld8(y3, base + g.C, w[h][1]);
         ld8(y3, base + (size_t)g.W * g.C, w[h][2]); ld8(y3, base + (size_t)g.W * g.C + g.C, w[h][3]);
@@ -154,10 +165,10 @@ __global__ __launch_bounds__(256) void k_tail_apply(const T* __restrict__ pooled
       const int sl = u / nci8, c8 = u % nci8;
       const long long pp = p0 + sl;
       if (pp < g.npool) {
-        const int ox = (int)(pp % g.Wo);
-        const long long r = pp / g.Wo;
+        int ox, oy, b;
+        px_decode(pp, g.Wo, g.Ho, ox, oy, b);
         float v[8];
-        skip_sample(x, g, (int)(r / g.Ho), (int)(r % g.Ho), ox, c8 * 8, v);
+        skip_sample(x, g, b, oy, ox, c8 * 8, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) xs[sl * xstride + c8 * 8 + j] = v[j];
       }
@@ -318,9 +329,8 @@ __global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ do
   }
   const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (long long pp = (long long)blockIdx.x * g.slots + slot; pp < g.npool; pp += (long long)gridDim.x * g.slots) {
-    const int ox = (int)(pp % g.Wo);
-    const long long r = pp / g.Wo;
-    const int oy = (int)(r % g.Ho), b = (int)(r / g.Ho);
+    int ox, oy, b;
+    px_decode(pp, g.Wo, g.Ho, ox, oy, b);
     float go[8], pv[8], dp[8];
     ld8(dout, (size_t)pp * g.C + cg * 8, go);
     ld8(pooled, (size_t)pp * g.C + cg * 8, pv);
@@ -369,8 +379,9 @@ __global__ __launch_bounds__(256) void k_skip_dxs(const T* __restrict__ dout, co
   const long long n = g.npool * nci8;
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
   const bool live = u < n;
-  const long long pp = live ? u / nci8 : 0;
-  const int c8 = live ? (int)(u % nci8) : 0;
+  const unsigned u32 = live ? (unsigned)u : 0u;
+  const long long pp = (long long)(u32 / (unsigned)nci8);
+  const int c8 = (int)(u32 - (unsigned)pp * (unsigned)nci8);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int cb = 0; cb < g.C; cb += 64) {
     const int nc = g.C - cb < 64 ? g.C - cb : 64;
@@ -414,9 +425,8 @@ __global__ __launch_bounds__(256) void k_skip_dxs(const T* __restrict__ dout, co
   if (live) {
     if (dx_even) {
       // H and W even: bilinear-to-half is the 2x2 mean, its transpose spreads dXs/4 over the 2x2 footprint
-      const int ox = (int)(pp % g.Wo);
-      const long long r = pp / g.Wo;
-      const int oy = (int)(r % g.Ho), b = (int)(r / g.Ho);
+      int ox, oy, b;
+      px_decode(pp, g.Wo, g.Ho, ox, oy, b);
       float q[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) q[j] = 0.25f * acc[j];
@@ -450,11 +460,10 @@ __global__ __launch_bounds__(256) void k_skip_scatter(const float* __restrict__ 
   const int nci8 = g.Cin_p / 8;
   const long long n = (long long)g.B * g.H * g.W * nci8;
   for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < n; u += (long long)gridDim.x * 256) {
-    const int c8 = (int)(u % nci8);
-    const long long p = u / nci8;
-    const int xx = (int)(p % g.W);
-    const long long r = p / g.W;
-    const int yy = (int)(r % g.H), b = (int)(r / g.H);
+    const unsigned u32 = (unsigned)u, p = u32 / (unsigned)nci8;
+    const int c8 = (int)(u32 - p * (unsigned)nci8);
+    int xx, yy, b;
+    px_decode((long long)p, g.W, g.H, xx, yy, b);
     int iy[4], ix[4]; float wy[4], wx[4];
     const int ny = bilinear_T_taps(yy, g.sy, g.H, g.Ho, iy, wy), nx = bilinear_T_taps(xx, g.sx, g.W, g.Wo, ix, wx);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -494,9 +503,9 @@ __global__ __launch_bounds__(256) void k_w1x1_grad(const T* __restrict__ dout, c
       if (is_d) {
         ld8(dout, (size_t)pp * g.C + c0 + half * 8, v);
       } else if (ci0 + half * 8 < g.Cin_p) {
-        const int ox = (int)(pp % g.Wo);
-        const long long r = pp / g.Wo;
-        skip_sample(x, g, (int)(r / g.Ho), (int)(r % g.Ho), ox, ci0 + half * 8, v);
+        int ox, oy, b;
+        px_decode(pp, g.Wo, g.Ho, ox, oy, b);
+        skip_sample(x, g, b, oy, ox, ci0 + half * 8, v);
       }
     }
   };
