@@ -131,17 +131,20 @@ __device__ __forceinline__ void bilinear_src(int o, float scale, int in_size, in
 }
 
 // Sum NV per-workgroup partial vectors in double, fixed order: partial k, vector v, channel c lives at
-// partials[(k*NV + v)*C + c].  256 threads: thread = (slice, channel); slices are combined through LDS in
-// slice order, so the result is deterministic.  Returns the totals in out[] for threads < C.
+// partials[(k*NV + v)*C + c].  The calling workgroup owns channels c0 .. c0+CG-1 (CG divides blockDim): thread =
+// (slice, channel); slices are combined through LDS in slice order, so the result is deterministic.  Returns the totals
+// in out[] for threads < CG (channel c0 + threadIdx.x).  One workgroup per 16 channels keeps a thread's chain of partial
+// loads short (a single 1024-thread workgroup over 256 channels walked 128 partials per thread).
 template <int NV>
-__device__ __forceinline__ void sum_partials_256(const float* __restrict__ partials, int nblk, int C, double out[NV]) {
+__device__ __forceinline__ void sum_partials_256(const float* __restrict__ partials, int nblk, int C, int c0, int CG, double out[NV]) {
   __shared__ double sp[NV][1024];
-  const int nslice = (int)blockDim.x / C;  // C in {8,16,...,256}; blockDim 256..1024
-  const int c = threadIdx.x % C, slice = threadIdx.x / C;
+  const int nslice = (int)blockDim.x / CG;
+  const int cc = threadIdx.x % CG, slice = threadIdx.x / CG;
+  const int c = c0 + cc;
   double acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = 0.0;
-  if (slice < nslice) {
+  if (slice < nslice && c < C) {
     int k = slice;
     for (; k + 3 * nslice < nblk; k += 4 * nslice) {        // 4*NV independent loads in flight; adds stay in k order
       float t[4][NV];
@@ -161,15 +164,17 @@ __device__ __forceinline__ void sum_partials_256(const float* __restrict__ parti
 #pragma unroll
   for (int v = 0; v < NV; ++v) sp[v][threadIdx.x] = acc[v];
   __syncthreads();
-  if ((int)threadIdx.x < C) {
+  if ((int)threadIdx.x < CG) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       double s = 0.0;
-      for (int sl = 0; sl < nslice; ++sl) s += sp[v][sl * C + threadIdx.x];
+      for (int sl = 0; sl < nslice; ++sl) s += sp[v][sl * CG + threadIdx.x];
       out[v] = s;
     }
   }
 }
+static inline int bx_finalize_cg(int C) { return C < 16 ? C : 16; }      // channels per finalize workgroup
+static inline int bx_finalize_grid(int C) { const int cg = bx_finalize_cg(C); return (C + cg - 1) / cg; }
 
 // forward 2: statistics -> (scale, shift); running-stat update (unbiased variance, momentum).  Launch with 256 threads.
 static __global__ void k_bn_finalize(const float* __restrict__ partials, int nblk, double count, int C, int training,
@@ -178,9 +183,10 @@ static __global__ void k_bn_finalize(const float* __restrict__ partials, int nbl
                               float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
                               float* __restrict__ save_invstd) {
   double tot[2] = {0.0, 0.0};
-  if (training) sum_partials_256<2>(partials, nblk, C, tot);
-  const int c = threadIdx.x;
-  if (c >= C) return;
+  const int CG = C < 16 ? C : 16, c0 = blockIdx.x * CG;            // grid = bx_finalize_grid(C)
+  if (training) sum_partials_256<2>(partials, nblk, C, c0, CG, tot);
+  const int c = c0 + threadIdx.x;
+  if ((int)threadIdx.x >= CG || c >= C) return;
   float mean, invstd;
   if (training) {
     const double m = tot[0] / count;

@@ -89,10 +89,12 @@ __global__ __launch_bounds__(256) void k_pack_mfma_many(const bxPackJob* __restr
       const size_t idx = i0 + u * 256;
       v[u] = 0.f;
       if (idx < n) {
-        const int kk = (int)(idx & 31);
-        const int o = (int)((idx >> 5) % jb.O_p);
-        const int s = (int)((idx / ((size_t)32 * jb.O_p)) % ks);
-        const int chunk = (int)(idx / ((size_t)32 * jb.O_p * ks));
+        const unsigned i32 = (unsigned)idx, row = i32 >> 5;          // n < 2^31: 32-bit divisions (64-bit ones cost ~70 instructions each)
+        const int kk = (int)(i32 & 31);
+        const unsigned so = row / (unsigned)jb.O_p;
+        const int o = (int)(row - so * (unsigned)jb.O_p);
+        const int chunk = (int)(so / (unsigned)ks);
+        const int s = (int)(so - (unsigned)chunk * (unsigned)ks);
         const int q = s * 32 + kk, tap = q / ck, i = chunk * ck + q % ck;
         if (tap < 9) {
           if (!jb.transpose_flip) { if (i < jb.Cin && o < jb.Cout) v[u] = w[((size_t)o * jb.Cin + i) * 9 + tap]; }

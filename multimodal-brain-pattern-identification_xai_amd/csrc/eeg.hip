@@ -323,14 +323,14 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
       hipLaunchKernelGGL((k_eeg_conv1<T>), dim3(w.nblk_rows), dim3(EEG_TT), (size_t)(8 * EEG_MAXK + g.T + g.K1 + 8) * sizeof(float), s, x, p->conv1_w, (T*)c1, part, g, tr));
   }
   BX_CHECK_LAUNCH("eeg conv1");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(1024), 0, s, part, w.nblk_rows, (double)g.B * g.Ch * g.T, g.F1, tr, p->bn1_w, p->bn1_b,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.F1)), dim3(1024), 0, s, part, w.nblk_rows, (double)g.B * g.Ch * g.T, g.F1, tr, p->bn1_w, p->bn1_b,
                      p->bn1_rm, p->bn1_rv, p->bn1_nbt, d->momentum, d->eps, st.sc1, st.sh1, st.mean1, st.inv1);
   BX_CHECK_LAUNCH("eeg bn1");
   dim3 gdw(bx_ceil_div(g.T, 256), g.B);
   BX_DISPATCH_DTYPE(d->dtype, T,
     hipLaunchKernelGGL((k_eeg_dw<T>), gdw, dim3(256), 0, s, (const T*)c1, p->dw_w, st.sc1, st.sh1, dmap, part, g, tr));
   BX_CHECK_LAUNCH("eeg depthwise");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(1024), 0, s, part, (int)(gdw.x * gdw.y), (double)g.B * g.T, g.FD, tr, p->bn2_w, p->bn2_b,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.FD)), dim3(1024), 0, s, part, (int)(gdw.x * gdw.y), (double)g.B * g.T, g.FD, tr, p->bn2_w, p->bn2_b,
                      p->bn2_rm, p->bn2_rv, p->bn2_nbt, d->momentum, d->eps, st.sc2, st.sh2, st.mean2, st.inv2);
   BX_CHECK_LAUNCH("eeg bn2");
   {
@@ -342,7 +342,7 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
   dim3 gsep(bx_ceil_div(g.T1, SEP_TT), g.B);
   hipLaunchKernelGGL(k_eeg_sep, gsep, dim3(256), 0, s, p1, p->sep_w, smap, part, g, tr);
   BX_CHECK_LAUNCH("eeg sepconv");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(1024), 0, s, part, (int)(gsep.x * gsep.y), (double)g.B * g.T1, g.F2, tr, p->bn3_w, p->bn3_b,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.F2)), dim3(1024), 0, s, part, (int)(gsep.x * gsep.y), (double)g.B * g.T1, g.F2, tr, p->bn3_w, p->bn3_b,
                      p->bn3_rm, p->bn3_rv, p->bn3_nbt, d->momentum, d->eps, st.sc3, st.sh3, st.mean3, st.inv3);
   BX_CHECK_LAUNCH("eeg bn3");
   {
@@ -397,7 +397,7 @@ __global__ void k_eeg_bn_bwd_finalize(const float* __restrict__ partials, int nb
                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
   // partial layout [blk][2][16] regardless of F
   double s[2] = {0.0, 0.0};
-  sum_partials_256<2>(partials, nblk, 16, s);
+  sum_partials_256<2>(partials, nblk, 16, 0, 16, s);
   const int f = threadIdx.x;
   if (f >= F) return;
   if (dbeta) dbeta[f] = (float)s[0];

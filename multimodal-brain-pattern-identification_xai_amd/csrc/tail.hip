@@ -243,7 +243,7 @@ extern "C" int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void
     hipLaunchKernelGGL((k_pool_stats<T>), dim3(nblk), dim3(256), 0, s, (const T*)y3, (T*)pooled, partials, g, d->pool, d->training,
                        w1x1, Cin, wT));
   BX_CHECK_LAUNCH("bx_block_tail_fwd(pool)");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(1024), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight, bn_bias,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.C)), dim3(1024), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight, bn_bias,
                      running_mean, running_var, num_batches_tracked, d->momentum, d->eps, scale, shift, save_mean, save_invstd);
   BX_CHECK_LAUNCH("bx_block_tail_fwd(finalize)");
   BX_DISPATCH_DTYPE(d->dtype, T,
@@ -302,9 +302,10 @@ __global__ void k_tail_bwd_finalize(const float* __restrict__ partials, int nblk
                                     const float* __restrict__ gamma, const float* __restrict__ invstd, float* __restrict__ coef,
                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db1x1) {
   double s[3] = {0.0, 0.0, 0.0};
-  sum_partials_256<3>(partials, nblk, C, s);
-  const int c = threadIdx.x;
-  if (c >= C) return;
+  const int CG = C < 16 ? C : 16, c0 = blockIdx.x * CG;            // grid = bx_finalize_grid(C)
+  sum_partials_256<3>(partials, nblk, C, c0, CG, s);
+  const int c = c0 + threadIdx.x;
+  if ((int)threadIdx.x >= CG || c >= C) return;
   if (dbeta) dbeta[c] = (float)s[0];
   if (dgamma) dgamma[c] = (float)s[1];
   if (db1x1) db1x1[c] = (float)s[2];
@@ -556,7 +557,7 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
     hipLaunchKernelGGL((k_tail_bwd_reduce<T>), dim3(nblk), dim3(256), 0, s, (const T*)dout, (const T*)pooled, save_mean, save_invstd,
                        seed, p, d->salt, partials, g));
   BX_CHECK_LAUNCH("bx_block_tail_bwd(reduce)");
-  hipLaunchKernelGGL(k_tail_bwd_finalize, dim3(1), dim3(1024), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight,
+  hipLaunchKernelGGL(k_tail_bwd_finalize, dim3(bx_finalize_grid(g.C)), dim3(1024), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight,
                      save_invstd, coef, d_bn_weight, d_bn_bias, d_b1x1);
   BX_CHECK_LAUNCH("bx_block_tail_bwd(finalize)");
   BX_DISPATCH_DTYPE(d->dtype, T,
