@@ -66,7 +66,7 @@ static EegWs eeg_ws(const EegGeom& g) {
   const int rows = g.B * g.Ch;
   w.nblk_rows = rows;
   size_t npart = (size_t)w.nblk_rows;
-  const size_t n_dw = (size_t)g.B * ((g.T + 255) / 256), n_sep = (size_t)g.B * ((g.T1 + 255) / 256);
+  const size_t n_dw = (size_t)g.B * ((g.T + 127) / 128), n_sep = (size_t)g.B * ((g.T1 + 255) / 256);
   if (npart < n_dw) npart = n_dw;
   if (npart < n_sep) npart = n_sep;
   if (npart < (size_t)g.B) npart = (size_t)g.B;
@@ -157,46 +157,64 @@ __global__ __launch_bounds__(EEG_TT) void k_eeg_conv1(const float* __restrict__ 
     partials[(size_t)blockIdx.x * 16 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// E2: BN1 apply + depthwise electrode mix; thread per (b, t) produces all FD maps.  grid (ceil(T/256), B)
-template <typename T>
-__global__ __launch_bounds__(256) void k_eeg_dw(const T* __restrict__ c1, const float* __restrict__ dw, const float* __restrict__ sc1,
+// E2: BN1 apply + depthwise electrode mix.  A thread owns DWV consecutive time steps (8-byte c1 loads for bf16 when
+// T % 4 == 0, else one step) and produces all FD maps for them.  grid (ceil(T / (128*DWV)), B), 128 threads.
+template <typename T, int DWV>
+__global__ __launch_bounds__(128) void k_eeg_dw(const T* __restrict__ c1, const float* __restrict__ dw, const float* __restrict__ sc1,
                                                  const float* __restrict__ sh1, float* __restrict__ dmap, float* __restrict__ partials,
                                                  EegGeom g, int want_stats) {
   __shared__ float sdw[EEG_MAXF * EEG_MAXCH];
-  __shared__ float red[4][32];
-  for (int i = threadIdx.x; i < g.FD * g.Ch; i += 256) sdw[i] = dw[i];
+  __shared__ float red[2][32];
+  for (int i = threadIdx.x; i < g.FD * g.Ch; i += 128) sdw[i] = dw[i];
   __syncthreads();
-  const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
-  float out[EEG_MAXF];
+  const int b = blockIdx.y, t0 = (blockIdx.x * 128 + threadIdx.x) * DWV;
+  float ssum[EEG_MAXF], ssq[EEG_MAXF];
 #pragma unroll
-  for (int i = 0; i < EEG_MAXF; ++i) out[i] = 0.f;
-  if (t < g.T) {
+  for (int i = 0; i < EEG_MAXF; ++i) ssum[i] = ssq[i] = 0.f;
+  if (t0 < g.T) {
 #pragma unroll
     for (int f = 0; f < 8; ++f) {
       const float a = sc1[f], c = sh1[f];
-      float o0 = 0.f, o1 = 0.f;
+      float o0[DWV], o1[DWV];
+#pragma unroll
+      for (int j = 0; j < DWV; ++j) o0[j] = o1[j] = 0.f;
+      const size_t rb = (((size_t)b * g.F1 + f) * g.Ch) * g.T + t0;
       for (int ch = 0; ch < g.Ch; ++ch) {
-        const float v = ldf(c1, (((size_t)b * g.F1 + f) * g.Ch + ch) * g.T + t) * a + c;
-        o0 = fmaf(sdw[(2 * f) * g.Ch + ch], v, o0);
-        o1 = fmaf(sdw[(2 * f + 1) * g.Ch + ch], v, o1);
+        float v[DWV];
+        if (DWV == 4) ld4(c1, rb + (size_t)ch * g.T, v);
+        else v[0] = ldf(c1, rb + (size_t)ch * g.T);
+        const float w0 = sdw[(2 * f) * g.Ch + ch], w1 = sdw[(2 * f + 1) * g.Ch + ch];
+#pragma unroll
+        for (int j = 0; j < DWV; ++j) {
+          const float u = v[j] * a + c;
+          o0[j] = fmaf(w0, u, o0[j]);
+          o1[j] = fmaf(w1, u, o1[j]);
+        }
       }
-      out[2 * f] = o0; out[2 * f + 1] = o1;
-      dmap[((size_t)b * g.FD + 2 * f) * g.T + t] = o0;
-      dmap[((size_t)b * g.FD + 2 * f + 1) * g.T + t] = o1;
+      float* d0 = dmap + ((size_t)b * g.FD + 2 * f) * g.T + t0;
+      if (DWV == 4) {
+        *reinterpret_cast<float4*>(d0) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+        *reinterpret_cast<float4*>(d0 + g.T) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+      } else {
+        d0[0] = o0[0]; d0[g.T] = o1[0];
+      }
+#pragma unroll
+      for (int j = 0; j < DWV; ++j) {
+        ssum[2 * f] += o0[j]; ssq[2 * f] += o0[j] * o0[j];
+        ssum[2 * f + 1] += o1[j]; ssq[2 * f + 1] += o1[j] * o1[j];
+      }
     }
   }
   if (!want_stats) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int i = 0; i < EEG_MAXF; ++i) {
-    const float s = wave_sum(out[i]), q = wave_sum(out[i] * out[i]);
+    const float s = wave_sum(ssum[i]), q = wave_sum(ssq[i]);
     if (lane == 0) { red[wave][i] = s; red[wave][16 + i] = q; }
   }
   __syncthreads();
-  if (threadIdx.x < 32) {
-    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + threadIdx.x] = v;   // [blk][2][16]
-  }
+  if (threadIdx.x < 32)
+    partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x];   // [blk][2][16]
 }
 
 __device__ __forceinline__ float elu1(float u) { return u > 0.f ? u : expm1f(u); }
@@ -326,9 +344,11 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
   hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.F1)), dim3(1024), 0, s, part, w.nblk_rows, (double)g.B * g.Ch * g.T, g.F1, tr, p->bn1_w, p->bn1_b,
                      p->bn1_rm, p->bn1_rv, p->bn1_nbt, d->momentum, d->eps, st.sc1, st.sh1, st.mean1, st.inv1);
   BX_CHECK_LAUNCH("eeg bn1");
-  dim3 gdw(bx_ceil_div(g.T, 256), g.B);
+  const int dwv = (g.T % 4 == 0) ? 4 : 1;
+  dim3 gdw(bx_ceil_div(g.T, 128 * dwv), g.B);
   BX_DISPATCH_DTYPE(d->dtype, T,
-    hipLaunchKernelGGL((k_eeg_dw<T>), gdw, dim3(256), 0, s, (const T*)c1, p->dw_w, st.sc1, st.sh1, dmap, part, g, tr));
+    if (dwv == 4) hipLaunchKernelGGL((k_eeg_dw<T, 4>), gdw, dim3(128), 0, s, (const T*)c1, p->dw_w, st.sc1, st.sh1, dmap, part, g, tr);
+    else hipLaunchKernelGGL((k_eeg_dw<T, 1>), gdw, dim3(128), 0, s, (const T*)c1, p->dw_w, st.sc1, st.sh1, dmap, part, g, tr));
   BX_CHECK_LAUNCH("eeg depthwise");
   hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.FD)), dim3(1024), 0, s, part, (int)(gdw.x * gdw.y), (double)g.B * g.T, g.FD, tr, p->bn2_w, p->bn2_b,
                      p->bn2_rm, p->bn2_rv, p->bn2_nbt, d->momentum, d->eps, st.sc2, st.sh2, st.mean2, st.inv2);
