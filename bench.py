@@ -257,8 +257,25 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt)
+        eager_maps = world * reps * maps.shape[0] * maps.shape[1] / dt
+        # the sweep form: the same launches replayed from a hipGraph (what a 10 000-sample sweep uses)
+        sweep = brainxai.GradCamSweep(model, eeg, spec, class_idx="all")
+        sweep(eeg, spec)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            maps = sweep(eeg, spec)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt)
         gradcam = {"maps_per_sec": round(world * reps * maps.shape[0] * maps.shape[1] / dt, 1),
-                   "samples_per_sec": round(world * reps * B / dt, 1), "classes": int(maps.shape[1]), "target": "spectrogram_model.block5"}
+                   "samples_per_sec": round(world * reps * B / dt, 1), "classes": int(maps.shape[1]), "target": "spectrogram_model.block5",
+                   "mode": "hipGraph sweep (GradCamSweep); eager grad_cam() calls: %.0f maps/s" % eager_maps}
+        del sweep
         # configs[4]-style integrated gradients (n_steps=50, zero baselines) on 8 samples of the batch: 50 fwd + dgrad sweeps
         ig_in = (eeg[:8], spec[:8])
         brainxai.integrated_gradients(model, ig_in, None, n_steps=50)

@@ -6,7 +6,7 @@ not an importable identifier); ``import brainxai`` (the shim at the repo root) l
 from . import _lib, ops                                                       # noqa: F401
 from .models import (Block, EEGNet, KLDivLoss, MultimodalModel, Spectrogram_Model,   # noqa: F401
                      build_multimodal, set_compute_dtype)
-from .explain import expected_gradients, generate_saliency_maps, grad_cam, integrated_gradients, saliency   # noqa: F401
+from .explain import GradCamSweep, expected_gradients, generate_saliency_maps, grad_cam, integrated_gradients, saliency   # noqa: F401
 from .data import (EEGStacker, stack_eeg, EEGMontageStacker, stack_eeg_montage,          # noqa: F401
                    SpectrogramPreprocessor, preprocess_spectrograms)                                        # noqa: F401
 from .train import (FlatAdamW, DataParallel, train_and_validate_combined, train_and_validate_eeg_distributed,   # noqa: F401

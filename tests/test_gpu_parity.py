@@ -428,6 +428,23 @@ def test_eegnet_bf16_mfma_temporal_conv(chans, samples):
         assert float(cos) > 0.995, ("mfma vs valu", n, float(cos))
 
 
+def test_gradcam_sweep_matches_eager():
+    """the hipGraph form of the default-target Grad-CAM replays the same launches: bit-identical maps, new inputs each call"""
+    torch.manual_seed(5)
+    net = brainxai.build_multimodal(19, 2000, 4, dropout=0.5).to(DEV).train()
+    eeg, spec = torch.randn(4, 1, 19, 2000, device=DEV), torch.rand(4, 4, 64, 128, device=DEV)
+    sweep = brainxai.GradCamSweep(net, eeg, spec, class_idx="all")
+    assert net.training, "the sweep leaves the module's mode alone"
+    for seed in (1, 2):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        e2, s2 = torch.randn(4, 1, 19, 2000, generator=g).to(DEV), torch.rand(4, 4, 64, 128, generator=g).to(DEV)
+        got = sweep(e2, s2).clone()
+        want = brainxai.grad_cam(net, e2, s2, class_idx="all")
+        assert got.shape == want.shape == (4, 6, 64, 128) and torch.equal(got, want)
+    with pytest.raises(RuntimeError, match="captured for"):
+        sweep(eeg[:2], spec[:2])
+
+
 def test_full_size_properties():
     """BASELINE shapes (B=64, 4x128x256 + 19x2000): size-independent checks instead of an oracle run."""
     torch.manual_seed(3)
