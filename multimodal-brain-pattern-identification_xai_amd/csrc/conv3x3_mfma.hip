@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const bf16_t* __restrict_
     int H, int W, int Ci_p, int Co, int tiles_x, int tiles_y, int ntiles, int tiles_per_split) {
   constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CIT = 16 * MA, COT = 16 * NB, XB = CIT * 2, ZB = COT * 2;
   constexpr int KPW = TH * TW / 32 / 4;                 // K-steps (32 pixels) per wave per tile
-  constexpr int XS_BYTES = HH * HWID * XB, ZS_BYTES = TH * TW * ZB;
+  constexpr int XS_BYTES = HH * HWID * XB;             // the dZ tile (TH * TW * ZB bytes) follows the halo tile
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* xs = lds;
   char* zs = lds + XS_BYTES;

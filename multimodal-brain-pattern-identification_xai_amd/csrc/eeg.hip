@@ -667,8 +667,6 @@ __global__ __launch_bounds__(256) void k_eeg_conv1_bwd(const T* __restrict__ c1,
   float dxa[EEG_DX_MAX];
 #pragma unroll
   for (int k = 0; k < EEG_DX_MAX; ++k) dxa[k] = 0.f;
-  const int tid = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int ff = tid >> 4, k0 = (tid & 15) * 4;
   for (int fg = 0; fg < 2; ++fg) {
     __syncthreads();
     if ((Tn & 3) == 0) {
