@@ -445,6 +445,33 @@ def test_gradcam_sweep_matches_eager():
         sweep(eeg[:2], spec[:2])
 
 
+def test_graphed_train_step_matches_eager():
+    """GraphedTrainStep (eager first batch, capture on the second, replay afterwards) walks the same trajectory as eager steps"""
+    def make():
+        torch.manual_seed(9)
+        m = brainxai.build_multimodal(19, 2000, 4, dropout=0.5).to(DEV).train()
+        return m, brainxai.FlatAdamW(m.parameters(), lr=1e-3)
+    batches = [((O.seeded((4, 1, 19, 2000), 90 + i, "randn").to(DEV), O.seeded((4, 4, 32, 64), 95 + i, "rand").to(DEV)),
+                torch.softmax(O.seeded((4, 6), 99 + i, "randn"), 1).to(DEV)) for i in range(5)]
+    crit = brainxai.KLDivLoss()
+    try:
+        m1, o1 = make(); ops.manual_seed(1234)
+        eager = []
+        for (e, s), y in batches:
+            loss, _ = brainxai.train_step(m1, o1, e, s, y, crit); eager.append(float(loss))
+        p1 = torch.cat([p.detach().flatten() for p in m1.parameters()]).clone()
+        ops.clear_grad_views()
+        m2, o2 = make(); ops.manual_seed(1234)
+        step = brainxai.GraphedTrainStep(m2, o2, crit)
+        graphed = [float(step([e, s], y)[0]) for (e, s), y in batches]
+        p2 = torch.cat([p.detach().flatten() for p in m2.parameters()])
+        assert step.enabled and len(step._graphs) == 1
+        np.testing.assert_allclose(graphed, eager, rtol=1e-5)
+        assert float((p1 - p2).abs().max()) < 1e-6
+    finally:
+        ops.clear_grad_views()
+
+
 def test_full_size_properties():
     """BASELINE shapes (B=64, 4x128x256 + 19x2000): size-independent checks instead of an oracle run."""
     torch.manual_seed(3)
