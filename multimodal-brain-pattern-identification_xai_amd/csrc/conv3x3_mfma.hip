@@ -18,6 +18,8 @@
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 static inline int mfma_ck(int Ci) { return Ci < 64 ? Ci : 64; }
 static inline int mfma_ks(int ck) { return (9 * ck + 31) / 32; }
@@ -126,7 +128,7 @@ __device__ __forceinline__ int lds_chunk(int c, int p) {
 template <int CK, int NC, int TW>
 __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const bf16_t* __restrict__ mask_src, const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
-    int H, int W, int Ci, int Co, int relu, int tiles_x, int tiles_y) {
+    int H, int W, int Ci, int Co, int relu, int tiles_x, int tiles_y, uint32_t x_bytes) {
   constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CKB = CK * 2, NCH = CK / 8, KS = (9 * CK + 31) / 32;
   constexpr int MP = TH * TW / 64;          // 16-pixel tiles per wave
   constexpr int TPR = TW / 16;              // 16-pixel tiles per tile row
@@ -146,16 +148,25 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   // staging: every thread issues ALL of its 16-byte global loads before the first LDS write (a rolled
   // load->wait->write loop serialises one HBM round trip per iteration)
   constexpr int NU = HH * HWID * NCH, NR = (NU + 255) / 256;
+  // halo loads through a raw buffer resource (out-of-image lanes point past the end and read zeros): no divergent
+  // branches, 32-bit offsets, per-thread invariants hoisted out of the chunk loop (see k_conv_mfma_p)
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
+  uint32_t hoff[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int u = threadIdx.x + k * 256;
+    const int p = u / NCH, c = u % NCH;
+    const int iy = y0 + p / HWID - 1, ix = x0 + p % HWID - 1;
+    const bool ok = u < NU && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    hoff[k] = ok ? (uint32_t)((((b * H + iy) * W + ix) * Ci + c * 8) * 2) : 0x80000000u;
+  }
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     uint4 rv[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      const int u = threadIdx.x + k * 256;
-      const int p = u / NCH, c = u % NCH;
-      const int iy = y0 + p / HWID - 1, ix = x0 + p % HWID - 1;
-      rv[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (u < NU && iy >= 0 && iy < H && ix >= 0 && ix < W)
-        rv[k] = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * Ci + chunk * CK + c * 8);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xres, hoff[k], 0, 0);
+      rv[k] = make_uint4(v.x, v.y, v.z, v.w);
+      hoff[k] += (uint32_t)(CK * 2);                          // next chunk of input channels (an invalid lane stays >= 2^31)
     }
     const bf16_t* wchunk = wp + (size_t)chunk * KS * Co * 32;
     // weight fragments run two K-steps ahead of the MFMAs that consume them (L2 latency >> one K-step)
@@ -198,41 +209,45 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
       }
     }
   }
-  // epilogue: lane = (pixel li of tile t, output channels co_base + n*16 + 4g .. +3)
+  // epilogue: lane = (pixel li of tile t, output channels co_base + n*16 + 4g .. +3).  y / mask / addend share one shape:
+  // 32-bit byte offsets through buffer resources, out-of-image lanes point past the end (loads read 0, stores are dropped)
+  const uint32_t y_bytes = (uint32_t)((size_t)gridDim.x / (tiles_x * tiles_y) * H * W * Co * 2);
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src ? mask_src : y), 0, y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend : y), 0, y_bytes, 0x00020000);
   float4 bz[NC];
 #pragma unroll
   for (int n = 0; n < NC; ++n)
     bz[n] = bias ? *reinterpret_cast<const float4*>(bias + co_base + n * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint32_t lane_off = (uint32_t)((((b * H + y0) * W + x0 + li) * Co + co_base + 4 * g) * 2);
 #pragma unroll
   for (int i = 0; i < MP; ++i) {
     const int t = wave * MP + i;
     const int oy = y0 + t / TPR, ox = x0 + (t % TPR) * 16 + li;
-    if (oy >= H || ox >= W) continue;
+    const bool inb = oy < H && ox < W;
+    const uint32_t orow = lane_off + (uint32_t)((((t / TPR) * W + (t % TPR) * 16) * Co) * 2);
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
-      const int co = co_base + n * 16 + 4 * g;
-      const size_t o = (((size_t)b * H + oy) * W + ox) * Co + co;
+      const uint32_t off = inb ? orow + (uint32_t)(n * 32) : 0x80000000u;
       float v[4] = {acc[i][n][0] + bz[n].x, acc[i][n][1] + bz[n].y, acc[i][n][2] + bz[n].z, acc[i][n][3] + bz[n].w};
       if (relu) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
       if (mask_src) {
-        const uint2 m = *reinterpret_cast<const uint2*>(mask_src + o);
+        const u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(mres, off, 0, 0);
         // bf16 > 0  <=>  sign bit clear and magnitude non-zero
         const uint32_t mm[4] = {m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16};
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (mm[r] != 0u && mm[r] < 0x8000u) ? v[r] : 0.f;
       }
       if (addend) {
-        const uint2 a2 = *reinterpret_cast<const uint2*>(addend + o);
+        const u32x2 a2 = __builtin_amdgcn_raw_buffer_load_b64(ares, off, 0, 0);
         v[0] += __uint_as_float(a2.x << 16); v[1] += __uint_as_float(a2.x & 0xffff0000u);
         v[2] += __uint_as_float(a2.y << 16); v[3] += __uint_as_float(a2.y & 0xffff0000u);
       }
-      uint2 out;
-      out.x = pack2bf(v[0], v[1]);
-      out.y = pack2bf(v[2], v[3]);
-      *reinterpret_cast<uint2*>(y + o) = out;
+      const u32x2 out = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      __builtin_amdgcn_raw_buffer_store_b64(out, yres, off, 0, 0);
     }
   }
 }
@@ -244,7 +259,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
 template <int CK, int NC, int TW>
 __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const bf16_t* __restrict__ mask_src, const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
-    int H, int W, int Co, int relu, int tiles_x, int tiles_y, int ntiles) {
+    int H, int W, int Co, int relu, int tiles_x, int tiles_y, int ntiles, uint32_t x_bytes) {
   constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CKB = CK * 2, NCH = CK / 8, KS = (9 * CK + 31) / 32;
   constexpr int MP = TH * TW / 64, TPR = TW / 16;
   constexpr int NU = HH * HWID * NCH, NR = (NU + 255) / 256;
@@ -252,18 +267,38 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
   const int co_base = blockIdx.y * (NC * 16);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
   uint4 rv[NR];
+  // Halo loads go through a raw buffer resource over x: a lane whose pixel is outside the image sets its byte offset past
+  // the end and the load returns zeros -- no divergent branches and no 64-bit address arithmetic per load (the flat-pointer
+  // form cost ~25 VALU instructions and two exec-mask branches per load; these kernels sit at 40-50 % VALU issue utilisation).
+  // Per-thread invariants (pixel of the halo tile, byte offset relative to the tile origin) are computed once.
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
+  int hpy[NR], hpx[NR];
+  uint32_t hrel[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int u = threadIdx.x + k * 256;
+    const int p = u / NCH, c = u % NCH;
+    hpy[k] = u < NU ? p / HWID - 1 : -100000;                 // outside every image -> always masked
+    hpx[k] = p % HWID - 1;
+    hrel[k] = (uint32_t)(((p / HWID - 1) * W + (p % HWID - 1)) * CK + c * 8) * 2u;
+  }
   auto fetch = [&](int tile) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    const uint32_t tbase = (uint32_t)(((b * H + y0) * W + x0) * CK) * 2u;        // bytes; < 2^31 (checked by the launcher)
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      const int u = threadIdx.x + k * 256;
-      const int p = u / NCH, c = u % NCH;
-      const int iy = ty * TH + p / HWID - 1, ix = tx * TW + p % HWID - 1;
-      rv[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (u < NU && iy >= 0 && iy < H && ix >= 0 && ix < W)
-        rv[k] = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * CK + c * 8);
+      const bool ok = (unsigned)(y0 + hpy[k]) < (unsigned)H && (unsigned)(x0 + hpx[k]) < (unsigned)W;
+      const uint32_t off = ok ? tbase + hrel[k] : 0x80000000u;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0);
+      rv[k] = make_uint4(v.x, v.y, v.z, v.w);
     }
   };
+  const uint32_t y_bytes = (uint32_t)((size_t)(ntiles / (tiles_x * tiles_y)) * H * W * Co * 2);
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src ? mask_src : y), 0, y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend : y), 0, y_bytes, 0x00020000);
+  const uint32_t lane_rel = (uint32_t)((li * Co + co_base + 4 * g) * 2);
   float4 bz[NC];
 #pragma unroll
   for (int n = 0; n < NC; ++n)
@@ -316,35 +351,34 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
         for (int n = 0; n < NC; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s % 3][n], bv, acc[i][n], 0, 0, 0);
       }
     }
+    const uint32_t tile_o = (uint32_t)((((b * H + y0) * W + x0) * Co) * 2) + lane_rel;
 #pragma unroll
     for (int i = 0; i < MP; ++i) {
       const int t = wave * MP + i;
       const int oy = y0 + t / TPR, ox = x0 + (t % TPR) * 16 + li;
-      if (oy >= H || ox >= W) continue;
+      const bool inb = oy < H && ox < W;
+      const uint32_t orow = tile_o + (uint32_t)((((t / TPR) * W + (t % TPR) * 16) * Co) * 2);
 #pragma unroll
       for (int n = 0; n < NC; ++n) {
-        const int co = co_base + n * 16 + 4 * g;
-        const size_t o = (((size_t)b * H + oy) * W + ox) * Co + co;
+        const uint32_t off = inb ? orow + (uint32_t)(n * 32) : 0x80000000u;
         float v[4] = {acc[i][n][0] + bz[n].x, acc[i][n][1] + bz[n].y, acc[i][n][2] + bz[n].z, acc[i][n][3] + bz[n].w};
         if (relu) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
         if (mask_src) {
-          const uint2 mk = *reinterpret_cast<const uint2*>(mask_src + o);
+          const u32x2 mk = __builtin_amdgcn_raw_buffer_load_b64(mres, off, 0, 0);
           const uint32_t mm[4] = {mk.x & 0xffffu, mk.x >> 16, mk.y & 0xffffu, mk.y >> 16};
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = (mm[r] != 0u && mm[r] < 0x8000u) ? v[r] : 0.f;
         }
         if (addend) {
-          const uint2 a2 = *reinterpret_cast<const uint2*>(addend + o);
+          const u32x2 a2 = __builtin_amdgcn_raw_buffer_load_b64(ares, off, 0, 0);
           v[0] += __uint_as_float(a2.x << 16); v[1] += __uint_as_float(a2.x & 0xffff0000u);
           v[2] += __uint_as_float(a2.y << 16); v[3] += __uint_as_float(a2.y & 0xffff0000u);
         }
-        uint2 out;
-        out.x = pack2bf(v[0], v[1]);
-        out.y = pack2bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>(y + o) = out;
+        const u32x2 out = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        __builtin_amdgcn_raw_buffer_store_b64(out, yres, off, 0, 0);
       }
     }
   }
@@ -490,16 +524,17 @@ static int launch_conv(const void* x, const void* wp, const float* bias, const v
     const int ntiles = tiles_x * tiles_y * B, ygroups = Co / (16 * NC);
     int gx = 2048 / ygroups;                       // ~8 workgroups per CU in total, each walking ntiles/gx tiles
     if (gx > ntiles) gx = ntiles;
-    if (ntiles >= 4 * gx) {
+    if (ntiles >= 4 * gx && (size_t)B * H * W * CK * 2 < ((size_t)1 << 31)) {       // 32-bit byte offsets in the halo fetch
       hipLaunchKernelGGL((k_conv_mfma_p<CK, NC, TW>), dim3((unsigned)gx, (unsigned)ygroups), dim3(256), lds, s, (const bf16_t*)x,
-                         (const bf16_t*)wp, bias, (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Co, relu, tiles_x, tiles_y, ntiles);
+                         (const bf16_t*)wp, bias, (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Co, relu, tiles_x, tiles_y, ntiles,
+                         (uint32_t)((size_t)B * H * W * CK * 2));
       BX_CHECK_LAUNCH("bx_conv3x3(mfma persistent)");
       return BX_OK;
     }
   }
   dim3 grid((unsigned)(tiles_x * tiles_y * B), (unsigned)(Co / (16 * NC)));
   hipLaunchKernelGGL((k_conv_mfma<CK, NC, TW>), grid, dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)wp, bias,
-                     (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y);
+                     (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2));
   BX_CHECK_LAUNCH("bx_conv3x3(mfma)");
   return BX_OK;
 }
@@ -526,6 +561,8 @@ static int launch_conv_nc(const void* x, const void* wp, const float* bias, cons
 int bx_conv3x3_mfma_launch(const void* x, const void* packed_mfma, const float* bias, const void* relu_mask_src,
                            const void* addend, void* y, int B, int H, int W, int Ci, int Co, int flags, hipStream_t s) {
   const int relu = (flags & BX_EPI_RELU) ? 1 : 0;
+  // the kernels address activations with 32-bit byte offsets through buffer resources
+  BX_REQUIRE((size_t)B * H * W * (Ci > Co ? Ci : Co) * 2 < ((size_t)1 << 31), "bx_conv3x3(mfma): an activation tensor of 2 GiB or more is not supported (B=%d H=%d W=%d)", B, H, W);
   // K-split variant: measured equal to the tile-per-workgroup kernel on MI355X (round 1: fwd +8 %, dgrad -3 %), so it is
   // opt-in (BX_KSPLIT=1) until its main loop gets LDS double buffering
   if (Co % 64 == 0 && getenv("BX_KSPLIT")) {
@@ -593,25 +630,46 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const bf16_t* __restrict_
   constexpr int NXU = HH * HWID * (CIT / 8), NZU = TH * TW * (COT / 8);
   constexpr int NX = (NXU + 255) / 256, NZ = (NZU + 255) / 256;
   uint4 rx[NX], rz[NZ];
+  // tile loads through raw buffer resources with 32-bit byte offsets; out-of-image lanes point past the end and read
+  // zeros (no divergent branches, no 64-bit address arithmetic); per-thread invariants are computed once
+  const int nimg = ntiles / (tiles_x * tiles_y);
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (uint32_t)((size_t)nimg * H * W * Ci_p * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t zres = __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, (uint32_t)((size_t)nimg * H * W * Co * 2), 0x00020000);
+  int xpy[NX], xpx[NX], zpy[NZ], zpx[NZ];
+  uint32_t xrel[NX], zrel[NZ];
+#pragma unroll
+  for (int k = 0; k < NX; ++k) {
+    const int u = threadIdx.x + k * 256;
+    const int p = u / (CIT / 8), c = u % (CIT / 8);
+    const bool live = u < NXU && ci0 + c * 8 < Ci_p;
+    xpy[k] = live ? p / HWID - 1 : -100000;
+    xpx[k] = p % HWID - 1;
+    xrel[k] = (uint32_t)((((p / HWID - 1) * W + (p % HWID - 1)) * Ci_p + ci0 + c * 8) * 2);
+  }
+#pragma unroll
+  for (int k = 0; k < NZ; ++k) {
+    const int u = threadIdx.x + k * 256;
+    const int p = u / (COT / 8), c = u % (COT / 8);
+    zpy[k] = u < NZU ? p / TW : 100000000;
+    zpx[k] = p % TW;
+    zrel[k] = (uint32_t)((((p / TW) * W + p % TW) * Co + co0 + c * 8) * 2);
+  }
   auto fetch = [&](int tile) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int y0 = ty * TH, x0 = tx * TW;
+    const uint32_t pix0 = (uint32_t)((b * H + y0) * W + x0);
+    const uint32_t xb = pix0 * (uint32_t)(Ci_p * 2), zb = pix0 * (uint32_t)(Co * 2);
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
-      const int u = threadIdx.x + k * 256;
-      const int p = u / (CIT / 8), c = u % (CIT / 8);
-      const int iy = y0 + p / HWID - 1, ix = x0 + p % HWID - 1;
-      rx[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (u < NXU && iy >= 0 && iy < H && ix >= 0 && ix < W && ci0 + c * 8 < Ci_p)
-        rx[k] = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * Ci_p + ci0 + c * 8);
+      const bool ok = (unsigned)(y0 + xpy[k]) < (unsigned)H && (unsigned)(x0 + xpx[k]) < (unsigned)W;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? xb + xrel[k] : 0x80000000u, 0, 0);
+      rx[k] = make_uint4(v.x, v.y, v.z, v.w);
     }
 #pragma unroll
     for (int k = 0; k < NZ; ++k) {
-      const int u = threadIdx.x + k * 256;
-      const int p = u / (COT / 8), c = u % (COT / 8);
-      const int iy = y0 + p / TW, ix = x0 + p % TW;
-      rz[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (u < NZU && iy < H && ix < W) rz[k] = *reinterpret_cast<const uint4*>(dz + (((size_t)b * H + iy) * W + ix) * Co + co0 + c * 8);
+      const bool ok = (unsigned)(y0 + zpy[k]) < (unsigned)H && (unsigned)(x0 + zpx[k]) < (unsigned)W;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(zres, ok ? zb + zrel[k] : 0x80000000u, 0, 0);
+      rz[k] = make_uint4(v.x, v.y, v.z, v.w);
     }
   };
   if (t_begin < t_end) fetch(t_begin);
@@ -807,6 +865,7 @@ int bx_wgrad_mfma_launch(const void* x, const void* dz, float* dw, float* db, in
                          int Co, void* ws, size_t ws_bytes, hipStream_t s) {
   const WgradPlan p = wgrad_plan(B, H, W, Ci_p, Co);
   (void)ws_bytes;
+  BX_REQUIRE((size_t)B * H * W * (Ci_p > Co ? Ci_p : Co) * 2 < ((size_t)1 << 31), "bx_conv3x3_wgrad(mfma): an activation tensor of 2 GiB or more is not supported");
   float* part = (float*)ws;
 #define BX_WG(MA_, NB_) do { if (p.tw == 16) launch_wgrad<MA_, NB_, 16>(p, x, dz, part, H, W, Ci_p, Co, s); \
                              else launch_wgrad<MA_, NB_, 32>(p, x, dz, part, H, W, Ci_p, Co, s); } while (0)
