@@ -148,15 +148,32 @@ __device__ __forceinline__ void skip_sample(const T* __restrict__ x, const TailG
 template <typename T>
 __global__ __launch_bounds__(256) void k_tail_apply(const T* __restrict__ pooled, const T* __restrict__ x, const float* __restrict__ wT,
     int Cin, const float* __restrict__ b1x1, const float* __restrict__ scale, const float* __restrict__ shift,
-    const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, T* __restrict__ out, TailGeom g) {
+    const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, T* __restrict__ out, TailGeom g,
+    const float* __restrict__ ev_gamma, const float* __restrict__ ev_beta, const float* __restrict__ ev_rmean,
+    const float* __restrict__ ev_rvar, float eps, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
   extern __shared__ float xs[];  // [slots][Cin_p + 1]
   const int cg = threadIdx.x % g.ncg, slot = threadIdx.x / g.ncg;
   const int xstride = g.Cin_p + 1, nci8 = g.Cin_p / 8;
   const uint64_t sd = (dropout_p > 0.f && seed) ? seed[0] : 0;
   const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
   float sc[8], sh[8], bb[8];
+  if (ev_gamma) {
+    // eval mode: scale / shift come straight from the running statistics (no finalize launch); workgroup 0 also
+    // publishes them as the saved mean / invstd an eval-mode backward (saliency, IG, inner Grad-CAM targets) reads
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sc[j] = scale[cg * 8 + j]; sh[j] = shift[cg * 8 + j]; bb[j] = b1x1[cg * 8 + j]; }
+    for (int j = 0; j < 8; ++j) {
+      const int c = cg * 8 + j;
+      const float is = 1.0f / sqrtf(ev_rvar[c] + eps), s_ = ev_gamma[c] * is;
+      sc[j] = s_; sh[j] = ev_beta[c] - ev_rmean[c] * s_; bb[j] = b1x1[c];
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < g.C) {
+      save_mean[threadIdx.x] = ev_rmean[threadIdx.x];
+      save_invstd[threadIdx.x] = 1.0f / sqrtf(ev_rvar[threadIdx.x] + eps);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = scale[cg * 8 + j]; sh[j] = shift[cg * 8 + j]; bb[j] = b1x1[cg * 8 + j]; }
+  }
   const long long nsteps = (g.npool + (long long)gridDim.x * g.slots - 1) / ((long long)gridDim.x * g.slots);
   for (long long st = 0; st < nsteps; ++st) {
     const long long p0 = (st * gridDim.x + blockIdx.x) * g.slots;
@@ -243,12 +260,16 @@ extern "C" int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void
     hipLaunchKernelGGL((k_pool_stats<T>), dim3(nblk), dim3(256), 0, s, (const T*)y3, (T*)pooled, partials, g, d->pool, d->training,
                        w1x1, Cin, wT));
   BX_CHECK_LAUNCH("bx_block_tail_fwd(pool)");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.C)), dim3(1024), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight, bn_bias,
-                     running_mean, running_var, num_batches_tracked, d->momentum, d->eps, scale, shift, save_mean, save_invstd);
-  BX_CHECK_LAUNCH("bx_block_tail_fwd(finalize)");
+  if (d->training) {
+    hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.C)), dim3(1024), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight, bn_bias,
+                       running_mean, running_var, num_batches_tracked, d->momentum, d->eps, scale, shift, save_mean, save_invstd);
+    BX_CHECK_LAUNCH("bx_block_tail_fwd(finalize)");
+  }
+  const bool ev = !d->training;
   BX_DISPATCH_DTYPE(d->dtype, T,
     hipLaunchKernelGGL((k_tail_apply<T>), dim3(tail_blocks_all(g)), dim3(256), xs_bytes, s, (const T*)pooled, (const T*)x, wT, Cin, b1x1,
-                       scale, shift, seed, p, d->salt, (T*)out, g));
+                       scale, shift, seed, p, d->salt, (T*)out, g, ev ? bn_weight : (const float*)nullptr, bn_bias, (const float*)running_mean,
+                       (const float*)running_var, d->eps, save_mean, save_invstd));
   BX_CHECK_LAUNCH("bx_block_tail_fwd(apply)");
   return BX_OK;
 }
