@@ -309,6 +309,24 @@ __global__ __launch_bounds__(256) void k_eeg_sep(const float* __restrict__ p1, c
   }
 }
 
+// eval mode: scale / shift / mean / invstd of all three BatchNorms straight from the running statistics, one launch
+// (the training path needs a finalize after each producer; in eval the three sets are known up front)
+__global__ void k_eeg_eval_stats(const float* g1, const float* b1, const float* m1, const float* v1, int n1, float* sc1, float* sh1, float* mean1, float* inv1,
+                                 const float* g2, const float* b2, const float* m2, const float* v2, int n2, float* sc2, float* sh2, float* mean2, float* inv2,
+                                 const float* g3, const float* b3, const float* m3, const float* v3, int n3, float* sc3, float* sh3, float* mean3, float* inv3,
+                                 float eps) {
+  const int i = threadIdx.x;
+  auto one = [&](const float* g, const float* b, const float* m, const float* v, int n, float* sc, float* sh, float* mean, float* inv) {
+    if (i < n) {
+      const float is = 1.0f / sqrtf(v[i] + eps), s_ = g[i] * is;
+      sc[i] = s_; sh[i] = b[i] - m[i] * s_; mean[i] = m[i]; inv[i] = is;
+    }
+  };
+  one(g1, b1, m1, v1, n1, sc1, sh1, mean1, inv1);
+  one(g2, b2, m2, v2, n2, sc2, sh2, mean2, inv2);
+  one(g3, b3, m3, v3, n3, sc3, sh3, mean3, inv3);
+}
+
 extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, const float* x, const uint64_t* seed,
                                    float* feat, void* saved, void* workspace, size_t workspace_bytes, bxStream stream) {
   BX_REQUIRE(d && p && x && feat && saved, "bx_eeg_features_fwd: null pointer");
@@ -331,6 +349,12 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
   const float pdrop = tr ? d->dropout_p : 0.f;
   BX_REQUIRE(pdrop == 0.f || seed, "bx_eeg_features_fwd: dropout needs a device seed");
 
+  if (!tr) {
+    hipLaunchKernelGGL(k_eeg_eval_stats, dim3(1), dim3(64), 0, s, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, g.F1, st.sc1, st.sh1, st.mean1, st.inv1,
+                       p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, g.FD, st.sc2, st.sh2, st.mean2, st.inv2,
+                       p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, g.F2, st.sc3, st.sh3, st.mean3, st.inv3, d->eps);
+    BX_CHECK_LAUNCH("eeg eval stats");
+  }
   // bf16 storage with the reference's 64-tap kernel: the temporal convolution runs on the matrix cores (eeg_mfma.hip)
   const bool no_mfma = getenv("BX_EEG_NO_MFMA") != nullptr;          // read per call: tests flip it to compare both paths
   if (d->dtype == BX_BF16 && g.K1 == 64 && !no_mfma && bx_eeg_conv1_mfma_lds(g.T) <= 150 * 1024) {
@@ -341,7 +365,8 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
       hipLaunchKernelGGL((k_eeg_conv1<T>), dim3(w.nblk_rows), dim3(EEG_TT), (size_t)(8 * EEG_MAXK + g.T + g.K1 + 8) * sizeof(float), s, x, p->conv1_w, (T*)c1, part, g, tr));
   }
   BX_CHECK_LAUNCH("eeg conv1");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.F1)), dim3(1024), 0, s, part, w.nblk_rows, (double)g.B * g.Ch * g.T, g.F1, tr, p->bn1_w, p->bn1_b,
+  if (tr)
+    hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.F1)), dim3(1024), 0, s, part, w.nblk_rows, (double)g.B * g.Ch * g.T, g.F1, tr, p->bn1_w, p->bn1_b,
                      p->bn1_rm, p->bn1_rv, p->bn1_nbt, d->momentum, d->eps, st.sc1, st.sh1, st.mean1, st.inv1);
   BX_CHECK_LAUNCH("eeg bn1");
   const int dwv = 1;      // 4 steps per thread (8-byte loads) measured SLOWER (35 vs 27 us): fewer, longer serial load chains
@@ -350,7 +375,8 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
     if (dwv == 4) hipLaunchKernelGGL((k_eeg_dw<T, 4>), gdw, dim3(128), 0, s, (const T*)c1, p->dw_w, st.sc1, st.sh1, dmap, part, g, tr);
     else hipLaunchKernelGGL((k_eeg_dw<T, 1>), gdw, dim3(128), 0, s, (const T*)c1, p->dw_w, st.sc1, st.sh1, dmap, part, g, tr));
   BX_CHECK_LAUNCH("eeg depthwise");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.FD)), dim3(1024), 0, s, part, (int)(gdw.x * gdw.y), (double)g.B * g.T, g.FD, tr, p->bn2_w, p->bn2_b,
+  if (tr)
+    hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.FD)), dim3(1024), 0, s, part, (int)(gdw.x * gdw.y), (double)g.B * g.T, g.FD, tr, p->bn2_w, p->bn2_b,
                      p->bn2_rm, p->bn2_rv, p->bn2_nbt, d->momentum, d->eps, st.sc2, st.sh2, st.mean2, st.inv2);
   BX_CHECK_LAUNCH("eeg bn2");
   {
@@ -362,7 +388,8 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
   dim3 gsep(bx_ceil_div(g.T1, SEP_TT), g.B);
   hipLaunchKernelGGL(k_eeg_sep, gsep, dim3(256), 0, s, p1, p->sep_w, smap, part, g, tr);
   BX_CHECK_LAUNCH("eeg sepconv");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.F2)), dim3(1024), 0, s, part, (int)(gsep.x * gsep.y), (double)g.B * g.T1, g.F2, tr, p->bn3_w, p->bn3_b,
+  if (tr)
+    hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.F2)), dim3(1024), 0, s, part, (int)(gsep.x * gsep.y), (double)g.B * g.T1, g.F2, tr, p->bn3_w, p->bn3_b,
                      p->bn3_rm, p->bn3_rv, p->bn3_nbt, d->momentum, d->eps, st.sc3, st.sh3, st.mean3, st.inv3);
   BX_CHECK_LAUNCH("eeg bn3");
   {
