@@ -587,9 +587,9 @@ int bx_conv3x3_mfma_launch(const void* x, const void* packed_mfma, const float* 
 //   registers); every lane supplies its own row address, so the 9 tap shifts cost nothing.
 //   A workgroup owns a (16*MA cin) x (16*NB cout) slice of dW for all 9 taps and walks a contiguous range of
 //   8 x TW pixel tiles; its 4 waves split each tile's K-steps (rows) and keep 9*MA*NB accumulator tiles in
-//   registers across the whole range.  At the end the waves are summed through LDS in a fixed order and the
-//   slice goes to the workspace as one partial; k_wgrad_reduce2 sums the partials in a fixed order
-//   (deterministic, no atomics) and writes OIHW.  The bias gradient rides along on the dZ fragments.
+//   registers across the whole range.  At the end the waves are summed through LDS (reduce-scatter, fixed order) and
+//   the slice goes to the workspace as one partial in MFMA fragment order; k_wgrad_reduce3 sums the partials in a
+//   fixed order (deterministic, no atomics) and writes OIHW.  The bias gradient rides along on the dZ fragments.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
