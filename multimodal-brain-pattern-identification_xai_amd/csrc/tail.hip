@@ -390,21 +390,23 @@ __global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ do
   }
 }
 
-// dXs[p][ci] = sum_c W1x1[c][ci] * dOut[p][c]   (half resolution, fp32).  One (pixel, 8 input channels) unit per
-// thread; the weight matrix streams through LDS in 64-output-channel slabs ([c][Cin_p], zero padded), dOut comes
-// straight from global as 16-byte vectors.
-template <typename T>
+// dXs[p][ci] = sum_c W1x1[c][ci] * dOut[p][c]   (half resolution, fp32).  One (pixel, CIV input channels) unit per
+// thread (CIV = 8, or 4 when the map is so small that 8 would leave most CUs without a workgroup); the weight matrix
+// streams through LDS in 64-output-channel slabs ([c][Cin_p], zero padded), dOut comes straight from global as 16-byte vectors.
+template <typename T, int CIV>
 __global__ __launch_bounds__(256) void k_skip_dxs(const T* __restrict__ dout, const float* __restrict__ w1x1, int Cin,
                                                    float* __restrict__ dxs, T* __restrict__ dx_even, TailGeom g) {
   extern __shared__ __attribute__((aligned(16))) float swt[];   // [64][Cin_p]
-  const int nci8 = g.Cin_p / 8;
-  const long long n = g.npool * nci8;
+  const int ncv = g.Cin_p / CIV;
+  const long long n = g.npool * ncv;
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
   const bool live = u < n;
   const unsigned u32 = live ? (unsigned)u : 0u;
-  const long long pp = (long long)(u32 / (unsigned)nci8);
-  const int c8 = (int)(u32 - (unsigned)pp * (unsigned)nci8);
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const long long pp = (long long)(u32 / (unsigned)ncv);
+  const int cv = (int)(u32 - (unsigned)pp * (unsigned)ncv);
+  float acc[CIV];
+#pragma unroll
+  for (int j = 0; j < CIV; ++j) acc[j] = 0.f;
   for (int cb = 0; cb < g.C; cb += 64) {
     const int nc = g.C - cb < 64 ? g.C - cb : 64;
     float go[8][8];                                       // this pixel's dOut over the slab: all loads issued up front
@@ -436,10 +438,12 @@ __global__ __launch_bounds__(256) void k_skip_dxs(const T* __restrict__ dout, co
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const float gv = go[q][k];
-          const float4 wa = *reinterpret_cast<const float4*>(swt + (q * 8 + k) * g.Cin_p + c8 * 8);
-          const float4 wb = *reinterpret_cast<const float4*>(swt + (q * 8 + k) * g.Cin_p + c8 * 8 + 4);
-          acc[0] = fmaf(wa.x, gv, acc[0]); acc[1] = fmaf(wa.y, gv, acc[1]); acc[2] = fmaf(wa.z, gv, acc[2]); acc[3] = fmaf(wa.w, gv, acc[3]);
-          acc[4] = fmaf(wb.x, gv, acc[4]); acc[5] = fmaf(wb.y, gv, acc[5]); acc[6] = fmaf(wb.z, gv, acc[6]); acc[7] = fmaf(wb.w, gv, acc[7]);
+#pragma unroll
+          for (int h = 0; h < CIV / 4; ++h) {
+            const float4 wv = *reinterpret_cast<const float4*>(swt + (q * 8 + k) * g.Cin_p + cv * CIV + 4 * h);
+            acc[4 * h] = fmaf(wv.x, gv, acc[4 * h]); acc[4 * h + 1] = fmaf(wv.y, gv, acc[4 * h + 1]);
+            acc[4 * h + 2] = fmaf(wv.z, gv, acc[4 * h + 2]); acc[4 * h + 3] = fmaf(wv.w, gv, acc[4 * h + 3]);
+          }
         }
       }
     }
@@ -449,15 +453,23 @@ __global__ __launch_bounds__(256) void k_skip_dxs(const T* __restrict__ dout, co
       // H and W even: bilinear-to-half is the 2x2 mean, its transpose spreads dXs/4 over the 2x2 footprint
       int ox, oy, b;
       px_decode(pp, g.Wo, g.Ho, ox, oy, b);
-      float q[8];
+      const size_t base = (((size_t)b * g.H + 2 * oy) * g.W + 2 * ox) * g.Cin_p + cv * CIV;
+      const size_t foot[4] = {0, (size_t)g.Cin_p, (size_t)g.W * g.Cin_p, (size_t)g.W * g.Cin_p + g.Cin_p};
+      if (CIV == 8) {
+        float q[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) q[j] = 0.25f * acc[j];
-      const size_t base = (((size_t)b * g.H + 2 * oy) * g.W + 2 * ox) * g.Cin_p + c8 * 8;
-      st8(dx_even, base, q); st8(dx_even, base + g.Cin_p, q);
-      st8(dx_even, base + (size_t)g.W * g.Cin_p, q); st8(dx_even, base + (size_t)g.W * g.Cin_p + g.Cin_p, q);
+        for (int j = 0; j < 8; ++j) q[j] = 0.25f * acc[j % CIV];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) st8(dx_even, base + foot[f], q);
+      } else {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int j = 0; j < CIV; ++j) stf(dx_even, base + foot[f] + j, 0.25f * acc[j]);
+      }
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dxs[(size_t)pp * g.Cin_p + c8 * 8 + j] = acc[j];
+      for (int j = 0; j < CIV; ++j) dxs[(size_t)pp * g.Cin_p + cv * CIV + j] = acc[j];
     }
   }
 }
@@ -610,11 +622,14 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
     BX_CHECK_LAUNCH("bx_block_tail_bwd(w1x1 reduce)");
   }
   if (dx_skip) {
-    const long long n1 = g.npool * (g.Cin_p / 8);
     const bool even = (g.H % 2 == 0) && (g.W % 2 == 0);
+    const bool narrow = g.npool * (g.Cin_p / 8) < 256 * 256;          // fewer than one workgroup per CU at 8 channels per thread
+    const long long n1 = g.npool * (g.Cin_p / (narrow ? 4 : 8));
     BX_DISPATCH_DTYPE(d->dtype, T,
-      hipLaunchKernelGGL((k_skip_dxs<T>), dim3(bx_ceil_div(n1, 256)), dim3(256), (size_t)64 * g.Cin_p * sizeof(float), s,
-                         (const T*)dout, w1x1, Cin, dxs, even ? (T*)dx_skip : (T*)nullptr, g));
+      if (narrow) hipLaunchKernelGGL((k_skip_dxs<T, 4>), dim3(bx_ceil_div(n1, 256)), dim3(256), (size_t)64 * g.Cin_p * sizeof(float), s,
+                                     (const T*)dout, w1x1, Cin, dxs, even ? (T*)dx_skip : (T*)nullptr, g);
+      else hipLaunchKernelGGL((k_skip_dxs<T, 8>), dim3(bx_ceil_div(n1, 256)), dim3(256), (size_t)64 * g.Cin_p * sizeof(float), s,
+                              (const T*)dout, w1x1, Cin, dxs, even ? (T*)dx_skip : (T*)nullptr, g));
     BX_CHECK_LAUNCH("bx_block_tail_bwd(dxs)");
     if (!even) {
       const long long n2 = (long long)g.B * g.H * g.W * (g.Cin_p / 8);
