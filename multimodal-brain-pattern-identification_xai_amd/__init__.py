@@ -9,7 +9,7 @@ from .models import (Block, EEGNet, KLDivLoss, MultimodalModel, Spectrogram_Mode
 from .explain import GradCamSweep, expected_gradients, generate_saliency_maps, grad_cam, integrated_gradients, saliency   # noqa: F401
 from .data import (EEGStacker, stack_eeg, EEGMontageStacker, stack_eeg_montage,          # noqa: F401
                    SpectrogramPreprocessor, preprocess_spectrograms)                                        # noqa: F401
-from .train import (FlatAdamW, DataParallel, GraphedTrainStep, train_and_validate_combined, train_and_validate_eeg_distributed,   # noqa: F401
+from .train import (FlatAdamW, DataParallel, GraphedTrainStep, AsyncCheckpointer, train_and_validate_combined, train_and_validate_eeg_distributed,   # noqa: F401
                     train_step, setup, cleanup, create_ddp_model)
 
 __version__ = "0.1.0"

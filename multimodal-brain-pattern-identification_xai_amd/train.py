@@ -281,6 +281,82 @@ class GraphedTrainStep:
 _STEPPER = [None]
 
 
+class AsyncCheckpointer:
+    """the per-epoch checkpoint without stalling the training stream.  ``save(state)`` snapshots every
+    CUDA tensor of the (nested) state dict into pinned host buffers with non-blocking copies on a side stream, and a worker
+    thread waits for that stream's event, then ``torch.save``s the reference-layout dict to ``<name>.tmp`` and renames it
+    over the previous file (a reader never sees a half-written checkpoint).  The next epoch's kernels run meanwhile.
+    ``wait()`` joins outstanding writes (call it before reading the file or exiting)."""
+
+    def __init__(self, checkpoint_dir, checkpoint_filename):
+        import threading
+        self.path = os.path.join(checkpoint_dir, checkpoint_filename)
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        self._thread, self._threading = None, threading
+        self._stream = None
+        self._pinned = {}
+        self.error = None
+
+    def _snapshot(self, obj, key):
+        if torch.is_tensor(obj):
+            if not obj.is_cuda:
+                return obj.detach().clone()
+            buf = self._pinned.get(key)
+            if buf is None or buf.shape != obj.shape or buf.dtype != obj.dtype:
+                buf = self._pinned[key] = torch.empty(obj.shape, dtype=obj.dtype, device="cpu", pin_memory=True)
+            buf.copy_(obj.detach(), non_blocking=True)
+            return buf
+        if isinstance(obj, dict):
+            return type(obj)((k, self._snapshot(v, f"{key}/{k}")) for k, v in obj.items())
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(self._snapshot(v, f"{key}/{i}") for i, v in enumerate(obj))
+        return obj
+
+    def save(self, state):
+        self.wait()                                        # one write in flight; also frees the pinned buffers for reuse
+        if torch.cuda.is_available():
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                snap = self._snapshot(state, "")
+                done = torch.cuda.Event()
+                done.record()
+        else:
+            snap, done = self._snapshot(state, ""), None
+
+        def work():
+            try:
+                if done is not None:
+                    done.synchronize()
+                cpu = _to_plain(snap)
+                torch.save(cpu, self.path + ".tmp")
+                os.replace(self.path + ".tmp", self.path)
+            except Exception as exc:                       # noqa: BLE001  (surfaced by wait())
+                self.error = exc
+        self._thread = self._threading.Thread(target=work, daemon=True)
+        self._thread.start()
+
+    def wait(self):
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        if self.error is not None:
+            err, self.error = self.error, None
+            raise RuntimeError(f"asynchronous checkpoint write failed: {err}") from err
+
+
+def _to_plain(obj):
+    """pinned snapshot -> ordinary CPU tensors (so that the file loads without CUDA / pinned-memory support)."""
+    if torch.is_tensor(obj):
+        return obj.clone() if obj.is_pinned() else obj
+    if isinstance(obj, dict):
+        return type(obj)((k, _to_plain(v)) for k, v in obj.items())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_plain(v) for v in obj)
+    return obj
+
+
 def _run_epoch(model, loader, criterion, device, optimizer=None, ddp=None, unpack=None):
     """One pass; loss*B and correct counts accumulate ON DEVICE (the reference syncs three times per step)."""
     loss_sum = torch.zeros((), dtype=torch.float32, device=device)
@@ -312,12 +388,14 @@ def _run_epoch(model, loader, criterion, device, optimizer=None, ddp=None, unpac
 
 
 def train_and_validate_combined(model, train_loader, valid_loader, epochs, optimizer, criterion, device, checkpoint_dir,
-                                n=2, sample_spectrogram=None):
+                                n=2, sample_spectrogram=None, async_checkpoint=False):
     """Reference XAI_Multimodality.py:1579-1681 minus its LIME tail (CPU skimage; out of scope).
     Batches are ``((eeg, spec), labels)``; returns (train_losses, valid_losses, train_accuracies, valid_accuracies)
-    and writes ``combined_checkpoint.pth.tar`` with the reference's dict layout each epoch."""
+    and writes ``combined_checkpoint.pth.tar`` with the reference's dict layout each epoch (``async_checkpoint=True``:
+    through AsyncCheckpointer, the file of the last epoch is complete when the function returns)."""
     name = "combined_checkpoint.pth.tar"
     start, tr_l, va_l, tr_a, va_a = load_checkpoint(checkpoint_dir, name, model, optimizer)
+    saver = AsyncCheckpointer(checkpoint_dir, name) if async_checkpoint else None
     for epoch in range(start, epochs):
         model.train()
         l, a = _run_epoch(model, train_loader, criterion, device, optimizer)
@@ -327,9 +405,14 @@ def train_and_validate_combined(model, train_loader, valid_loader, epochs, optim
         va_l.append(l); va_a.append(a)
         print(f"Epoch {epoch + 1}/{epochs}:\n  Train Loss: {tr_l[-1]:.4f} Train Accuracy: {tr_a[-1]:.2f}%\n"
               f"  Valid Loss: {va_l[-1]:.4f} Valid Accuracy: {va_a[-1]:.2f}%")
-        save_checkpoint({"epoch": epoch + 1, "state_dict": model.state_dict(), "optimizer": optimizer.state_dict(),
-                         "train_losses": tr_l, "valid_losses": va_l, "train_accuracies": tr_a, "valid_accuracies": va_a},
-                        checkpoint_dir, name)
+        state = {"epoch": epoch + 1, "state_dict": model.state_dict(), "optimizer": optimizer.state_dict(),
+                 "train_losses": list(tr_l), "valid_losses": list(va_l), "train_accuracies": list(tr_a), "valid_accuracies": list(va_a)}
+        if saver is not None:
+            saver.save(state)
+        else:
+            save_checkpoint(state, checkpoint_dir, name)
+    if saver is not None:
+        saver.wait()
     return tr_l, va_l, tr_a, va_a
 
 

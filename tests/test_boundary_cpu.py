@@ -89,3 +89,23 @@ def test_flat_adamw_host_math_matches_torch():
     for p, q in zip(ps, qs):
         torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-5, atol=1e-6)
     assert ps[0].data_ptr() == mine.flat_p.data_ptr()
+
+
+def test_async_checkpointer_host_logic(tmp_path):
+    """8(f) rank 4 (host side): nested state dicts survive, the rename is atomic, errors surface in wait()"""
+    ck = brainxai.AsyncCheckpointer(str(tmp_path), "c.pth.tar")
+    state = {"epoch": 2, "state_dict": {"w": torch.arange(6.).reshape(2, 3)}, "optimizer": {"step": torch.tensor([5.]), "m": [torch.ones(3)]},
+             "train_losses": [1.0, 0.5]}
+    ck.save(state)
+    state["state_dict"]["w"].add_(100)                  # the snapshot was taken at save(): later updates must not leak into the file
+    ck.wait()
+    got = torch.load(tmp_path / "c.pth.tar", weights_only=False)
+    assert got["epoch"] == 2 and got["train_losses"] == [1.0, 0.5]
+    torch.testing.assert_close(got["state_dict"]["w"], torch.arange(6.).reshape(2, 3))
+    torch.testing.assert_close(got["optimizer"]["m"][0], torch.ones(3))
+    assert sorted(os.listdir(tmp_path)) == ["c.pth.tar"]
+    bad = brainxai.AsyncCheckpointer(str(tmp_path), "d.pth.tar")
+    bad.path = str(tmp_path / "missing_dir" / "d.pth.tar")
+    bad.save(state)
+    with pytest.raises(RuntimeError, match="asynchronous checkpoint"):
+        bad.wait()

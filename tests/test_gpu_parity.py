@@ -472,6 +472,27 @@ def test_graphed_train_step_matches_eager():
         ops.clear_grad_views()
 
 
+def test_async_checkpoint_equals_synchronous(tmp_path):
+    """8(f) rank 4: the loop with async_checkpoint=True writes the same reference-layout file as the synchronous path"""
+    def run(sub, asyn):
+        torch.manual_seed(3)
+        net = brainxai.build_multimodal(19, 2000, 4, dropout=0.0).to(DEV)
+        opt = brainxai.FlatAdamW(net.parameters(), lr=1e-3)
+        try:
+            brainxai.train_and_validate_combined(net, _toy_loader(2, 4, 300), _toy_loader(1, 4, 400), 2, opt, brainxai.KLDivLoss(), DEV,
+                                                 str(tmp_path / sub), async_checkpoint=asyn)
+        finally:
+            ops.clear_grad_views()
+        return torch.load(tmp_path / sub / "combined_checkpoint.pth.tar", map_location="cpu", weights_only=False)
+    a, b = run("sync", False), run("async", True)
+    assert a["epoch"] == b["epoch"] == 2 and a["train_losses"] == b["train_losses"] and a["valid_accuracies"] == b["valid_accuracies"]
+    assert list(a["state_dict"].keys()) == list(b["state_dict"].keys())
+    for k in a["state_dict"]:
+        assert torch.equal(a["state_dict"][k], b["state_dict"][k]), k
+    for k in ("step", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(a["optimizer"][k], b["optimizer"][k]), k
+
+
 def test_full_size_properties():
     """BASELINE shapes (B=64, 4x128x256 + 19x2000): size-independent checks instead of an oracle run."""
     torch.manual_seed(3)
