@@ -197,6 +197,10 @@ int bx_saliency_reduce(const void* g, float* out, int B, int HW, int C, int Cs, 
 /* y = alpha*x + beta*y over fp32 (integrated-gradients accumulate, baseline interpolation). */
 int bx_axpby(const float* x, float* y, size_t n, float alpha, float beta, bxStream stream);
 int bx_mul(const float* a, const float* b, float* out, size_t n, bxStream stream);
+/* Integrated gradients (Captum semantics): all K interpolants of a pass, out[k][i] = (1-a_k)*base[i] + a_k*x[i],
+ * and the weighted accumulation acc[i] += sum_k w_k * grads[k][i] (k ascending); alphas / weights are device float[K]. */
+int bx_ig_interpolate(const float* x, const float* base, const float* alphas_device, float* out, size_t n, int K, bxStream stream);
+int bx_ig_accumulate(const float* grads, const float* weights_device, float* acc, size_t n, int K, bxStream stream);
 /* out = |x| over fp32 (EEG saliency, NB:3121-3122). */
 int bx_abs(const float* x, float* out, size_t n, bxStream stream);
 /* out = x * scalar[0] with the scalar on the device (loss.backward()'s upstream gradient; no host sync). */

@@ -79,6 +79,8 @@ SIGNATURES = {
     "bx_saliency_reduce": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "bx_axpby": (i32, [vp, vp, sz, f32, f32, vp]),
     "bx_mul": (i32, [vp, vp, vp, sz, vp]),
+    "bx_ig_interpolate": (i32, [vp, vp, vp, vp, sz, i32, vp]),
+    "bx_ig_accumulate": (i32, [vp, vp, vp, sz, i32, vp]),
     "bx_eeg_stack_iir": (i32, [vp, vp, vp, i32, i32, i32, i32, P(C.c_double), P(C.c_double), i32, i32, f32, f32, vp]),
     "bx_eeg_montage_workspace": (sz, [i32, i32, i32, i32]),
     "bx_eeg_montage_stack": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, P(C.c_double), P(C.c_double), i32, P(C.c_double), P(C.c_double),

@@ -146,6 +146,46 @@ extern "C" int bx_mul(const float* a, const float* b, float* out, size_t n, bxSt
   return BX_OK;
 }
 
+// Integrated-gradients helpers: all K interpolants / all K weighted gradient slices of one pass in ONE launch each (the
+// per-interpolant bx_axpby calls were 300 launches of ~3.6 us per attribution, 11 % of its time)
+//   interpolate: out[k][i] = (1 - a_k) * base[i] + a_k * x[i]        accumulate: acc[i] += sum_k w_k * g[k][i]  (k ascending)
+__global__ void k_ig_interpolate(const float* __restrict__ x, const float* __restrict__ base, const float* __restrict__ alphas,
+                                 float* __restrict__ out, size_t n, int K) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float xv = x[i], bv = base[i];
+  for (int k = 0; k < K; ++k) {
+    const float a = alphas[k];
+    out[(size_t)k * n + i] = a * xv + (1.0f - a) * bv;
+  }
+}
+__global__ void k_ig_accumulate(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ acc, size_t n, int K) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = acc[i];
+  int k = 0;
+  for (; k + 4 <= K; k += 4) {                       // four loads in flight, added in k order
+    const float g0 = g[(size_t)k * n + i], g1 = g[(size_t)(k + 1) * n + i], g2 = g[(size_t)(k + 2) * n + i], g3 = g[(size_t)(k + 3) * n + i];
+    s = w[k] * g0 + s; s = w[k + 1] * g1 + s; s = w[k + 2] * g2 + s; s = w[k + 3] * g3 + s;
+  }
+  for (; k < K; ++k) s = w[k] * g[(size_t)k * n + i] + s;
+  acc[i] = s;
+}
+extern "C" int bx_ig_interpolate(const float* x, const float* base, const float* alphas_device, float* out, size_t n, int K, bxStream stream) {
+  BX_REQUIRE(x && base && alphas_device && out && K > 0, "bx_ig_interpolate: bad arguments");
+  if (n == 0) return BX_OK;
+  hipLaunchKernelGGL(k_ig_interpolate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, base, alphas_device, out, n, K);
+  BX_CHECK_LAUNCH("bx_ig_interpolate");
+  return BX_OK;
+}
+extern "C" int bx_ig_accumulate(const float* grads, const float* weights_device, float* acc, size_t n, int K, bxStream stream) {
+  BX_REQUIRE(grads && weights_device && acc && K > 0, "bx_ig_accumulate: bad arguments");
+  if (n == 0) return BX_OK;
+  hipLaunchKernelGGL(k_ig_accumulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grads, weights_device, acc, n, K);
+  BX_CHECK_LAUNCH("bx_ig_accumulate");
+  return BX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // AdamW (decoupled weight decay), torch.optim.AdamW semantics:
 //   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;

@@ -299,6 +299,8 @@ def integrated_gradients(model, inputs, baselines=None, target=None, n_steps=50,
     B = eeg.shape[0]
     alphas, steps = ig_nodes(n_steps)
     acc_e, acc_s = torch.zeros_like(eeg), torch.zeros_like(spec)
+    alphas_dev = torch.tensor([float(a) for a in alphas], dtype=torch.float32, device=eeg.device)
+    steps_dev = torch.tensor([float(w) for w in steps], dtype=torch.float32, device=eeg.device)
     per_pass = max(1, max_batch // B)
     with _eval_frozen(model):
         if target is None:
@@ -310,18 +312,18 @@ def integrated_gradients(model, inputs, baselines=None, target=None, n_steps=50,
             ks = range(k0, min(n_steps, k0 + per_pass))
             xe = torch.empty(len(ks), *eeg.shape, dtype=torch.float32, device=eeg.device)
             xs = torch.empty(len(ks), *spec.shape, dtype=torch.float32, device=spec.device)
-            for j, k in enumerate(ks):
-                _axpby(be, xe[j], 1.0 - alphas[k], 0.0); _axpby(eeg, xe[j], alphas[k], 1.0)
-                _axpby(bs, xs[j], 1.0 - alphas[k], 0.0); _axpby(spec, xs[j], alphas[k], 1.0)
+            a_dev, w_dev = alphas_dev[k0:k0 + len(ks)], steps_dev[k0:k0 + len(ks)]
+            lib_ = L.load()
+            L.check(lib_.bx_ig_interpolate(_p(eeg), _p(be), _p(a_dev), _p(xe), eeg.numel(), len(ks), _stream()), "bx_ig_interpolate")
+            L.check(lib_.bx_ig_interpolate(_p(spec), _p(bs), _p(a_dev), _p(xs), spec.numel(), len(ks), _stream()), "bx_ig_interpolate")
             xe = xe.flatten(0, 1).requires_grad_(True)
             xs = xs.flatten(0, 1).requires_grad_(True)
             out = model(xe, xs)
             seed = _one_hot_rows(tgt.repeat(len(ks)), out.shape[1])
             ge, gs = torch.autograd.grad(out, (xe, xs), grad_outputs=seed)
-            ge, gs = ge.reshape(len(ks), *eeg.shape), gs.reshape(len(ks), *spec.shape)
-            for j, k in enumerate(ks):
-                _axpby(ge[j], acc_e, steps[k], 1.0)
-                _axpby(gs[j], acc_s, steps[k], 1.0)
+            ge, gs = ge.contiguous(), gs.contiguous()
+            L.check(lib_.bx_ig_accumulate(_p(ge), _p(w_dev), _p(acc_e), acc_e.numel(), len(ks), _stream()), "bx_ig_accumulate")
+            L.check(lib_.bx_ig_accumulate(_p(gs), _p(w_dev), _p(acc_s), acc_s.numel(), len(ks), _stream()), "bx_ig_accumulate")
     de, ds = eeg.clone(), spec.clone()
     _axpby(be, de, -1.0, 1.0)
     _axpby(bs, ds, -1.0, 1.0)
