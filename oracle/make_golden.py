@@ -226,6 +226,51 @@ def gen_eegnet(M):
         save(tag, **rec)
 
 
+def gen_eegnet_deep(M):
+    """Row C': EEGNetAttentionDeep (M:136-235) forward / backward, eval and train (dropout 0), attention weights included."""
+    for tag, (chans, samples, b) in {"eegdeep19x2000": (19, 2000, 3), "eegdeep37x3000": (37, 3000, 2)}.items():
+        ref = O.fill_params(M.EEGNetAttentionDeep(6, Chans=chans, Samples=samples, dropoutRate=0.0), seed=61)
+        mine = O.fill_params(O.EEGNetAttentionDeep(6, Chans=chans, Samples=samples, dropoutRate=0.0), seed=61)
+        assert ref.output_samples == mine.output_samples and ref.flattened_size == mine.flattened_size
+        assert list(ref.state_dict()) == list(mine.state_dict())
+        x = O.seeded((b, 1, chans, samples), 62, "randn")
+        r = O.seeded((b, 6), 63, "randn")
+        rec = {"r": r}
+        for mode in ("eval", "train"):
+            ref.train(mode == "train"); mine.train(mode == "train")
+            grabbed = {}
+            hooks = [getattr(ref, n).register_forward_hook(
+                lambda m, i, o, n=n: grabbed.__setitem__(n, o[1].detach().clone() if isinstance(o, tuple) else o.detach().clone()))
+                for n in ("conv2", "batchnorm4", "attention_layer", "dropout3")]
+            ref.zero_grad(); mine.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            y = ref(xi); (y * r).sum().backward()
+            for h in hooks:
+                h.remove()
+            xj = x.clone().requires_grad_(True)
+            st = mine.stages(xj); (st["out"] * r).sum().backward()
+            note(f"eegdeep.{mode}.out", st["out"], y); note(f"eegdeep.{mode}.dx", xj.grad, xi.grad)
+            for a, bname in (("conv2", "conv2"), ("bn4", "batchnorm4"), ("attn", "attention_layer"), ("pool3", "dropout3")):
+                note(f"eegdeep.{mode}.{a}", st[a], grabbed[bname])
+            for (n, p_), (_, q) in zip(ref.named_parameters(), mine.named_parameters()):
+                note(f"eegdeep.{mode}.dparam", q.grad, p_.grad)
+                rec[f"{mode}.grad.{n}"] = p_.grad.detach().clone()
+            rec[f"{mode}.out"] = y.detach()
+            rec[f"{mode}.dx.head"] = xi.grad.detach()[..., :96].clone()
+            rec[f"{mode}.dx.tail"] = xi.grad.detach()[..., -96:].clone()
+            rec[f"{mode}.dx.sum"] = O.summarize(xi.grad)
+            rec[f"{mode}.conv2"] = grabbed["conv2"]                 # pad L7 / R8 on the T/32 axis
+            rec[f"{mode}.bn4"] = grabbed["batchnorm4"]
+            rec[f"{mode}.attn"] = grabbed["attention_layer"]         # [B, L, L] softmax weights
+            rec[f"{mode}.pool3"] = grabbed["dropout3"]               # [B, F3, 1, L]
+        for k in ("batchnorm3", "batchnorm4"):
+            rec[f"after.{k}.running_mean"] = getattr(ref, k).running_mean.clone()
+            rec[f"after.{k}.running_var"] = getattr(ref, k).running_var.clone()
+            note("eegdeep.running_var", getattr(mine, k).running_var, getattr(ref, k).running_var)
+        rec["after.batchnorm4.num_batches_tracked"] = ref.batchnorm4.num_batches_tracked.clone()
+        save(tag, **rec)
+
+
 def gen_multimodal(M, MM):
     """Logits, both KLDiv reductions, gradient digests, state after 3 AdamW steps (dropout 0)."""
     for tag, (chans, samples, cin, h, w, b) in {"mm_bench_small": (19, 2000, 4, 32, 64, 4),
@@ -449,18 +494,25 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     NB = os.path.join(REF, "root/jupyter_notebooks/XAI_Multimodality.py")
     M = import_reference()
+    only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
+    report_path = os.path.join(OUT, "PIN_REPORT.json")
+    if only:                                                  # regenerate some fixtures, keep the other pins
+        REPORT.update({k: v for k, v in json.load(open(report_path)).items() if k != "_meta"})
+    want = lambda name: only is None or name in only          # noqa: E731
     MM = extract(NB, "MultimodalModel", {"nn": nn, "torch": torch, "F": F})
-    print("blocks"); gen_blocks(M)
-    print("spectrogram models"); gen_spec_models(M)
-    print("eegnet"); gen_eegnet(M)
-    print("multimodal"); gen_multimodal(M, MM)
-    print("attribution"); gen_attribution(M, MM, NB)
-    print("stacker"); gen_stacker()
-    print("montage stacker"); gen_montage(NB)
-    print("spectrogram pre-processing"); gen_spectrogram_prep(NB)
-    gen_manifest(M, MM)
+    if want("blocks"): print("blocks"); gen_blocks(M)
+    if want("spec"): print("spectrogram models"); gen_spec_models(M)
+    if want("eegnet"): print("eegnet"); gen_eegnet(M)
+    if want("eegdeep"): print("eegnet attention deep"); gen_eegnet_deep(M)
+    if want("multimodal"): print("multimodal"); gen_multimodal(M, MM)
+    if want("attribution"): print("attribution"); gen_attribution(M, MM, NB)
+    if want("stacker"): print("stacker"); gen_stacker()
+    if want("montage"): print("montage stacker"); gen_montage(NB)
+    if want("specprep"): print("spectrogram pre-processing"); gen_spectrogram_prep(NB)
+    if only is None:
+        gen_manifest(M, MM)
     REPORT["_meta"] = {"torch": torch.__version__, "note": "max |oracle - reference| / max|reference| on full tensors"}
-    json.dump(REPORT, open(os.path.join(OUT, "PIN_REPORT.json"), "w"), indent=1, sort_keys=True)
+    json.dump(REPORT, open(report_path, "w"), indent=1, sort_keys=True)
     worst = max(v for k, v in REPORT.items() if k != "_meta")
     print(json.dumps(REPORT, indent=1, sort_keys=True))
     print("worst relative deviation oracle vs reference:", worst)

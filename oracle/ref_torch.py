@@ -13,8 +13,8 @@ their outputs on seeded inputs; ``tests/test_oracle_golden.py`` replays those
 fixtures through this file.
 
 Parity status per piece
-  * Block / Spectrogram_Model / EEGNet / MultimodalModel / KLDiv / AdamW step /
-    saliency / EEG stacker: pinned by reference outputs (fixtures).
+  * Block / Spectrogram_Model / EEGNet / EEGNetAttentionDeep / MultimodalModel / KLDiv /
+    AdamW step / saliency / EEG stacker: pinned by reference outputs (fixtures).
   * Grad-CAM, Integrated Gradients: the reference ships NO implementation
      -> "parity unpinned" by the reference; pinned here by the
     canonical definitions applied to the *reference's* model classes when the
@@ -145,6 +145,77 @@ class EEGNet(nn.Module):
         t["bn3"] = self.batchnorm3(t["sep"])
         t["pool2"] = self.dropout(self.avg_pool2(self.activation(t["bn3"])))
         t["out"] = self.log_softmax(self.dense(self.flatten(t["pool2"])))
+        return t
+
+    def forward(self, x):
+        return self.stages(x)["out"]
+
+
+# --------------------------------------------------------------------------------------
+# Row C' -- deeper EEGNet with a single-head self-attention over time (M:109-235)
+# --------------------------------------------------------------------------------------
+class Attention(nn.Module):
+    """softmax(Q K^T / sqrt(d)) V with three biased Linear maps (M:109-134); returns (output, weights)."""
+
+    def __init__(self, input_dim, attention_dim):
+        super().__init__()
+        self.query = nn.Linear(input_dim, attention_dim)
+        self.key = nn.Linear(input_dim, attention_dim)
+        self.value = nn.Linear(input_dim, attention_dim)
+        self.scale = attention_dim ** -0.5
+
+    def forward(self, x):
+        q, k, v = self.query(x), self.key(x), self.value(x)
+        w = torch.softmax(q @ k.transpose(-2, -1) * self.scale, dim=-1)
+        return w @ v, w
+
+
+class EEGNetAttentionDeep(nn.Module):
+    """EEGNet blocks 1-2 (own Dropout per block), a third block conv(1x16 'same', F2->F3) -> BN -> ELU -> avgpool8 ->
+    dropout, attention over the remaining time steps (tokens = time, features = F3), then Linear(F3*L,128) ->
+    Linear(128,nb_classes) with NO activation in between -> LogSoftmax (M:136-235)."""
+
+    def __init__(self, nb_classes, Chans=37, Samples=3000, dropoutRate=0.5, kernLength=64, F1=8, D=2, F2=16, F3=32,
+                 norm_rate=0.25, dropoutType="Dropout"):
+        super().__init__()
+        self.nb_classes, self.Chans, self.Samples = nb_classes, Chans, Samples
+        drop = (lambda: nn.Dropout(dropoutRate)) if dropoutType == "Dropout" else (lambda: nn.Dropout2d(dropoutRate))
+        self.conv1 = nn.Conv2d(1, F1, (1, kernLength), padding="same", bias=False)
+        self.batchnorm1 = nn.BatchNorm2d(F1)
+        self.depthwiseConv = nn.Conv2d(F1, F1 * D, (Chans, 1), groups=F1, bias=False)
+        self.batchnorm2 = nn.BatchNorm2d(F1 * D)
+        self.activation = nn.ELU()
+        self.avg_pool1 = nn.AvgPool2d((1, 4))
+        self.dropout1 = drop()
+        self.separableConv = nn.Conv2d(F1 * D, F2, (1, 16), padding="same", bias=False)
+        self.batchnorm3 = nn.BatchNorm2d(F2)
+        self.avg_pool2 = nn.AvgPool2d((1, 8))
+        self.dropout2 = drop()
+        self.conv2 = nn.Conv2d(F2, F3, (1, 16), padding="same", bias=False)
+        self.batchnorm4 = nn.BatchNorm2d(F3)
+        self.avg_pool3 = nn.AvgPool2d((1, 8))
+        self.dropout3 = drop()
+        self.attention_layer = Attention(F3, F3)
+        self.output_samples = ((Samples // 4) // 8) // 8        # what the reference finds with a dummy forward (M:180-202)
+        self.flattened_size = F3 * self.output_samples
+        self.flatten = nn.Flatten()
+        self.dense1 = nn.Linear(self.flattened_size, 128)
+        self.dense2 = nn.Linear(128, nb_classes)
+        self.log_softmax = nn.LogSoftmax(dim=1)
+
+    def stages(self, x):
+        t = {}
+        u = self.batchnorm2(self.depthwiseConv(self.batchnorm1(self.conv1(x))))
+        t["pool1"] = self.dropout1(self.avg_pool1(self.activation(u)))
+        t["pool2"] = self.dropout2(self.avg_pool2(self.activation(self.batchnorm3(self.separableConv(t["pool1"])))))
+        t["conv2"] = self.conv2(t["pool2"])
+        t["bn4"] = self.batchnorm4(t["conv2"])
+        t["pool3"] = self.dropout3(self.avg_pool3(self.activation(t["bn4"])))
+        b, c, h, w = t["pool3"].shape
+        tokens = t["pool3"].reshape(b, c, h * w).permute(0, 2, 1)          # [B, L, F3]
+        o, t["attn"] = self.attention_layer(tokens)
+        t["attended"] = o.permute(0, 2, 1).reshape(b, c, h, w)
+        t["out"] = self.log_softmax(self.dense2(self.dense1(self.flatten(t["attended"]))))
         return t
 
     def forward(self, x):

@@ -83,6 +83,30 @@ def test_eegnet(tag, chans, samples):
         check(fix, f"after.{k}.running_var", getattr(net, k).running_var)
 
 
+@pytest.mark.parametrize("tag,chans,samples,b", [("eegdeep19x2000", 19, 2000, 3), ("eegdeep37x3000", 37, 3000, 2)])
+def test_eegnet_attention_deep(tag, chans, samples, b):
+    """Row C' (models.py:109-235): third block, attention over time, two dense layers."""
+    fix = load(tag)
+    net = O.fill_params(O.EEGNetAttentionDeep(6, Chans=chans, Samples=samples, dropoutRate=0.0), seed=61)
+    x = O.seeded((b, 1, chans, samples), 62, "randn")
+    r = torch.from_numpy(fix["r"])
+    for mode in ("eval", "train"):
+        net.train(mode == "train")
+        net.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        st = net.stages(xi)
+        (st["out"] * r).sum().backward()
+        for k in ("out", "conv2", "bn4", "attn", "pool3"):
+            check(fix, f"{mode}.{k}", st[k])
+        check(fix, f"{mode}.dx.head", xi.grad[..., :96])
+        check(fix, f"{mode}.dx.tail", xi.grad[..., -96:])
+        for n, p in net.named_parameters():
+            check(fix, f"{mode}.grad.{n}", p.grad, tol=2e-5)
+    for k in ("batchnorm3", "batchnorm4"):
+        check(fix, f"after.{k}.running_var", getattr(net, k).running_var)
+    assert int(net.batchnorm4.num_batches_tracked) == int(fix["after.batchnorm4.num_batches_tracked"]) == 1
+
+
 @pytest.mark.parametrize("tag,cfg", [("mm_bench_small", (19, 2000, 4, 32, 64, 4)),
                                      ("mm_native_small", (37, 3000, 3, 50, 37, 2))])
 def test_multimodal_train3(tag, cfg):
