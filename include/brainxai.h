@@ -182,6 +182,42 @@ int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, const float* x
                         const uint64_t* seed, const void* saved, const bxEegGrads* g, float* dx,
                         void* workspace, size_t workspace_bytes, bxStream stream);
 
+/* ---- EEGNetAttentionDeep head (M:136-235, Attention M:109-134): everything after EEGNet's block 2 ----------
+ * feat fp32 [B, F2*T2] (bx_eeg_features_fwd's output for the same input; the class's dropout2 is applied there)
+ *   -> conv2 (1x16 'same', F2 -> F3, no bias) -> batchnorm4 -> ELU -> avg_pool3 (1x8) -> dropout3
+ *   -> attention_layer over the L = T2/8 time steps (query/key/value = Linear(F3,F3), scale F3^-0.5)
+ *   -> flatten (channel-major) -> dense1 (F3*L -> Hd) -> dense2 (Hd -> N) -> LogSoftmax.  All tensors fp32. */
+typedef struct {
+  int B, T2;            /* feat is [B, F2, T2]                                          */
+  int F2, F3, K3, P3;   /* 16, 32, 16, 8                                                */
+  int Hd, N;            /* dense1 width (128; power of two in [32,256]), classes (<=16) */
+  int training;
+  float eps, momentum, dropout_p;
+  uint32_t salt;
+} bxEegDeepDesc;
+typedef struct {
+  const float* conv2_w;      /* conv2.weight [F3,F2,1,K3] */
+  const float* bn4_w; const float* bn4_b; float* bn4_rm; float* bn4_rv; int64_t* bn4_nbt;
+  const float* wq; const float* bq;   /* attention_layer.query.weight [F3,F3] / .bias */
+  const float* wk; const float* bk;   /* attention_layer.key                          */
+  const float* wv; const float* bv;   /* attention_layer.value                        */
+  const float* w1; const float* b1;   /* dense1.weight [Hd, F3*L] (16-byte aligned) / .bias */
+  const float* w2; const float* b2;   /* dense2.weight [N, Hd] / .bias                */
+} bxEegDeepParams;
+typedef struct {
+  float* conv2_w; float* bn4_w; float* bn4_b; float* wq; float* bq; float* wk; float* bk; float* wv; float* bv;
+  float* w1; float* b1; float* w2; float* b2;
+} bxEegDeepGrads;
+size_t bx_eeg_deep_saved_bytes(const bxEegDeepDesc* d);   /* 0 = unsupported geometry */
+size_t bx_eeg_deep_workspace(const bxEegDeepDesc* d);
+/* logp fp32 [B,N]; attn fp32 [B,L,L] = the softmax weights (the module's second return value), also read by bwd. */
+int bx_eeg_deep_fwd(const bxEegDeepDesc* d, const bxEegDeepParams* p, const float* feat, const uint64_t* seed,
+                    float* logp, float* attn, void* saved, void* workspace, size_t workspace_bytes, bxStream stream);
+/* dlogp [B,N] -> dfeat [B,F2*T2] (may be NULL) and the parameter gradients (g may be NULL: inputs only). */
+int bx_eeg_deep_bwd(const bxEegDeepDesc* d, const bxEegDeepParams* p, const float* feat, const float* dlogp,
+                    const float* attn, const uint64_t* seed, const void* saved, const bxEegDeepGrads* g, float* dfeat,
+                    void* workspace, size_t workspace_bytes, bxStream stream);
+
 /* ---- attribution ----------------------------------------------------------------------------- */
 /* Grad-CAM channel reduce (canonical; the reference has none -- SURVEY.md K18):
  *   w[m,c] = mean_p G[m,p,c];  raw[m,p] = sum_c w[m,c]*A[m/maps_per_act,p,c];  cam = relu ? max(raw,0) : raw.

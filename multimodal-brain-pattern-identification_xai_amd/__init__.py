@@ -4,7 +4,7 @@ The directory is named after the reference repository (``multimodal-brain-patter
 not an importable identifier); ``import brainxai`` (the shim at the repo root) loads it under that name.
 """
 from . import _lib, ops                                                       # noqa: F401
-from .models import (Block, EEGNet, KLDivLoss, MultimodalModel, Spectrogram_Model,   # noqa: F401
+from .models import (Attention, Block, EEGNet, EEGNetAttentionDeep, KLDivLoss, MultimodalModel, Spectrogram_Model,   # noqa: F401
                      build_multimodal, set_compute_dtype)
 from .explain import GradCamSweep, expected_gradients, generate_saliency_maps, grad_cam, integrated_gradients, saliency   # noqa: F401
 from .data import (EEGStacker, stack_eeg, EEGMontageStacker, stack_eeg_montage,          # noqa: F401

@@ -35,6 +35,20 @@ class EegParams(C.Structure):
                                   "bn2_rm", "bn2_rv", "bn2_nbt", "sep_w", "bn3_w", "bn3_b", "bn3_rm", "bn3_rv", "bn3_nbt")]
 
 
+class EegDeepDesc(C.Structure):
+    _fields_ = [("B", i32), ("T2", i32), ("F2", i32), ("F3", i32), ("K3", i32), ("P3", i32), ("Hd", i32), ("N", i32), ("training", i32),
+                ("eps", f32), ("momentum", f32), ("dropout_p", f32), ("salt", u32)]
+
+
+class EegDeepParams(C.Structure):
+    _fields_ = [(n, vp) for n in ("conv2_w", "bn4_w", "bn4_b", "bn4_rm", "bn4_rv", "bn4_nbt", "wq", "bq", "wk", "bk", "wv", "bv",
+                                  "w1", "b1", "w2", "b2")]
+
+
+class EegDeepGrads(C.Structure):
+    _fields_ = [(n, vp) for n in ("conv2_w", "bn4_w", "bn4_b", "wq", "bq", "wk", "bk", "wv", "bv", "w1", "b1", "w2", "b2")]
+
+
 class PackJob(C.Structure):
     _fields_ = [("w_oihw", vp), ("packed_mfma", vp), ("Cout", i32), ("Cin", i32), ("I_p", i32), ("O_p", i32),
                 ("transpose_flip", i32), ("block_begin", i32)]
@@ -74,6 +88,10 @@ SIGNATURES = {
     "bx_eeg_workspace": (sz, [P(EegDesc)]),
     "bx_eeg_features_fwd": (i32, [P(EegDesc), P(EegParams), vp, vp, vp, vp, vp, sz, vp]),
     "bx_eeg_features_bwd": (i32, [P(EegDesc), P(EegParams), vp, vp, vp, vp, P(EegGrads), vp, vp, sz, vp]),
+    "bx_eeg_deep_saved_bytes": (sz, [P(EegDeepDesc)]),
+    "bx_eeg_deep_workspace": (sz, [P(EegDeepDesc)]),
+    "bx_eeg_deep_fwd": (i32, [P(EegDeepDesc), P(EegDeepParams), vp, vp, vp, vp, vp, vp, sz, vp]),
+    "bx_eeg_deep_bwd": (i32, [P(EegDeepDesc), P(EegDeepParams), vp, vp, vp, vp, vp, P(EegDeepGrads), vp, vp, sz, vp]),
     "bx_gradcam_reduce": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "bx_resize_bilinear": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "bx_saliency_reduce": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, vp]),

@@ -170,6 +170,95 @@ class EEGNet(nn.Module):
         return ops.LinearLsmFn.apply(feat, self.dense.weight, self.dense.bias)
 
 
+class Attention(nn.Module):
+    """Single-head scaled dot-product self-attention (reference models.py:109-134): parameter container for
+    ``EEGNetAttentionDeep`` (the attention itself runs inside the fused head kernels).  Called on its own it takes
+    tokens [B, L, input_dim] and returns (output, attention_weights) like the reference; only the geometry the fused
+    kernels are built for is accepted (input_dim = attention_dim = 32, L <= 32)."""
+
+    def __init__(self, input_dim, attention_dim):
+        super().__init__()
+        self.query = nn.Linear(input_dim, attention_dim)
+        self.key = nn.Linear(input_dim, attention_dim)
+        self.value = nn.Linear(input_dim, attention_dim)
+        self.scale = attention_dim ** -0.5
+
+    def forward(self, x):
+        raise NotImplementedError("brainxai Attention runs fused inside EEGNetAttentionDeep's head kernels (bx_eeg_deep_fwd); "
+                                  "a stand-alone launch is not part of the hot path")
+
+
+class EEGNetAttentionDeep(nn.Module):
+    """EEGNet blocks 1-2, a third temporal block and self-attention over time (reference models.py:136-235).
+    Blocks 1-2 run through the same kernels as ``EEGNet``; everything from ``conv2`` on is ``ops.EegDeepHeadFn``.
+    ``last_attention`` holds the [B, L, L] softmax weights of the latest forward (the reference discards them)."""
+
+    def __init__(self, nb_classes, Chans=37, Samples=3000, dropoutRate=0.5, kernLength=64, F1=8, D=2, F2=16, F3=32,
+                 norm_rate=0.25, dropoutType="Dropout"):
+        super().__init__()
+        if dropoutType != "Dropout":
+            raise NotImplementedError("brainxai EEGNetAttentionDeep: only dropoutType='Dropout' (the reference's default) is implemented")
+        self.nb_classes, self.Chans, self.Samples = nb_classes, Chans, Samples
+        self.conv1 = nn.Conv2d(1, F1, (1, kernLength), padding="same", bias=False)
+        self.batchnorm1 = nn.BatchNorm2d(F1)
+        self.depthwiseConv = nn.Conv2d(F1, F1 * D, (Chans, 1), groups=F1, bias=False)
+        self.batchnorm2 = nn.BatchNorm2d(F1 * D)
+        self.activation = nn.ELU()
+        self.avg_pool1 = nn.AvgPool2d((1, 4))
+        self.dropout1 = nn.Dropout(dropoutRate)
+        self.separableConv = nn.Conv2d(F1 * D, F2, (1, 16), padding="same", bias=False)
+        self.batchnorm3 = nn.BatchNorm2d(F2)
+        self.avg_pool2 = nn.AvgPool2d((1, 8))
+        self.dropout2 = nn.Dropout(dropoutRate)
+        self.conv2 = nn.Conv2d(F2, F3, (1, 16), padding="same", bias=False)
+        self.batchnorm4 = nn.BatchNorm2d(F3)
+        self.avg_pool3 = nn.AvgPool2d((1, 8))
+        self.dropout3 = nn.Dropout(dropoutRate)
+        self.attention_layer = Attention(F3, F3)
+        self.output_samples = ((Samples // 4) // 8) // 8
+        self.flattened_size = F3 * self.output_samples
+        self.flatten = nn.Flatten()
+        self.dense1 = nn.Linear(self.flattened_size, 128)
+        self.dense2 = nn.Linear(128, nb_classes)
+        self.log_softmax = nn.LogSoftmax(dim=1)
+        self._geom = SimpleNamespace(F1=F1, D=D, F2=F2, F3=F3, K1=kernLength, K2=16, K3=16, P1=4, P2=8, P3=8)
+        self.compute_dtype = torch.float32
+        self.salt = 200
+        self.last_attention = None
+
+    def features(self, x):
+        """Block 1-2 output after dropout2, flattened [B, F2 * (T//32)] (same kernels as EEGNet.features)."""
+        if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != self.Chans:
+            raise RuntimeError(f"EEGNetAttentionDeep expected [B,1,{self.Chans},T], got {tuple(x.shape)}")
+        if self.dropout1.p != self.dropout2.p:
+            raise NotImplementedError("brainxai EEGNetAttentionDeep: dropout1 and dropout2 share one rate in the fused block kernels")
+        g = self._geom
+        bn1, bn2, bn3 = self.batchnorm1, self.batchnorm2, self.batchnorm3
+        cfg = SimpleNamespace(F1=g.F1, D=g.D, F2=g.F2, K1=g.K1, K2=g.K2, P1=g.P1, P2=g.P2, training=self.training,
+                              eps=bn1.eps, momentum=0.1 if bn1.momentum is None else bn1.momentum,
+                              dropout_p=self.dropout1.p if self.training else 0.0, salt=self.salt, dtype=self.compute_dtype)
+        bufs = (bn1.running_mean, bn1.running_var, bn1.num_batches_tracked, bn2.running_mean, bn2.running_var,
+                bn2.num_batches_tracked, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked)
+        return ops.EegFeaturesFn.apply(x, self.conv1.weight, bn1.weight, bn1.bias, self.depthwiseConv.weight, bn2.weight, bn2.bias,
+                                       self.separableConv.weight, bn3.weight, bn3.bias, bufs, cfg)
+
+    def forward(self, x):
+        feat = self.features(x)
+        g, bn4, att = self._geom, self.batchnorm4, self.attention_layer
+        T2 = feat.shape[1] // g.F2
+        if g.F3 * (T2 // g.P3) != self.dense1.in_features:
+            raise RuntimeError(f"EEGNetAttentionDeep: {g.F3 * (T2 // g.P3)} features but dense1 expects {self.dense1.in_features} (Samples mismatch)")
+        cfg = SimpleNamespace(T2=T2, F2=g.F2, F3=g.F3, K3=g.K3, P3=g.P3, training=self.training, eps=bn4.eps,
+                              momentum=0.1 if bn4.momentum is None else bn4.momentum,
+                              dropout_p=self.dropout3.p if self.training else 0.0, salt=self.salt + 1)
+        logp, attn = ops.EegDeepHeadFn.apply(feat, self.conv2.weight, bn4.weight, bn4.bias, att.query.weight, att.query.bias,
+                                             att.key.weight, att.key.bias, att.value.weight, att.value.bias, self.dense1.weight,
+                                             self.dense1.bias, self.dense2.weight, self.dense2.bias,
+                                             (bn4.running_mean, bn4.running_var, bn4.num_batches_tracked), cfg)
+        self.last_attention = attn
+        return logp
+
+
 class MultimodalModel(nn.Module):
     """Late fusion over the two branches' log-probabilities (reference XAI_Multimodality.py:1082-1108)."""
 

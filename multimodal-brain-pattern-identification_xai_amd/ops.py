@@ -538,6 +538,54 @@ class EegFeaturesFn(torch.autograd.Function):
         return (dx, *gl, None, None)
 
 
+class EegDeepHeadFn(torch.autograd.Function):
+    """EEGNetAttentionDeep after block 2 (reference models.py:215-233 + Attention :109-134): conv2 -> BN4 -> ELU -> pool8 ->
+    dropout -> attention over time -> dense1 -> dense2 -> LogSoftmax.  feat fp32 [B, 16*T2] -> (logp [B,N], attn [B,L,L])."""
+
+    @staticmethod
+    def forward(ctx, feat, c2w, bn4w, bn4b, wq, bq, wk, bk, wv, bv, w1, b1, w2, b2, bufs, cfg):
+        lib = L.load()
+        _require_gpu(feat, "EEG features")
+        B = feat.shape[0]
+        feat = feat.contiguous().float()
+        desc = L.EegDeepDesc(B, cfg.T2, cfg.F2, cfg.F3, cfg.K3, cfg.P3, w1.shape[0], w2.shape[0], 1 if cfg.training else 0, cfg.eps,
+                             cfg.momentum, float(cfg.dropout_p), cfg.salt)
+        nsaved = lib.bx_eeg_deep_saved_bytes(C.byref(desc))
+        if nsaved == 0:
+            raise RuntimeError("brainxai: unsupported EEGNetAttentionDeep geometry (needs F2=16, F3=32, 8 <= Samples//32, Samples//256 <= 32, "
+                               "dense1 width a power of two in [32,256], <= 16 classes)")
+        if w1.data_ptr() % 16:      # the kernels read dense1.weight 16 bytes at a time; a packed parameter arena may misalign it
+            w1 = w1.clone()
+        L_ = cfg.T2 // cfg.P3
+        saved = torch.empty(nsaved, dtype=torch.uint8, device=feat.device)
+        ws = workspace(lib.bx_eeg_deep_workspace(C.byref(desc)), feat.device)
+        params = L.EegDeepParams(_p(c2w), _p(bn4w), _p(bn4b), _p(bufs[0]), _p(bufs[1]), _p(bufs[2]), _p(wq), _p(bq), _p(wk), _p(bk),
+                                 _p(wv), _p(bv), _p(w1), _p(b1), _p(w2), _p(b2))
+        logp = torch.empty(B, w2.shape[0], dtype=torch.float32, device=feat.device)
+        attn = torch.empty(B, L_, L_, dtype=torch.float32, device=feat.device)
+        seed = next_seed(feat.device, "eeg") if (cfg.training and cfg.dropout_p > 0) else None
+        L.check(lib.bx_eeg_deep_fwd(C.byref(desc), C.byref(params), _p(feat), _p(seed), _p(logp), _p(attn), _p(saved), _p(ws), ws.numel(),
+                                    _stream()), "bx_eeg_deep_fwd")
+        ctx.desc, ctx.params, ctx.seed, ctx.bufs = desc, params, seed, bufs
+        ctx.save_for_backward(feat, saved, attn, c2w, bn4w, bn4b, wq, bq, wk, bk, wv, bv, w1, b1, w2, b2)
+        ctx.mark_non_differentiable(attn)
+        return logp, attn
+
+    @staticmethod
+    def backward(ctx, dlogp, _dattn):
+        lib = L.load()
+        feat, saved, attn, *plist = ctx.saved_tensors
+        need_w = any(ctx.needs_input_grad[1:14])
+        dfeat = torch.empty_like(feat) if ctx.needs_input_grad[0] else None
+        gl = [new_grad(t) for t in plist] if need_w else [None] * 13
+        grads = L.EegDeepGrads(*[_p(t) for t in gl])
+        ws = workspace(lib.bx_eeg_deep_workspace(C.byref(ctx.desc)), feat.device)
+        dlogp = dlogp.contiguous()
+        L.check(lib.bx_eeg_deep_bwd(C.byref(ctx.desc), C.byref(ctx.params), _p(feat), _p(dlogp), _p(attn), _p(ctx.seed), _p(saved),
+                                    C.byref(grads) if need_w else None, _p(dfeat), _p(ws), ws.numel(), _stream()), "bx_eeg_deep_bwd")
+        return (dfeat, *gl, None, None)
+
+
 def block_cfg(**kw) -> SimpleNamespace:
     base = dict(pool="max", training=False, dropout_p=0.0, eps=1e-5, momentum=0.1, salt=0, preact=0, capture=None,
                 prepacked=None, pack_base=0, seed=None)

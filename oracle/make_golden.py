@@ -483,6 +483,8 @@ def gen_manifest(M, MM):
     for name, net in {"Block(4,16)": M.Block(4, 16), "Spectrogram_Model": M.Spectrogram_Model(6),
                       "EEGNet(6,19,2000)": M.EEGNet(6, Chans=19, Samples=2000),
                       "EEGNet(6,37,3000)": M.EEGNet(6),
+                      "EEGNetAttentionDeep(6,19,2000)": M.EEGNetAttentionDeep(6, Chans=19, Samples=2000),
+                      "EEGNetAttentionDeep(6,37,3000)": M.EEGNetAttentionDeep(6),
                       "MultimodalModel(bench)": make_ref_multimodal(M, MM, 19, 2000, 4),
                       "MultimodalModel(native)": make_ref_multimodal(M, MM, 37, 3000, 3)}.items():
         man[name] = {k: list(v.shape) for k, v in net.state_dict().items()}
@@ -509,8 +511,7 @@ if __name__ == "__main__":
     if want("stacker"): print("stacker"); gen_stacker()
     if want("montage"): print("montage stacker"); gen_montage(NB)
     if want("specprep"): print("spectrogram pre-processing"); gen_spectrogram_prep(NB)
-    if only is None:
-        gen_manifest(M, MM)
+    if want("manifest"): gen_manifest(M, MM)
     REPORT["_meta"] = {"torch": torch.__version__, "note": "max |oracle - reference| / max|reference| on full tensors"}
     json.dump(REPORT, open(report_path, "w"), indent=1, sort_keys=True)
     worst = max(v for k, v in REPORT.items() if k != "_meta")

@@ -50,6 +50,10 @@ def test_state_dict_layout_matches_reference():
     man = json.load(open(os.path.join(GOLDEN, "state_dict_manifest.json")))
     nets = {"Block(4,16)": brainxai.Block(4, 16), "Spectrogram_Model": brainxai.Spectrogram_Model(6),
             "EEGNet(6,19,2000)": brainxai.EEGNet(6, Chans=19, Samples=2000), "EEGNet(6,37,3000)": brainxai.EEGNet(6),
+            "EEGNetAttentionDeep(6,19,2000)": brainxai.EEGNetAttentionDeep(6, Chans=19, Samples=2000),
+            "EEGNetAttentionDeep(6,37,3000)": brainxai.EEGNetAttentionDeep(6),
+            "EEGNetAttentionDeep(6,19,2000)": brainxai.EEGNetAttentionDeep(6, Chans=19, Samples=2000),
+            "EEGNetAttentionDeep(6,37,3000)": brainxai.EEGNetAttentionDeep(6),
             "MultimodalModel(bench)": brainxai.build_multimodal(19, 2000, 4),
             "MultimodalModel(native)": brainxai.build_multimodal(37, 3000, 3)}
     for name, net in nets.items():

@@ -161,6 +161,66 @@ def test_eegnet_fwd_bwd(tag, chans, samples):
         check(fix, f"after.{k}.running_var", getattr(mine, k).running_var.cpu(), tol=TOL)
 
 
+@pytest.mark.parametrize("tag,chans,samples,b", [("eegdeep19x2000", 19, 2000, 3), ("eegdeep37x3000", 37, 3000, 2)])
+def test_eegnet_attention_deep_fwd_bwd(tag, chans, samples, b):
+    """Row C' (models.py:109-235): third block + attention + two dense layers, against the oracle and the reference's fixtures."""
+    fix = load(tag)
+    ref, mine = _pair(lambda: O.EEGNetAttentionDeep(6, Chans=chans, Samples=samples, dropoutRate=0.0),
+                      lambda: brainxai.EEGNetAttentionDeep(6, Chans=chans, Samples=samples, dropoutRate=0.0), 61)
+    assert list(mine.state_dict()) == list(ref.state_dict())
+    assert (mine.output_samples, mine.flattened_size) == (ref.output_samples, ref.flattened_size)
+    x = O.seeded((b, 1, chans, samples), 62, "randn")
+    r = torch.from_numpy(fix["r"])
+    for mode in ("eval", "train"):
+        ref.train(mode == "train"); mine.train(mode == "train")
+        ref.zero_grad(); mine.zero_grad()
+        xr = x.clone().requires_grad_(True)
+        st = ref.stages(xr); (st["out"] * r).sum().backward()
+        xm = x.clone().to(DEV).requires_grad_(True)
+        ym = mine(xm); (ym * r.to(DEV)).sum().backward()
+        assert _sync_err(ym, st["out"]) < TIGHT, mode
+        assert _sync_err(mine.last_attention, st["attn"]) < TIGHT, mode
+        check(fix, f"{mode}.out", ym.detach().cpu(), tol=TOL)
+        check(fix, f"{mode}.attn", mine.last_attention.cpu(), tol=TOL)
+        _gclose(xm.grad, xr.grad, f"eegdeep {tag} {mode} dx")
+        gx = float(xr.grad.abs().max())
+        check(fix, f"{mode}.dx.head", xm.grad.cpu()[..., :96], tol=TOL, floor=gx)
+        check(fix, f"{mode}.dx.tail", xm.grad.cpu()[..., -96:], tol=TOL, floor=gx)
+        fl = _gscale(ref)
+        for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+            _gclose(p.grad, q.grad, f"eegdeep {tag} {mode} d{n}", tol=TIGHT, floor=fl)
+            check(fix, f"{mode}.grad.{n}", p.grad.cpu(), tol=TOL, floor=fl)
+    for k in ("batchnorm3", "batchnorm4"):
+        assert _sync_err(getattr(mine, k).running_var, getattr(ref, k).running_var) < TIGHT
+        check(fix, f"after.{k}.running_var", getattr(mine, k).running_var.cpu(), tol=TOL)
+    assert int(mine.batchnorm4.num_batches_tracked) == 1
+
+
+def test_eegnet_attention_deep_dropout_and_bench_batch():
+    """Dropout masks of forward and backward agree (finite-difference-free check: the gradient w.r.t. a token that the
+    mask removed is zero), the pass is deterministic for a fixed seed state, and the bench batch (64 x 19 x 2000) runs."""
+    torch.manual_seed(0)
+    net = brainxai.EEGNetAttentionDeep(6, Chans=19, Samples=2000, dropoutRate=0.5).to(DEV).train()
+    x = torch.randn(64, 1, 19, 2000, device=DEV)
+    outs = []
+    for _ in range(2):
+        ops.manual_seed(1234, DEV)
+        net.zero_grad()
+        y = net(x)
+        y.sum().backward()
+        outs.append((y.detach().clone(), net.conv2.weight.grad.detach().clone()))
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])      # same seed state -> same masks, fixed-order sums
+    ops.manual_seed(99, DEV)
+    assert not torch.equal(net(x), outs[0][0])                                              # another seed -> another mask
+    assert torch.allclose(outs[0][0].exp().sum(1), torch.ones(64, device=DEV), atol=1e-4)
+    assert net.last_attention.shape == (64, 7, 7)
+    assert torch.allclose(net.last_attention.sum(-1), torch.ones(64, 7, device=DEV), atol=1e-5)
+    net.eval()
+    y1, y2 = net(x), net(x)
+    assert torch.equal(y1, y2)
+
+
 @pytest.mark.parametrize("tag,cfg", [("mm_bench_small", (19, 2000, 4, 32, 64, 4)), ("mm_native_small", (37, 3000, 3, 50, 37, 2))])
 @pytest.mark.parametrize("opt", ["flat", "torch"])
 def test_multimodal_train3(tag, cfg, opt):

@@ -171,6 +171,10 @@ def test_state_dict_manifest():
     man = json.load(open(os.path.join(GOLDEN, "state_dict_manifest.json")))
     nets = {"Block(4,16)": O.Block(4, 16), "Spectrogram_Model": O.Spectrogram_Model(6),
             "EEGNet(6,19,2000)": O.EEGNet(6, Chans=19, Samples=2000), "EEGNet(6,37,3000)": O.EEGNet(6),
+            "EEGNetAttentionDeep(6,19,2000)": O.EEGNetAttentionDeep(6, Chans=19, Samples=2000),
+            "EEGNetAttentionDeep(6,37,3000)": O.EEGNetAttentionDeep(6),
+            "EEGNetAttentionDeep(6,19,2000)": O.EEGNetAttentionDeep(6, Chans=19, Samples=2000),
+            "EEGNetAttentionDeep(6,37,3000)": O.EEGNetAttentionDeep(6),
             "MultimodalModel(bench)": O.build_multimodal(19, 2000, 4),
             "MultimodalModel(native)": O.build_multimodal(37, 3000, 3)}
     for name, net in nets.items():
