@@ -338,6 +338,25 @@ def main():
         cpu["spectrogram_prep_samples_per_sec"] = round(4 / (time.perf_counter() - t0), 2)
 
     if rank == 0:
+        # SURVEY 8(a) row C': the deeper EEG-only variant (EEGNetAttentionDeep), eager train steps on the same EEG batch
+        deep = brainxai.set_compute_dtype(brainxai.EEGNetAttentionDeep(6, Chans=CHANS, Samples=T), cdt).to(dev).train()
+        dopt = brainxai.FlatAdamW(deep.parameters(), lr=1e-3)
+
+        def deep_step():
+            dopt.zero_grad()
+            dl = crit(deep(eeg), labels)
+            dl.backward()
+            dopt.step()
+        for _ in range(3):
+            deep_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            deep_step()
+        torch.cuda.synchronize()
+        extra["eegnet_attention_deep_train_samples_per_sec"] = round(10 * B / (time.perf_counter() - t0), 1)
+        del deep, dopt
+    if rank == 0:
         line = {"metric": "samples/sec train (multimodal SpectrogramCNN+EEGNet fusion, B=64/GPU, 4x128x256 spectro + 10000x19 EEG)",
                 "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -504,7 +504,9 @@ __global__ __launch_bounds__(256) void k_deep_conv_bwd(const float* __restrict__
   __shared__ __attribute__((aligned(16))) float xp[DP_F2][DP_XP];   // column j <-> time t0 + j - 7
   __shared__ float wt[DP_F3 * DP_K][DP_F2 + 1];             // [o][k][i], pitch 17
   const int b = blockIdx.x, t0 = blockIdx.y * DP_TC, tid = threadIdx.x;
-  {
+  // blockIdx.z selects the role when both are wanted (two half-length workgroups instead of one): 0 = (a), 1 = (b)
+  if (gridDim.z == 2) { if (blockIdx.z == 0) want_w = 0; else dfeat = nullptr; }
+  if (dfeat) {
     float tmp[32];
 #pragma unroll
     for (int u = 0; u < 32; ++u) tmp[u] = w[tid + u * 256];
@@ -665,7 +667,7 @@ extern "C" int bx_eeg_deep_bwd(const bxEegDeepDesc* d, const bxEegDeepParams* p,
                      want_w ? gr->bn4_w : nullptr, want_w ? gr->bn4_b : nullptr);
   float* wpart = (float*)(ws + g.w_wpart);
   if (dfeat || want_w)
-    hipLaunchKernelGGL(k_deep_conv_bwd, dim3(g.B, g.nchunk), dim3(256), 0, s, a.dv, a.z, stats, coef, feat, p->conv2_w, dfeat, wpart, g.T2, want_w);
+    hipLaunchKernelGGL(k_deep_conv_bwd, dim3(g.B, g.nchunk, (dfeat && want_w) ? 2 : 1), dim3(256), 0, s, a.dv, a.z, stats, coef, feat, p->conv2_w, dfeat, wpart, g.T2, want_w);
   if (want_w) {
     if (gr->conv2_w) BX_SUM_PARTIALS(wpart, gr->conv2_w, g.B * g.nchunk, DP_F3 * DP_F2 * DP_K, s);
     DeepQkvOut qo;

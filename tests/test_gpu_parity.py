@@ -674,7 +674,8 @@ def test_train_and_validate_combined_loop(tmp_path):
         ops.clear_grad_views()
 
 
-def test_train_and_validate_eeg_distributed_single_rank(tmp_path):
+@pytest.mark.parametrize("arch", ["EEGNet", "EEGNetAttentionDeep"])
+def test_train_and_validate_eeg_distributed_single_rank(tmp_path, arch):
     """row F: reference training_distributed.py loop on a 1-rank RCCL group: DDP wrapper, manual L2 term, module.-prefixed
     checkpoint with the extra keys the reference's load_checkpoint expects"""
     import socket
@@ -682,7 +683,7 @@ def test_train_and_validate_eeg_distributed_single_rank(tmp_path):
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.manual_seed(5)
-    net = brainxai.EEGNet(6, Chans=19, Samples=2000, dropoutRate=0.25)
+    net = getattr(brainxai, arch)(6, Chans=19, Samples=2000, dropoutRate=0.25)
     net.weight_decay = 1e-4
     data = [(O.seeded((4, 1, 19, 2000), 70 + i, "randn"), torch.softmax(O.seeded((4, 6), 80 + i, "randn"), 1)) for i in range(3)]
     net.to(DEV)
