@@ -278,9 +278,9 @@ extern "C" int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void
 // backward
 // reduce: per channel  s1 = sum dD,  s2 = sum dD * xhat,  s3 = sum dOut   (dD = dOut * dropout multiplier)
 template <typename T>
-__global__ __launch_bounds__(256) void k_tail_bwd_reduce(const T* __restrict__ dout, const T* __restrict__ pooled,
+__device__ __forceinline__ void tail_bwd_reduce_body(const T* __restrict__ dout, const T* __restrict__ pooled,
     const float* __restrict__ mean, const float* __restrict__ invstd, const uint64_t* __restrict__ seed, float dropout_p,
-    uint32_t salt, float* __restrict__ partials, TailGeom g) {
+    uint32_t salt, float* __restrict__ partials, const TailGeom& g, int bid, int nblocks) {
   __shared__ float lds[2048];
   const int cg = threadIdx.x % g.ncg, slot = threadIdx.x / g.ncg;
   const uint64_t sd = (dropout_p > 0.f && seed) ? seed[0] : 0;
@@ -288,8 +288,8 @@ __global__ __launch_bounds__(256) void k_tail_bwd_reduce(const T* __restrict__ d
   float mu[8], is[8], acc[3][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { mu[j] = mean[cg * 8 + j]; is[j] = invstd[cg * 8 + j]; acc[0][j] = acc[1][j] = acc[2][j] = 0.f; }
-  const long long stride = (long long)gridDim.x * g.slots;
-  for (long long pp0 = (long long)blockIdx.x * g.slots + slot; pp0 < g.npool; pp0 += 2 * stride) {   // two pixels per trip
+  const long long stride = (long long)nblocks * g.slots;
+  for (long long pp0 = (long long)bid * g.slots + slot; pp0 < g.npool; pp0 += 2 * stride) {   // two pixels per trip
     float go[2][8], pv[2][8];
     bool ok[2];
 #pragma unroll
@@ -316,14 +316,14 @@ __global__ __launch_bounds__(256) void k_tail_bwd_reduce(const T* __restrict__ d
   block_channel_reduce<3>(acc, lds, g.C, g.ncg, g.slots, red);
   if ((int)threadIdx.x < g.C)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) partials[((size_t)blockIdx.x * 3 + k) * g.C + threadIdx.x] = red[k];
+    for (int k = 0; k < 3; ++k) partials[((size_t)bid * 3 + k) * g.C + threadIdx.x] = red[k];
 }
 
-__global__ void k_tail_bwd_finalize(const float* __restrict__ partials, int nblk, double count, int C, int training,
+__device__ __forceinline__ void tail_bwd_finalize_body(const float* __restrict__ partials, int nblk, double count, int C, int training,
                                     const float* __restrict__ gamma, const float* __restrict__ invstd, float* __restrict__ coef,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db1x1) {
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db1x1, int bid) {
   double s[3] = {0.0, 0.0, 0.0};
-  const int CG = C < 16 ? C : 16, c0 = blockIdx.x * CG;            // grid = bx_finalize_grid(C)
+  const int CG = C < 16 ? C : 16, c0 = bid * CG;                   // bx_finalize_grid(C) workgroups
   sum_partials_256<3>(partials, nblk, C, c0, CG, s);
   const int c = c0 + threadIdx.x;
   if ((int)threadIdx.x >= CG || c >= C) return;
@@ -394,12 +394,12 @@ __global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ do
 // thread (CIV = 8, or 4 when the map is so small that 8 would leave most CUs without a workgroup); the weight matrix
 // streams through LDS in 64-output-channel slabs ([c][Cin_p], zero padded), dOut comes straight from global as 16-byte vectors.
 template <typename T, int CIV>
-__global__ __launch_bounds__(256) void k_skip_dxs(const T* __restrict__ dout, const float* __restrict__ w1x1, int Cin,
-                                                   float* __restrict__ dxs, T* __restrict__ dx_even, TailGeom g) {
+__device__ __forceinline__ void skip_dxs_body(const T* __restrict__ dout, const float* __restrict__ w1x1, int Cin,
+                                              float* __restrict__ dxs, T* __restrict__ dx_even, const TailGeom& g, int bid) {
   extern __shared__ __attribute__((aligned(16))) float swt[];   // [64][Cin_p]
   const int ncv = g.Cin_p / CIV;
   const long long n = g.npool * ncv;
-  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long u = (long long)bid * 256 + threadIdx.x;
   const bool live = u < n;
   const unsigned u32 = live ? (unsigned)u : 0u;
   const long long pp = (long long)(u32 / (unsigned)ncv);
@@ -515,13 +515,13 @@ __global__ __launch_bounds__(256) void k_skip_scatter(const float* __restrict__ 
 // conv1x1 weight gradient: dW[c][ci] = sum_p dOut[p][c] * xs[p][ci]; 16x16 output tile per workgroup,
 // pixel chunks over blockIdx.x, partials reduced in fixed order.
 template <typename T>
-__global__ __launch_bounds__(256) void k_w1x1_grad(const T* __restrict__ dout, const T* __restrict__ x, float* __restrict__ partial,
-                                                    int pix_per_chunk, TailGeom g) {
+__device__ __forceinline__ void w1x1_grad_body(const T* __restrict__ dout, const T* __restrict__ x, float* __restrict__ partial,
+                                               int pix_per_chunk, const TailGeom& g, int bx, int by, int bz) {
   __shared__ float sd[64][17], sxs[64][17];
   const int c = threadIdx.x >> 4, ci = threadIdx.x & 15;
-  const int c0 = blockIdx.y * 16, ci0 = blockIdx.z * 16;
+  const int c0 = by * 16, ci0 = bz * 16;
   float acc = 0.f;
-  const long long p_begin = (long long)blockIdx.x * pix_per_chunk;
+  const long long p_begin = (long long)bx * pix_per_chunk;
   long long p_end = p_begin + pix_per_chunk;
   if (p_end > g.npool) p_end = g.npool;
   // threads 0..127 stage 64 pixels x 2 halves of dOut, threads 128..255 the bilinear-sampled input; the next trip's
@@ -554,14 +554,71 @@ __global__ __launch_bounds__(256) void k_w1x1_grad(const T* __restrict__ dout, c
 #pragma unroll 8
     for (int q = 0; q < 64; ++q) acc = fmaf(sd[q][c], sxs[q][ci], acc);
   }
-  if (ci0 + ci < g.Cin_p) partial[((size_t)blockIdx.x * g.C + c0 + c) * g.Cin_p + ci0 + ci] = acc;
+  if (ci0 + ci < g.Cin_p) partial[((size_t)bx * g.C + c0 + c) * g.Cin_p + ci0 + ci] = acc;
 }
-// dW1x1: partial layout [chunk][C][Cin_p]; when Cin == Cin_p the sum lands directly in the OIHW gradient,
-// otherwise (padded first stage) it goes through a compaction.
-__global__ void k_w1x1_compact(const float* __restrict__ src, float* __restrict__ dw, int C, int Cin, int Cin_p) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= C * Cin) return;
-  dw[idx] = src[(idx / Cin) * Cin_p + idx % Cin];
+
+// ---- merged launches of the block-tail backward ---------------------------------------------------------------------
+// A kernel boundary costs ~5 us here (drain, L2 write-back, next dispatch) and the late stages' tail kernels are a few
+// microseconds of latency-bound work each, so independent pieces share a launch, the role chosen by workgroup index:
+//   front: [BN/dropout reduction | 1x1-skip weight-gradient partials | 1x1-skip input gradient]   (all read only dOut)
+//   mid:   [BN-backward finalize | fixed-order sum of the weight-gradient partials (+ un-padding of the first stage)]
+// followed by the apply kernel.  6-7 launches per block become 3.
+template <typename T>
+struct TailFrontArgs {
+  const T *dout, *pooled, *x;
+  const float *mean, *invstd, *w1x1;
+  const uint64_t* seed;
+  float *partials, *wpart, *dxs;
+  T* dx_even;
+  float dropout_p;
+  uint32_t salt;
+  int n_red, n_w, wg_x, wg_y, ppc, Cin;
+};
+template <typename T, int CIV>
+__global__ __launch_bounds__(256) void k_tail_bwd_front(TailFrontArgs<T> a, TailGeom g) {
+  int bid = blockIdx.x;
+  if (bid < a.n_red) { tail_bwd_reduce_body<T>(a.dout, a.pooled, a.mean, a.invstd, a.seed, a.dropout_p, a.salt, a.partials, g, bid, a.n_red); return; }
+  bid -= a.n_red;
+  if (bid < a.n_w) {
+    const int bx = bid % a.wg_x, r = bid / a.wg_x;
+    w1x1_grad_body<T>(a.dout, a.x, a.wpart, a.ppc, g, bx, r % a.wg_y, r / a.wg_y);
+    return;
+  }
+  skip_dxs_body<T, CIV>(a.dout, a.w1x1, a.Cin, a.dxs, a.dx_even, g, bid - a.n_w);
+}
+// mid: 1024 threads.  Workgroups [0, n_fin) finalize 16 channels each; the others sum weight-gradient partials, four
+// 256-thread groups per workgroup, each group as in k_sum_partials; (c, ci) of the padded layout goes to dw[c][ci < Cin].
+__global__ __launch_bounds__(1024) void k_tail_bwd_mid(const float* __restrict__ partials, int nblk, double count, int C, int training,
+                                                       const float* __restrict__ gamma, const float* __restrict__ invstd, float* __restrict__ coef,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db1x1, int n_fin,
+                                                       const float* __restrict__ wpart, float* __restrict__ dw, int nchunk, int Cin, int Cin_p, int S) {
+  if ((int)blockIdx.x < n_fin) {
+    tail_bwd_finalize_body(partials, nblk, count, C, training, gamma, invstd, coef, dgamma, dbeta, db1x1, blockIdx.x);
+    return;
+  }
+  __shared__ float sm[1024];
+  const int n = C * Cin_p, NO = 256 / S;
+  const int grp = threadIdx.x >> 8, t = threadIdx.x & 255;
+  const int o = t % NO, sl = t / NO;
+  const int i = (((int)blockIdx.x - n_fin) * 4 + grp) * NO + o;
+  float s = 0.f;
+  if (i < n) {
+    int k = sl;
+    for (; k + 3 * S < nchunk; k += 4 * S) {
+      const float v0 = wpart[(size_t)k * n + i], v1 = wpart[(size_t)(k + S) * n + i];
+      const float v2 = wpart[(size_t)(k + 2 * S) * n + i], v3 = wpart[(size_t)(k + 3 * S) * n + i];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; k < nchunk; k += S) s += wpart[(size_t)k * n + i];
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    float r = sm[grp * 256 + o];
+    for (int k = 1; k < S; ++k) r += sm[grp * 256 + k * NO + o];
+    const int c = i / Cin_p, ci = i - c * Cin_p;
+    if (ci < Cin) dw[(size_t)c * Cin + ci] = r;
+  }
 }
 
 extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const void* y3, const void* x, const void* pooled,
@@ -586,51 +643,48 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
   float* dxs = coef + 3 * g.C;
   float* wpart = (float*)((char*)dxs + bx_align_up((size_t)g.npool * g.Cin_p * sizeof(float), 256));
 
-  BX_DISPATCH_DTYPE(d->dtype, T,
-    hipLaunchKernelGGL((k_tail_bwd_reduce<T>), dim3(nblk), dim3(256), 0, s, (const T*)dout, (const T*)pooled, save_mean, save_invstd,
-                       seed, p, d->salt, partials, g));
-  BX_CHECK_LAUNCH("bx_block_tail_bwd(reduce)");
-  hipLaunchKernelGGL(k_tail_bwd_finalize, dim3(bx_finalize_grid(g.C)), dim3(1024), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight,
-                     save_invstd, coef, d_bn_weight, d_bn_bias, d_b1x1);
-  BX_CHECK_LAUNCH("bx_block_tail_bwd(finalize)");
-  BX_DISPATCH_DTYPE(d->dtype, T,
-    hipLaunchKernelGGL((k_tail_bwd_apply<T>), dim3(tail_blocks_all(g)), dim3(256), 0, s, (const T*)dout, (const T*)pooled, (const T*)y3, save_mean,
-                       save_invstd, coef, seed, p, d->salt, d->pool, (T*)dz3, g));
-  BX_CHECK_LAUNCH("bx_block_tail_bwd(apply)");
+  // ---- front: reduction | w1x1 weight-gradient partials | skip input gradient
+  const bool even = (g.H % 2 == 0) && (g.W % 2 == 0);
+  int nchunk = 0, ppc = 0, wg_y = g.C / 16, wg_z = (g.Cin_p + 15) / 16;
   if (d_w1x1) {
     // up to ~4096 workgroups in total; partial buffer = nchunk * C * Cin_p floats <= 2048*256 + 64*C*Cin_p (workspace formula)
-    const int otiles = (g.C / 16) * ((g.Cin_p + 15) / 16);
-    int nchunk = (int)((g.npool + 63) / 64);
+    const int otiles = wg_y * wg_z;
+    nchunk = (int)((g.npool + 63) / 64);
     int cap = 4096 / otiles;
     if (cap < 64) cap = 64;
     while ((size_t)cap * g.C * g.Cin_p > (size_t)2048 * 256 + (size_t)64 * g.C * g.Cin_p) cap /= 2;
     if (nchunk > cap) nchunk = cap;
-    int ppc = (int)((g.npool + nchunk - 1) / nchunk);
+    ppc = (int)((g.npool + nchunk - 1) / nchunk);
     ppc = (ppc + 63) / 64 * 64;
     nchunk = (int)((g.npool + ppc - 1) / ppc);
-    dim3 grid(nchunk, g.C / 16, (g.Cin_p + 15) / 16);
-    BX_DISPATCH_DTYPE(d->dtype, T,
-      hipLaunchKernelGGL((k_w1x1_grad<T>), grid, dim3(256), 0, s, (const T*)dout, (const T*)x, wpart, ppc, g));
-    BX_CHECK_LAUNCH("bx_block_tail_bwd(w1x1)");
-    if (Cin == g.Cin_p) {
-      BX_SUM_PARTIALS(wpart, d_w1x1, nchunk, g.C * g.Cin_p, s);
-    } else {
-      float* tmp = wpart + (size_t)nchunk * g.C * g.Cin_p;           // spare room behind the partials (workspace formula)
-      BX_SUM_PARTIALS(wpart, tmp, nchunk, g.C * g.Cin_p, s);
-      hipLaunchKernelGGL(k_w1x1_compact, dim3(bx_ceil_div(g.C * Cin, 256)), dim3(256), 0, s, tmp, d_w1x1, g.C, Cin, g.Cin_p);
-    }
-    BX_CHECK_LAUNCH("bx_block_tail_bwd(w1x1 reduce)");
   }
+  const bool narrow = g.npool * (g.Cin_p / 8) < 256 * 256;          // fewer than one workgroup per CU at 8 channels per thread
+  const int n_dxs = dx_skip ? bx_ceil_div(g.npool * (g.Cin_p / (narrow ? 4 : 8)), 256) : 0;
+  const int n_w = nchunk * wg_y * wg_z;
+  const size_t front_lds = dx_skip ? (size_t)64 * g.Cin_p * sizeof(float) : 0;
+  BX_DISPATCH_DTYPE(d->dtype, T, {
+    TailFrontArgs<T> a;
+    a.dout = (const T*)dout; a.pooled = (const T*)pooled; a.x = (const T*)x; a.mean = save_mean; a.invstd = save_invstd; a.w1x1 = w1x1;
+    a.seed = seed; a.partials = partials; a.wpart = wpart; a.dxs = dxs; a.dx_even = even ? (T*)dx_skip : (T*)nullptr;
+    a.dropout_p = p; a.salt = d->salt; a.n_red = nblk; a.n_w = n_w; a.wg_x = nchunk > 0 ? nchunk : 1; a.wg_y = wg_y; a.ppc = ppc; a.Cin = Cin;
+    if (narrow) hipLaunchKernelGGL((k_tail_bwd_front<T, 4>), dim3(nblk + n_w + n_dxs), dim3(256), front_lds, s, a, g);
+    else hipLaunchKernelGGL((k_tail_bwd_front<T, 8>), dim3(nblk + n_w + n_dxs), dim3(256), front_lds, s, a, g);
+  });
+  BX_CHECK_LAUNCH("bx_block_tail_bwd(front)");
+  // ---- mid: finalize | weight-gradient sum
+  {
+    const int n_fin = bx_finalize_grid(g.C), n = g.C * g.Cin_p;
+    const int S = d_w1x1 ? bx_partial_slices(n, nchunk) : 4;
+    const int n_sum = d_w1x1 ? bx_ceil_div(n, 4 * (256 / S)) : 0;
+    hipLaunchKernelGGL(k_tail_bwd_mid, dim3(n_fin + n_sum), dim3(1024), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight,
+                       save_invstd, coef, d_bn_weight, d_bn_bias, d_b1x1, n_fin, wpart, d_w1x1, nchunk, Cin, g.Cin_p, S);
+  }
+  BX_CHECK_LAUNCH("bx_block_tail_bwd(mid)");
+  BX_DISPATCH_DTYPE(d->dtype, T,
+    hipLaunchKernelGGL((k_tail_bwd_apply<T>), dim3(tail_blocks_all(g)), dim3(256), 0, s, (const T*)dout, (const T*)pooled, (const T*)y3, save_mean,
+                       save_invstd, coef, seed, p, d->salt, d->pool, (T*)dz3, g));
+  BX_CHECK_LAUNCH("bx_block_tail_bwd(apply)");
   if (dx_skip) {
-    const bool even = (g.H % 2 == 0) && (g.W % 2 == 0);
-    const bool narrow = g.npool * (g.Cin_p / 8) < 256 * 256;          // fewer than one workgroup per CU at 8 channels per thread
-    const long long n1 = g.npool * (g.Cin_p / (narrow ? 4 : 8));
-    BX_DISPATCH_DTYPE(d->dtype, T,
-      if (narrow) hipLaunchKernelGGL((k_skip_dxs<T, 4>), dim3(bx_ceil_div(n1, 256)), dim3(256), (size_t)64 * g.Cin_p * sizeof(float), s,
-                                     (const T*)dout, w1x1, Cin, dxs, even ? (T*)dx_skip : (T*)nullptr, g);
-      else hipLaunchKernelGGL((k_skip_dxs<T, 8>), dim3(bx_ceil_div(n1, 256)), dim3(256), (size_t)64 * g.Cin_p * sizeof(float), s,
-                              (const T*)dout, w1x1, Cin, dxs, even ? (T*)dx_skip : (T*)nullptr, g));
-    BX_CHECK_LAUNCH("bx_block_tail_bwd(dxs)");
     if (!even) {
       const long long n2 = (long long)g.B * g.H * g.W * (g.Cin_p / 8);
       BX_DISPATCH_DTYPE(d->dtype, T,
