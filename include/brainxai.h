@@ -142,6 +142,22 @@ int bx_fusion_head_bwd(const float* dlogp, const float* logp, const float* hidde
                        const float* spec_logp, const float* w1, const float* w2, float* d_eeg_logp,
                        float* d_spec_logp, float* dw1, float* db1, float* dw2, float* db2, int B, int N, int Hd,
                        bxStream stream);
+/* Fused multimodal head: the three ops above in one launch forward / two backward, for MultimodalModel.forward
+ * (NB:1095-1105 over models.py:103-106 and :286-288).  feat: block5 output [B,HW,C] channels-last `dtype`; eeg_feat fp32
+ * [B,K] (EEGNet features).  Outputs of fwd (all fp32, all read again by bwd): gap_out [B,C], spec_logp / eeg_logp [B,N]
+ * (the two branch outputs), hidden [B,Hd], logp [B,N].  bwd: dfeat [B,HW,C] `dtype` and d_eeg_feat [B,K] may be NULL;
+ * parameter gradients are written when non-NULL.  Limits: C <= 1024, K <= 4096, N <= 32, Hd <= 256, Hd*2N <= 4096. */
+size_t bx_mm_head_workspace(int B, int N, int Hd);
+int bx_mm_head_fwd(const void* feat, const float* eeg_feat, const float* fc_w, const float* fc_b, const float* dense_w,
+                   const float* dense_b, const float* w1, const float* b1, const float* w2, const float* b2,
+                   float* gap_out, float* spec_logp, float* eeg_logp, float* hidden, float* logp, int B, int HW, int C,
+                   int K, int N, int Hd, int dtype, bxStream stream);
+int bx_mm_head_bwd(const float* dlogp, const float* logp, const float* hidden, const float* spec_logp,
+                   const float* eeg_logp, const float* gap, const float* eeg_feat, const float* fc_w,
+                   const float* dense_w, const float* w1, const float* w2, void* dfeat, float* d_eeg_feat,
+                   float* d_fc_w, float* d_fc_b, float* d_dense_w, float* d_dense_b, float* dw1, float* db1, float* dw2,
+                   float* db2, void* workspace, size_t workspace_bytes, int B, int HW, int C, int K, int N, int Hd,
+                   int dtype, bxStream stream);
 /* nn.KLDivLoss on log-prob input / prob target (NB:1989,1599): loss[1] and dlogp = -t/denom.
  * reduction: 0 'mean' (denom B*N), 1 'batchmean' (denom B), 2 'sum'.  grad_scale multiplies dlogp. */
 int bx_kldiv_fwd_bwd(const float* logp, const float* target, float* loss, float* dlogp, int B, int N,

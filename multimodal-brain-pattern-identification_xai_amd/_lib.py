@@ -83,6 +83,9 @@ SIGNATURES = {
     "bx_linear_lsm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "bx_fusion_head_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "bx_fusion_head_bwd": (i32, [vp] * 13 + [i32, i32, i32, vp]),
+    "bx_mm_head_workspace": (sz, [i32, i32, i32]),
+    "bx_mm_head_fwd": (i32, [vp] * 15 + [i32] * 7 + [vp]),
+    "bx_mm_head_bwd": (i32, [vp] * 22 + [sz] + [i32] * 7 + [vp]),
     "bx_kldiv_fwd_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "bx_eeg_saved_bytes": (sz, [P(EegDesc)]),
     "bx_eeg_workspace": (sz, [P(EegDesc)]),

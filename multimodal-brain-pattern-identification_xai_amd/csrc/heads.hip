@@ -336,3 +336,244 @@ extern "C" int bx_kldiv_fwd_bwd(const float* logp, const float* target, float* l
   BX_CHECK_LAUNCH("bx_kldiv_fwd_bwd");
   return BX_OK;
 }
+
+// ================================================================================================
+// Fused multimodal head: everything between the two feature extractors and the loss in ONE launch forward and TWO
+// backward (the separate ops above cost 4 + 6 launches of ~5-12 us for a few kFLOP per sample):
+//   gap = mean_hw feat5;  s = LogSoftmax(fc gap + b)           (models.py:103-106)
+//   e = LogSoftmax(dense eegfeat + b)                           (models.py:286-288)
+//   out = LogSoftmax(fc2 relu(fc1 cat(e, s) + b1) + b2)         (XAI_Multimodality.py:1099-1103)
+// One workgroup per sample; parameter gradients are batch sums computed by a second kernel, one thread per entry.
+#define MMH_MAXK 4096
+#define MMH_MAXC 1024
+#define MMH_MAXHD 256
+
+__device__ __forceinline__ void mmh_lsm(const float* logit, int N, float* out) {      // serial, N <= HEAD_MAX_N
+  float m = -INFINITY;
+  for (int n = 0; n < N; ++n) m = fmaxf(m, logit[n]);
+  float se = 0.f;
+  for (int n = 0; n < N; ++n) se += expf(logit[n] - m);
+  const float lse = m + logf(se);
+  for (int n = 0; n < N; ++n) out[n] = logit[n] - lse;
+}
+// dot of a global row with an LDS vector by one wave (all loads of a lane issued before the adds)
+__device__ __forceinline__ float mmh_wave_dot(const float* __restrict__ wrow, const float* vec, int n, int lane) {
+  float acc = 0.f;
+  for (int i0 = lane; i0 < n; i0 += 64 * 8) {
+    float w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u; w[u] = i < n ? wrow[i] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u; if (i < n) acc = fmaf(w[u], vec[i], acc); }
+  }
+  return wave_sum(acc);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_mm_head_fwd(const T* __restrict__ feat, const float* __restrict__ ef, const float* __restrict__ fcw,
+    const float* __restrict__ fcb, const float* __restrict__ dw_, const float* __restrict__ db_, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ gap_out,
+    float* __restrict__ s_logp, float* __restrict__ e_logp, float* __restrict__ hidden, float* __restrict__ logp, int HW, int C, int K, int N, int Hd) {
+  __shared__ float gs[MMH_MAXC], es[MMH_MAXK], hs[MMH_MAXHD], lg[2 * HEAD_MAX_N], z[2 * HEAD_MAX_N], lo[HEAD_MAX_N];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float inv_hw = 1.f / (float)HW;
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    const T* fp = feat + (size_t)b * HW * C + c;
+    for (int p0 = 0; p0 < HW; p0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p0 + u < HW ? ldf(fp, (size_t)(p0 + u) * C) : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    s *= inv_hw;
+    gs[c] = s;
+    gap_out[(size_t)b * C + c] = s;
+  }
+  lds_fill<4>(es, K, [&](int i) { return ef[(size_t)b * K + i]; });
+  __syncthreads();
+  for (int q = wave; q < 2 * N; q += 4) {                     // 2N dot products over the 4 waves: eeg rows first, then spectrogram rows
+    const bool eeg = q < N;
+    const int n = eeg ? q : q - N;
+    const float v = eeg ? mmh_wave_dot(dw_ + (size_t)n * K, es, K, lane) : mmh_wave_dot(fcw + (size_t)n * C, gs, C, lane);
+    if (lane == 0) lg[q] = v + (eeg ? db_[n] : fcb[n]);
+  }
+  __syncthreads();
+  if (tid < 2) mmh_lsm(lg + tid * N, N, z + tid * N);
+  __syncthreads();
+  if (tid < 2 * N) (tid < N ? e_logp : s_logp)[(size_t)b * N + (tid < N ? tid : tid - N)] = z[tid];
+  for (int j = tid; j < Hd; j += 256) {
+    float wv[2 * HEAD_MAX_N];
+#pragma unroll
+    for (int i = 0; i < 2 * HEAD_MAX_N; ++i) wv[i] = i < 2 * N ? w1[(size_t)j * 2 * N + i] : 0.f;
+    float s = b1[j];
+#pragma unroll
+    for (int i = 0; i < 2 * HEAD_MAX_N; ++i) if (i < 2 * N) s = fmaf(wv[i], z[i], s);
+    s = fmaxf(s, 0.f);
+    hs[j] = s;
+    hidden[(size_t)b * Hd + j] = s;
+  }
+  __syncthreads();
+  for (int n = wave; n < N; n += 4) {
+    const float v = mmh_wave_dot(w2 + (size_t)n * Hd, hs, Hd, lane);
+    if (lane == 0) lo[n] = v + b2[n];
+  }
+  __syncthreads();
+  if (tid == 0) mmh_lsm(lo, N, lg);
+  __syncthreads();
+  if (tid < N) logp[(size_t)b * N + tid] = lg[tid];
+}
+
+// backward 1: per sample, gradients w.r.t. the two feature inputs; the per-sample logit / pre-activation gradients go to
+// the workspace ([B][N] dl2 | [B][Hd] dpre | [B][N] dle | [B][N] dls) for the parameter-gradient kernel
+template <typename T>
+__global__ __launch_bounds__(256) void k_mm_head_bwd_in(const float* __restrict__ dlogp, const float* __restrict__ logp, const float* __restrict__ hidden,
+    const float* __restrict__ s_logp, const float* __restrict__ e_logp, const float* __restrict__ fcw, const float* __restrict__ dw_,
+    const float* __restrict__ w1, const float* __restrict__ w2, T* __restrict__ dfeat, float* __restrict__ def, float* __restrict__ ws,
+    int B, int HW, int C, int K, int N, int Hd) {
+  __shared__ float w1s[MMH_MAXHD * 2 * HEAD_MAX_N / 4];      // Hd * 2N <= 4096 floats (checked by the launcher)
+  __shared__ float dl2[HEAD_MAX_N], dpre[MMH_MAXHD], dz[2 * HEAD_MAX_N], dbr[2 * HEAD_MAX_N];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  lds_fill<8>(w1s, Hd * 2 * N, [&](int i) { return w1[i]; });
+  if (tid == 0) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dlogp[(size_t)b * N + n];
+    for (int n = 0; n < N; ++n) dl2[n] = dlogp[(size_t)b * N + n] - expf(logp[(size_t)b * N + n]) * s;
+  }
+  __syncthreads();
+  float* ws_dl2 = ws; float* ws_dpre = ws + (size_t)B * N; float* ws_dle = ws_dpre + (size_t)B * Hd; float* ws_dls = ws_dle + (size_t)B * N;
+  if (tid < N) ws_dl2[(size_t)b * N + tid] = dl2[tid];
+  for (int j = tid; j < Hd; j += 256) {
+    float wv[HEAD_MAX_N];
+#pragma unroll
+    for (int n = 0; n < HEAD_MAX_N; ++n) wv[n] = n < N ? w2[(size_t)n * Hd + j] : 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) s = fmaf(dl2[n], wv[n], s);
+    s = hidden[(size_t)b * Hd + j] > 0.f ? s : 0.f;
+    dpre[j] = s;
+    ws_dpre[(size_t)b * Hd + j] = s;
+  }
+  __syncthreads();
+  if (tid < 2 * N) {
+    float s = 0.f;
+    for (int j = 0; j < Hd; ++j) s = fmaf(dpre[j], w1s[j * 2 * N + tid], s);
+    dz[tid] = s;
+  }
+  __syncthreads();
+  if (tid < 2) {                                               // log-softmax backward of the two branch outputs
+    const float* lp = (tid == 0 ? e_logp : s_logp) + (size_t)b * N;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dz[tid * N + n];
+    for (int n = 0; n < N; ++n) dbr[tid * N + n] = dz[tid * N + n] - expf(lp[n]) * s;
+  }
+  __syncthreads();
+  if (tid < 2 * N) (tid < N ? ws_dle : ws_dls)[(size_t)b * N + (tid < N ? tid : tid - N)] = dbr[tid];
+  if (def)
+    for (int k = tid; k < K; k += 256) {
+      float wv[HEAD_MAX_N];
+#pragma unroll
+      for (int n = 0; n < HEAD_MAX_N; ++n) wv[n] = n < N ? dw_[(size_t)n * K + k] : 0.f;
+      float s = 0.f;
+#pragma unroll
+      for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) s = fmaf(dbr[n], wv[n], s);
+      def[(size_t)b * K + k] = s;
+    }
+  if (dfeat) {
+    const float inv_hw = 1.f / (float)HW;
+    for (int c = tid; c < C; c += 256) {
+      float wv[HEAD_MAX_N];
+#pragma unroll
+      for (int n = 0; n < HEAD_MAX_N; ++n) wv[n] = n < N ? fcw[(size_t)n * C + c] : 0.f;
+      float s = 0.f;
+#pragma unroll
+      for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) s = fmaf(dbr[N + n], wv[n], s);
+      s *= inv_hw;
+      for (int p = 0; p < HW; ++p) stf(dfeat, ((size_t)b * HW + p) * C + c, s);
+    }
+  }
+}
+
+// backward 2: every parameter-gradient entry is a batch sum  sum_b A[b][m] * V[b][n]  (V = 1 for biases); one thread per entry
+struct MmHeadSeg { const float* A; const float* V; const float* V2; float* out; int M, Nn, sa, sv, split; };   // V2: second half of a concatenated V
+struct MmHeadJobs { MmHeadSeg seg[8]; int start[9]; };
+__global__ __launch_bounds__(256) void k_mm_head_bwd_w(MmHeadJobs jobs, int B) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= jobs.start[8]) return;
+  int si = 0;
+#pragma unroll
+  for (int q = 1; q < 8; ++q) if (idx >= jobs.start[q]) si = q;
+  const MmHeadSeg sg = jobs.seg[si];
+  if (!sg.out) return;
+  const int e = idx - jobs.start[si];
+  const bool bias = sg.V == nullptr;
+  const int m = bias ? e : e / sg.Nn, n = bias ? 0 : e - m * sg.Nn;
+  const float* vp = bias ? nullptr : (sg.V2 && n >= sg.split ? sg.V2 + (n - sg.split) : sg.V + n);
+  float s = 0.f;
+  int b = 0;
+  for (; b + 8 <= B; b += 8) {
+    float av[8], vv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { av[u] = sg.A[(size_t)(b + u) * sg.sa + m]; vv[u] = bias ? 1.f : vp[(size_t)(b + u) * sg.sv]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s = fmaf(av[u], vv[u], s);
+  }
+  for (; b < B; ++b) s = fmaf(sg.A[(size_t)b * sg.sa + m], bias ? 1.f : vp[(size_t)b * sg.sv], s);
+  sg.out[e] = s;
+}
+
+extern "C" size_t bx_mm_head_workspace(int B, int N, int Hd) { return (size_t)B * (3 * (size_t)N + Hd) * sizeof(float); }
+static int mm_head_check(const char* who, int B, int HW, int C, int K, int N, int Hd) {
+  BX_REQUIRE(B > 0 && HW > 0 && C > 0 && C <= MMH_MAXC && K > 0 && K <= MMH_MAXK, "%s: need C <= %d and K <= %d", who, MMH_MAXC, MMH_MAXK);
+  BX_REQUIRE(N > 0 && N <= HEAD_MAX_N && Hd > 0 && Hd <= MMH_MAXHD && Hd * 2 * N <= MMH_MAXHD * 2 * HEAD_MAX_N / 4, "%s: need N <= %d, Hd <= %d, Hd*2N <= %d",
+             who, HEAD_MAX_N, MMH_MAXHD, MMH_MAXHD * 2 * HEAD_MAX_N / 4);
+  return BX_OK;
+}
+extern "C" int bx_mm_head_fwd(const void* feat, const float* eeg_feat, const float* fc_w, const float* fc_b, const float* dense_w,
+                              const float* dense_b, const float* w1, const float* b1, const float* w2, const float* b2, float* gap_out,
+                              float* spec_logp, float* eeg_logp, float* hidden, float* logp, int B, int HW, int C, int K, int N, int Hd,
+                              int dtype, bxStream stream) {
+  BX_REQUIRE(feat && eeg_feat && fc_w && fc_b && dense_w && dense_b && w1 && b1 && w2 && b2 && gap_out && spec_logp && eeg_logp && hidden && logp,
+             "bx_mm_head_fwd: null pointer");
+  BX_DTYPE_OK(dtype);
+  const int rc = mm_head_check("bx_mm_head_fwd", B, HW, C, K, N, Hd);
+  if (rc) return rc;
+  BX_DISPATCH_DTYPE(dtype, T,
+    hipLaunchKernelGGL((k_mm_head_fwd<T>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const T*)feat, eeg_feat, fc_w, fc_b, dense_w, dense_b, w1, b1,
+                       w2, b2, gap_out, spec_logp, eeg_logp, hidden, logp, HW, C, K, N, Hd));
+  BX_CHECK_LAUNCH("bx_mm_head_fwd");
+  return BX_OK;
+}
+extern "C" int bx_mm_head_bwd(const float* dlogp, const float* logp, const float* hidden, const float* spec_logp, const float* eeg_logp,
+                              const float* gap, const float* eeg_feat, const float* fc_w, const float* dense_w, const float* w1, const float* w2,
+                              void* dfeat, float* d_eeg_feat, float* d_fc_w, float* d_fc_b, float* d_dense_w, float* d_dense_b, float* dw1,
+                              float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes, int B, int HW, int C, int K, int N,
+                              int Hd, int dtype, bxStream stream) {
+  BX_REQUIRE(dlogp && logp && hidden && spec_logp && eeg_logp && gap && eeg_feat && fc_w && dense_w && w1 && w2, "bx_mm_head_bwd: null pointer");
+  BX_DTYPE_OK(dtype);
+  const int rc = mm_head_check("bx_mm_head_bwd", B, HW, C, K, N, Hd);
+  if (rc) return rc;
+  if (!workspace || workspace_bytes < bx_mm_head_workspace(B, N, Hd)) BX_FAIL(BX_EWORKSPACE, "bx_mm_head_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  BX_DISPATCH_DTYPE(dtype, T,
+    hipLaunchKernelGGL((k_mm_head_bwd_in<T>), dim3(B), dim3(256), 0, s, dlogp, logp, hidden, spec_logp, eeg_logp, fc_w, dense_w, w1, w2, (T*)dfeat,
+                       d_eeg_feat, ws, B, HW, C, K, N, Hd));
+  BX_CHECK_LAUNCH("bx_mm_head_bwd(inputs)");
+  if (d_fc_w || d_fc_b || d_dense_w || d_dense_b || dw1 || db1 || dw2 || db2) {
+    const float* dl2 = ws; const float* dpre = ws + (size_t)B * N; const float* dle = dpre + (size_t)B * Hd; const float* dls = dle + (size_t)B * N;
+    MmHeadJobs j;
+    const MmHeadSeg segs[8] = {
+        {dl2, hidden, nullptr, dw2, N, Hd, N, Hd, 0},            {dl2, nullptr, nullptr, db2, N, 1, N, 0, 0},
+        {dpre, eeg_logp, spec_logp, dw1, Hd, 2 * N, Hd, N, N},   {dpre, nullptr, nullptr, db1, Hd, 1, Hd, 0, 0},
+        {dle, eeg_feat, nullptr, d_dense_w, N, K, N, K, 0},      {dle, nullptr, nullptr, d_dense_b, N, 1, N, 0, 0},
+        {dls, gap, nullptr, d_fc_w, N, C, N, C, 0},              {dls, nullptr, nullptr, d_fc_b, N, 1, N, 0, 0}};
+    int acc = 0;
+    for (int q = 0; q < 8; ++q) { j.seg[q] = segs[q]; j.start[q] = acc; acc += segs[q].M * segs[q].Nn; }
+    j.start[8] = acc;
+    hipLaunchKernelGGL(k_mm_head_bwd_w, dim3(bx_ceil_div(acc, 256)), dim3(256), 0, s, j, B);
+    BX_CHECK_LAUNCH("bx_mm_head_bwd(weights)");
+  }
+  return BX_OK;
+}

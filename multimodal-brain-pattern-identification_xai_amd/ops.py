@@ -24,6 +24,7 @@ CONV_PROFILE = None               # bench.py sets a list: every conv launch appe
 # so it is OFF by default; BX_OVERLAP=1 turns it on.
 import os as _os
 OVERLAP = _os.environ.get("BX_OVERLAP", "0") == "1"
+FUSED_HEAD = _os.environ.get("BX_FUSED_HEAD", "1") == "1"    # MultimodalModel: GAP+fc, dense and the fusion head in one launch
 _SIDE = {}
 
 
@@ -468,6 +469,42 @@ class FusionHeadFn(torch.autograd.Function):
         L.check(L.load().bx_fusion_head_bwd(_p(dlogp), _p(logp), _p(hidden), _p(e), _p(s), _p(w1), _p(w2), _p(de), _p(ds),
                                             _p(dw1), _p(db1), _p(dw2), _p(db2), B, N, Hd, _stream()), "bx_fusion_head_bwd")
         return de, ds, dw1, db1, dw2, db2
+
+
+class MultimodalHeadFn(torch.autograd.Function):
+    """GAP+fc+LogSoftmax (spectrogram), dense+LogSoftmax (EEG) and the fusion head in one launch forward, two backward
+    (reference models.py:103-106, :286-288, XAI_Multimodality.py:1095-1105).  feat: NHWC block5 map, efeat fp32 [B,K]."""
+
+    @staticmethod
+    def forward(ctx, feat, efeat, fcw, fcb, dw, db, w1, b1, w2, b2):
+        B, H, W, Cc = feat.shape
+        K, N, Hd = efeat.shape[1], fcw.shape[0], w1.shape[0]
+        dev = feat.device
+        efeat = efeat.contiguous()
+        gap = torch.empty(B, Cc, dtype=torch.float32, device=dev)
+        slp, elp, logp = (torch.empty(B, N, dtype=torch.float32, device=dev) for _ in range(3))
+        hidden = torch.empty(B, Hd, dtype=torch.float32, device=dev)
+        L.check(L.load().bx_mm_head_fwd(_p(feat), _p(efeat), _p(fcw), _p(fcb), _p(dw), _p(db), _p(w1), _p(b1), _p(w2), _p(b2), _p(gap), _p(slp),
+                                        _p(elp), _p(hidden), _p(logp), B, H * W, Cc, K, N, Hd, bx_dtype(feat.dtype), _stream()), "bx_mm_head_fwd")
+        ctx.shape, ctx.dt = (B, H, W, Cc), feat.dtype
+        ctx.save_for_backward(gap, slp, elp, hidden, logp, efeat, fcw, fcb, dw, db, w1, b1, w2, b2)
+        return logp
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        gap, slp, elp, hidden, logp, efeat, fcw, fcb, dw, db, w1, b1, w2, b2 = ctx.saved_tensors
+        B, H, W, Cc = ctx.shape
+        K, N, Hd = efeat.shape[1], fcw.shape[0], w1.shape[0]
+        lib = L.load()
+        dfeat = torch.empty(B, H, W, Cc, dtype=ctx.dt, device=gap.device) if ctx.needs_input_grad[0] else None
+        defeat = torch.empty_like(efeat) if ctx.needs_input_grad[1] else None
+        gl = [new_grad(t) if need else None for t, need in zip((fcw, fcb, dw, db, w1, b1, w2, b2), ctx.needs_input_grad[2:])]
+        ws = workspace(lib.bx_mm_head_workspace(B, N, Hd), gap.device)
+        dlogp = dlogp.contiguous()
+        L.check(lib.bx_mm_head_bwd(_p(dlogp), _p(logp), _p(hidden), _p(slp), _p(elp), _p(gap), _p(efeat), _p(fcw), _p(dw), _p(w1), _p(w2),
+                                   _p(dfeat), _p(defeat), *[_p(t) for t in gl], _p(ws), ws.numel(), B, H * W, Cc, K, N, Hd, bx_dtype(ctx.dt),
+                                   _stream()), "bx_mm_head_bwd")
+        return (dfeat, defeat, *gl)
 
 
 _REDUCTIONS = {"mean": 0, "batchmean": 1, "sum": 2}

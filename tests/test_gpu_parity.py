@@ -408,6 +408,47 @@ def test_native_pipeline_end_to_end():
         ops.clear_grad_views()
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_fused_multimodal_head_matches_separate_ops(dt):
+    """MultimodalModel's one-launch head (bx_mm_head_*) against the three separate ops it replaces, same features in:
+    outputs and every gradient; a forward hook on a branch switches the fused path off (hooks must keep firing)."""
+    ref, mine = _pair(lambda: O.build_multimodal(19, 2000, 4, dropout=0.0), lambda: brainxai.build_multimodal(19, 2000, 4, dropout=0.0, compute_dtype=dt), 41)
+    eeg = O.seeded((5, 1, 19, 2000), 42, "randn").to(DEV)
+    spec = O.seeded((5, 4, 32, 64), 43, "rand").to(DEV)
+    r = O.seeded((5, 6), 44, "randn").to(DEV)
+    res = {}
+    sd = {k: v.clone() for k, v in mine.state_dict().items()}
+    for fused in (True, False):
+        ops.FUSED_HEAD = fused
+        mine.load_state_dict(sd)                       # the train pass moves the BatchNorm running statistics
+        try:
+            for mode in ("train", "eval"):
+                mine.train(mode == "train"); mine.zero_grad()
+                e_in, s_in = eeg.clone().requires_grad_(True), spec.clone().requires_grad_(True)
+                y = mine(e_in, s_in)
+                (y * r).sum().backward()
+                torch.cuda.synchronize()
+                res[(fused, mode)] = (y.detach().clone(), e_in.grad.clone(), s_in.grad.clone(), {n: p.grad.clone() for n, p in mine.named_parameters()})
+        finally:
+            ops.FUSED_HEAD = True
+    assert mine._fusable()
+    for mode in ("train", "eval"):
+        yf, ef, sf, gf = res[(True, mode)]
+        ys, es, ss, gs = res[(False, mode)]
+        tol = 1e-4 if dt == torch.float32 else 2e-2       # bf16: an fp32 rounding difference can move a stored gradient by one bf16 ulp
+        assert rel_err(yf.cpu(), ys.cpu()) < 1e-5, mode
+        assert rel_err(ef.cpu(), es.cpu()) < tol and rel_err(sf.cpu(), ss.cpu()) < tol, mode
+        fl = 1e-2 * max(float(g.abs().max()) for g in gs.values())     # EEGNet's batchnorm1 gradients are pure rounding noise in train mode
+        for n in gf:
+            assert rel_err(gf[n].cpu(), gs[n].cpu(), floor=fl) < tol, (mode, n)
+    seen = []
+    h = mine.spectrogram_model.register_forward_hook(lambda m, i, o: seen.append(tuple(o.shape)))
+    assert not mine._fusable()
+    mine(eeg, spec)
+    h.remove()
+    assert seen == [(5, 6)] and mine._fusable()
+
+
 def test_dropout_statistics_and_determinism():
     torch.manual_seed(0)
     blk = brainxai.Block(8, 16, "max", (2, 2), dropout_p=0.5).to(DEV).train()
