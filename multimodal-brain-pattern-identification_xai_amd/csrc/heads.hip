@@ -369,7 +369,9 @@ __device__ __forceinline__ float mmh_wave_dot(const float* __restrict__ wrow, co
   return wave_sum(acc);
 }
 
-template <typename T>
+// FAST (2N <= 12, N <= 8, K <= 1024, C <= 1024): every weight a thread will need is loaded into registers at kernel start,
+// together with the feature loads, so the chain gap -> logits -> hidden -> logits costs one memory round trip instead of six.
+template <typename T, bool FAST>
 __global__ __launch_bounds__(256) void k_mm_head_fwd(const T* __restrict__ feat, const float* __restrict__ ef, const float* __restrict__ fcw,
     const float* __restrict__ fcb, const float* __restrict__ dw_, const float* __restrict__ db_, const float* __restrict__ w1,
     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ gap_out,
@@ -377,15 +379,39 @@ __global__ __launch_bounds__(256) void k_mm_head_fwd(const T* __restrict__ feat,
   __shared__ float gs[MMH_MAXC], es[MMH_MAXK], hs[MMH_MAXHD], lg[2 * HEAD_MAX_N], z[2 * HEAD_MAX_N], lo[HEAD_MAX_N];
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float inv_hw = 1.f / (float)HW;
+  // FAST: register copies of this thread's weights (rows q = wave + 4r of [dense ; fc], row tid of fc1, rows wave, wave+4 of fc2)
+  float wq[FAST ? 3 : 1][FAST ? 16 : 1], bq[FAST ? 3 : 1], w1r[FAST ? 12 : 1], b1r = 0.f, w2r[FAST ? 2 : 1][FAST ? 4 : 1], b2r[FAST ? 2 : 1];
+  if (FAST) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int q = wave + 4 * r;
+      const bool live = q < 2 * N, eeg = q < N;
+      const int n = eeg ? q : q - N, len = eeg ? K : C;
+      const float* row = eeg ? dw_ + (size_t)n * K : fcw + (size_t)n * C;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const int i = lane + 64 * u; wq[r][u] = (live && i < len) ? row[i] : 0.f; }
+      bq[r] = live ? (eeg ? db_[n] : fcb[n]) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) w1r[i] = (tid < Hd && i < 2 * N) ? w1[(size_t)tid * 2 * N + i] : 0.f;
+    b1r = tid < Hd ? b1[tid] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int n = wave + 4 * r;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int j = lane + 64 * u; w2r[r][u] = (n < N && j < Hd) ? w2[(size_t)n * Hd + j] : 0.f; }
+      b2r[r] = n < N ? b2[n] : 0.f;
+    }
+  }
   for (int c = tid; c < C; c += 256) {
     float s = 0.f;
     const T* fp = feat + (size_t)b * HW * C + c;
-    for (int p0 = 0; p0 < HW; p0 += 8) {
-      float v[8];
+    for (int p0 = 0; p0 < HW; p0 += 16) {
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p0 + u < HW ? ldf(fp, (size_t)(p0 + u) * C) : 0.f;
+      for (int u = 0; u < 16; ++u) v[u] = p0 + u < HW ? ldf(fp, (size_t)(p0 + u) * C) : 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
+      for (int u = 0; u < 16; ++u) s += v[u];
     }
     s *= inv_hw;
     gs[c] = s;
@@ -393,31 +419,68 @@ __global__ __launch_bounds__(256) void k_mm_head_fwd(const T* __restrict__ feat,
   }
   lds_fill<4>(es, K, [&](int i) { return ef[(size_t)b * K + i]; });
   __syncthreads();
-  for (int q = wave; q < 2 * N; q += 4) {                     // 2N dot products over the 4 waves: eeg rows first, then spectrogram rows
-    const bool eeg = q < N;
-    const int n = eeg ? q : q - N;
-    const float v = eeg ? mmh_wave_dot(dw_ + (size_t)n * K, es, K, lane) : mmh_wave_dot(fcw + (size_t)n * C, gs, C, lane);
-    if (lane == 0) lg[q] = v + (eeg ? db_[n] : fcb[n]);
+  if (FAST) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int q = wave + 4 * r;
+      const float* vec = q < N ? es : gs;
+      const int len = q < N ? K : C;
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const int i = lane + 64 * u; if (i < len) acc = fmaf(wq[r][u], vec[i], acc); }
+      acc = wave_sum(acc);
+      if (lane == 0 && q < 2 * N) lg[q] = acc + bq[r];
+    }
+  } else {
+    for (int q = wave; q < 2 * N; q += 4) {                   // 2N dot products over the 4 waves: eeg rows first, then spectrogram rows
+      const bool eeg = q < N;
+      const int n = eeg ? q : q - N;
+      const float v = eeg ? mmh_wave_dot(dw_ + (size_t)n * K, es, K, lane) : mmh_wave_dot(fcw + (size_t)n * C, gs, C, lane);
+      if (lane == 0) lg[q] = v + (eeg ? db_[n] : fcb[n]);
+    }
   }
   __syncthreads();
   if (tid < 2) mmh_lsm(lg + tid * N, N, z + tid * N);
   __syncthreads();
   if (tid < 2 * N) (tid < N ? e_logp : s_logp)[(size_t)b * N + (tid < N ? tid : tid - N)] = z[tid];
-  for (int j = tid; j < Hd; j += 256) {
-    float wv[2 * HEAD_MAX_N];
+  if (FAST) {
+    if (tid < Hd) {
+      float s = b1r;
 #pragma unroll
-    for (int i = 0; i < 2 * HEAD_MAX_N; ++i) wv[i] = i < 2 * N ? w1[(size_t)j * 2 * N + i] : 0.f;
-    float s = b1[j];
+      for (int i = 0; i < 12; ++i) if (i < 2 * N) s = fmaf(w1r[i], z[i], s);
+      s = fmaxf(s, 0.f);
+      hs[tid] = s;
+      hidden[(size_t)b * Hd + tid] = s;
+    }
+  } else {
+    for (int j = tid; j < Hd; j += 256) {
+      float wv[2 * HEAD_MAX_N];
 #pragma unroll
-    for (int i = 0; i < 2 * HEAD_MAX_N; ++i) if (i < 2 * N) s = fmaf(wv[i], z[i], s);
-    s = fmaxf(s, 0.f);
-    hs[j] = s;
-    hidden[(size_t)b * Hd + j] = s;
+      for (int i = 0; i < 2 * HEAD_MAX_N; ++i) wv[i] = i < 2 * N ? w1[(size_t)j * 2 * N + i] : 0.f;
+      float s = b1[j];
+#pragma unroll
+      for (int i = 0; i < 2 * HEAD_MAX_N; ++i) if (i < 2 * N) s = fmaf(wv[i], z[i], s);
+      s = fmaxf(s, 0.f);
+      hs[j] = s;
+      hidden[(size_t)b * Hd + j] = s;
+    }
   }
   __syncthreads();
-  for (int n = wave; n < N; n += 4) {
-    const float v = mmh_wave_dot(w2 + (size_t)n * Hd, hs, Hd, lane);
-    if (lane == 0) lo[n] = v + b2[n];
+  if (FAST) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int n = wave + 4 * r;
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int j = lane + 64 * u; if (j < Hd) acc = fmaf(w2r[r][u], hs[j], acc); }
+      acc = wave_sum(acc);
+      if (lane == 0 && n < N) lo[n] = acc + b2r[r];
+    }
+  } else {
+    for (int n = wave; n < N; n += 4) {
+      const float v = mmh_wave_dot(w2 + (size_t)n * Hd, hs, Hd, lane);
+      if (lane == 0) lo[n] = v + b2[n];
+    }
   }
   __syncthreads();
   if (tid == 0) mmh_lsm(lo, N, lg);
@@ -435,6 +498,20 @@ __global__ __launch_bounds__(256) void k_mm_head_bwd_in(const float* __restrict_
   __shared__ float w1s[MMH_MAXHD * 2 * HEAD_MAX_N / 4];      // Hd * 2N <= 4096 floats (checked by the launcher)
   __shared__ float dl2[HEAD_MAX_N], dpre[MMH_MAXHD], dz[2 * HEAD_MAX_N], dbr[2 * HEAD_MAX_N];
   const int b = blockIdx.x, tid = threadIdx.x;
+  // everything this thread will read from global memory is requested up front (one round trip for the whole kernel)
+  constexpr int PN = 8, PK = 4;                               // register prefetch covers N <= 8, K <= 1024, C <= 256, Hd <= 256
+  const bool pre = N <= PN && K <= 256 * PK && C <= 256 && Hd <= 256;
+  float w2c[PN], hid = 0.f, fcc[PN], dwc[PK][PN];
+  if (pre) {
+#pragma unroll
+    for (int n = 0; n < PN; ++n) {
+      w2c[n] = (n < N && tid < Hd) ? w2[(size_t)n * Hd + tid] : 0.f;
+      fcc[n] = (n < N && tid < C) ? fcw[(size_t)n * C + tid] : 0.f;
+#pragma unroll
+      for (int u = 0; u < PK; ++u) { const int k = tid + 256 * u; dwc[u][n] = (n < N && k < K) ? dw_[(size_t)n * K + k] : 0.f; }
+    }
+    hid = tid < Hd ? hidden[(size_t)b * Hd + tid] : 0.f;
+  }
   lds_fill<8>(w1s, Hd * 2 * N, [&](int i) { return w1[i]; });
   if (tid == 0) {
     float s = 0.f;
@@ -444,16 +521,27 @@ __global__ __launch_bounds__(256) void k_mm_head_bwd_in(const float* __restrict_
   __syncthreads();
   float* ws_dl2 = ws; float* ws_dpre = ws + (size_t)B * N; float* ws_dle = ws_dpre + (size_t)B * Hd; float* ws_dls = ws_dle + (size_t)B * N;
   if (tid < N) ws_dl2[(size_t)b * N + tid] = dl2[tid];
-  for (int j = tid; j < Hd; j += 256) {
-    float wv[HEAD_MAX_N];
+  if (pre) {
+    if (tid < Hd) {
+      float s = 0.f;
 #pragma unroll
-    for (int n = 0; n < HEAD_MAX_N; ++n) wv[n] = n < N ? w2[(size_t)n * Hd + j] : 0.f;
-    float s = 0.f;
+      for (int n = 0; n < PN; ++n) if (n < N) s = fmaf(dl2[n], w2c[n], s);
+      s = hid > 0.f ? s : 0.f;
+      dpre[tid] = s;
+      ws_dpre[(size_t)b * Hd + tid] = s;
+    }
+  } else {
+    for (int j = tid; j < Hd; j += 256) {
+      float wv[HEAD_MAX_N];
 #pragma unroll
-    for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) s = fmaf(dl2[n], wv[n], s);
-    s = hidden[(size_t)b * Hd + j] > 0.f ? s : 0.f;
-    dpre[j] = s;
-    ws_dpre[(size_t)b * Hd + j] = s;
+      for (int n = 0; n < HEAD_MAX_N; ++n) wv[n] = n < N ? w2[(size_t)n * Hd + j] : 0.f;
+      float s = 0.f;
+#pragma unroll
+      for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) s = fmaf(dl2[n], wv[n], s);
+      s = hidden[(size_t)b * Hd + j] > 0.f ? s : 0.f;
+      dpre[j] = s;
+      ws_dpre[(size_t)b * Hd + j] = s;
+    }
   }
   __syncthreads();
   if (tid < 2 * N) {
@@ -470,6 +558,27 @@ __global__ __launch_bounds__(256) void k_mm_head_bwd_in(const float* __restrict_
   }
   __syncthreads();
   if (tid < 2 * N) (tid < N ? ws_dle : ws_dls)[(size_t)b * N + (tid < N ? tid : tid - N)] = dbr[tid];
+  const float inv_hw = 1.f / (float)HW;
+  if (pre) {
+    if (def) {
+#pragma unroll
+      for (int u = 0; u < PK; ++u) {
+        const int k = tid + 256 * u;
+        float s = 0.f;
+#pragma unroll
+        for (int n = 0; n < PN; ++n) if (n < N) s = fmaf(dbr[n], dwc[u][n], s);
+        if (k < K) def[(size_t)b * K + k] = s;
+      }
+    }
+    if (dfeat && tid < C) {
+      float s = 0.f;
+#pragma unroll
+      for (int n = 0; n < PN; ++n) if (n < N) s = fmaf(dbr[N + n], fcc[n], s);
+      s *= inv_hw;
+      for (int p = 0; p < HW; ++p) stf(dfeat, ((size_t)b * HW + p) * C + tid, s);
+    }
+    return;
+  }
   if (def)
     for (int k = tid; k < K; k += 256) {
       float wv[HEAD_MAX_N];
@@ -481,7 +590,6 @@ __global__ __launch_bounds__(256) void k_mm_head_bwd_in(const float* __restrict_
       def[(size_t)b * K + k] = s;
     }
   if (dfeat) {
-    const float inv_hw = 1.f / (float)HW;
     for (int c = tid; c < C; c += 256) {
       float wv[HEAD_MAX_N];
 #pragma unroll
@@ -539,9 +647,12 @@ extern "C" int bx_mm_head_fwd(const void* feat, const float* eeg_feat, const flo
   BX_DTYPE_OK(dtype);
   const int rc = mm_head_check("bx_mm_head_fwd", B, HW, C, K, N, Hd);
   if (rc) return rc;
+  const bool fast = 2 * N <= 12 && N <= 8 && K <= 1024 && C <= 1024;
   BX_DISPATCH_DTYPE(dtype, T,
-    hipLaunchKernelGGL((k_mm_head_fwd<T>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const T*)feat, eeg_feat, fc_w, fc_b, dense_w, dense_b, w1, b1,
-                       w2, b2, gap_out, spec_logp, eeg_logp, hidden, logp, HW, C, K, N, Hd));
+    if (fast) hipLaunchKernelGGL((k_mm_head_fwd<T, true>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const T*)feat, eeg_feat, fc_w, fc_b, dense_w,
+                                 dense_b, w1, b1, w2, b2, gap_out, spec_logp, eeg_logp, hidden, logp, HW, C, K, N, Hd);
+    else hipLaunchKernelGGL((k_mm_head_fwd<T, false>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const T*)feat, eeg_feat, fc_w, fc_b, dense_w,
+                            dense_b, w1, b1, w2, b2, gap_out, spec_logp, eeg_logp, hidden, logp, HW, C, K, N, Hd));
   BX_CHECK_LAUNCH("bx_mm_head_fwd");
   return BX_OK;
 }
