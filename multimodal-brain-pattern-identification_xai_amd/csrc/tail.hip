@@ -557,6 +557,160 @@ __device__ __forceinline__ void w1x1_grad_body(const T* __restrict__ dout, const
   if (ci0 + ci < g.Cin_p) partial[((size_t)bx * g.C + c0 + c) * g.Cin_p + ci0 + ci] = acc;
 }
 
+// Late-stage variant (C and Cin_p multiples of 64): 64 x 64 output tile per workgroup, a thread owns 4 x 4 outputs and one
+// trip covers 64 pixels (two 16-byte LDS reads feed 16 FMAs).  The 16 x 16 tiling above re-reads every pixel C*Cin_p/256
+// times from L2 (128 x for the last stage: 40 MB for 3 MB of operands); this one 16 x less.
+template <typename T>
+__device__ __forceinline__ void w1x1_grad_big_body(const T* __restrict__ dout, const T* __restrict__ x, float* __restrict__ partial,
+                                                   int pix_per_chunk, const TailGeom& g, int bx, int by, int bz) {
+  __shared__ __attribute__((aligned(16))) float sd[64][64], sxs[64][64];
+  const int tc = threadIdx.x & 15, tci = threadIdx.x >> 4;
+  const int c0 = by * 64, ci0 = bz * 64;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  const long long p_begin = (long long)bx * pix_per_chunk;
+  long long p_end = p_begin + pix_per_chunk;
+  if (p_end > g.npool) p_end = g.npool;
+  for (long long p0 = p_begin; p0 < p_end; p0 += 64) {
+    float vd[2][8], vx[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                             // unit = (pixel, 8-channel group): 512 units per operand, 2 per thread
+      const int u = threadIdx.x + 256 * h, px = u >> 3, c8 = u & 7;
+      const long long pp = p0 + px;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vd[h][j] = vx[h][j] = 0.f;
+      if (pp < p_end) {
+        ld8(dout, (size_t)pp * g.C + c0 + c8 * 8, vd[h]);
+        int ox, oy, b;
+        px_decode(pp, g.Wo, g.Ho, ox, oy, b);
+        skip_sample(x, g, b, oy, ox, ci0 + c8 * 8, vx[h]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int u = threadIdx.x + 256 * h, px = u >> 3, c8 = u & 7;
+      *reinterpret_cast<float4*>(&sd[px][c8 * 8]) = make_float4(vd[h][0], vd[h][1], vd[h][2], vd[h][3]);
+      *reinterpret_cast<float4*>(&sd[px][c8 * 8 + 4]) = make_float4(vd[h][4], vd[h][5], vd[h][6], vd[h][7]);
+      *reinterpret_cast<float4*>(&sxs[px][c8 * 8]) = make_float4(vx[h][0], vx[h][1], vx[h][2], vx[h][3]);
+      *reinterpret_cast<float4*>(&sxs[px][c8 * 8 + 4]) = make_float4(vx[h][4], vx[h][5], vx[h][6], vx[h][7]);
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) {
+      const float4 d4 = *reinterpret_cast<const float4*>(&sd[q][4 * tc]);
+      const float4 x4 = *reinterpret_cast<const float4*>(&sxs[q][4 * tci]);
+      const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(dv[i], xv[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    *reinterpret_cast<float4*>(partial + ((size_t)bx * g.C + c0 + 4 * tc + i) * g.Cin_p + ci0 + 4 * tci) =
+        make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+}
+
+// dXs on the matrix cores (bf16 storage, Cin_p in {16,32,64,128}, C % 32 == 0): the VALU kernel above re-stages the whole
+// weight matrix through LDS for 8-32 pixels per workgroup (31 us for the 2048-pixel last stage).  Here D^T = W^T dOut^T:
+// A = W^T [ci][c] built from the fp32 weights as a bf16 hi + lo pair (two MFMAs, ~fp32-accurate weights), B = dOut rows read
+// straight from global memory (8 consecutive channels of one pixel = one 16-byte load).  A lane ends up with 4 consecutive
+// input channels of one pixel: one 8-byte bf16 store per footprint position.  Waves split (channel tiles) x (pixel tiles).
+typedef __attribute__((ext_vector_type(8))) short tl_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float tl_f32x4;
+template <int NTW, int WN, int PTW>
+__device__ __forceinline__ void skip_dxs_mfma_body(const bf16_t* __restrict__ dout, const float* __restrict__ w1x1, int Cin,
+                                                   float* __restrict__ dxs, bf16_t* __restrict__ dx_even, const TailGeom& g, int bid) {
+  constexpr int PW = (4 / WN) * PTW * 16;                      // pixels per workgroup
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gq = lane >> 4, li = lane & 15;
+  const int wn = wave % WN, wp = wave / WN;
+  const long long p0 = (long long)bid * PW + wp * PTW * 16;
+  tl_f32x4 acc[PTW][NTW];
+#pragma unroll
+  for (int pt = 0; pt < PTW; ++pt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[pt][nt] = (tl_f32x4){0.f, 0.f, 0.f, 0.f};
+  float wv[2][NTW][8];
+  uint4 bv[2][PTW];
+  auto fetch = [&](int kb, int sel) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int ci = (wn * NTW + nt) * 16 + li;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wv[sel][nt][j] = ci < Cin ? w1x1[(size_t)(kb + 8 * gq + j) * Cin + ci] : 0.f;
+    }
+#pragma unroll
+    for (int pt = 0; pt < PTW; ++pt) {
+      const long long pix = p0 + pt * 16 + li;
+      bv[sel][pt] = pix < g.npool ? *reinterpret_cast<const uint4*>(dout + (size_t)pix * g.C + kb + 8 * gq) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  fetch(0, 0);
+  int sel = 0;
+  for (int kb = 0; kb < g.C; kb += 32, sel ^= 1) {
+    if (kb + 32 < g.C) fetch(kb + 32, sel ^ 1);
+    tl_bf16x8 ahi[NTW], alo[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      uint32_t h[4], l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = wv[sel][nt][2 * j], b = wv[sel][nt][2 * j + 1];
+        h[j] = pack2bf(a, b);
+        l[j] = pack2bf(a - __uint_as_float(h[j] << 16), b - __uint_as_float(h[j] & 0xffff0000u));
+      }
+      ahi[nt] = __builtin_bit_cast(tl_bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+      alo[nt] = __builtin_bit_cast(tl_bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+    }
+#pragma unroll
+    for (int pt = 0; pt < PTW; ++pt) {
+      const tl_bf16x8 bfr = __builtin_bit_cast(tl_bf16x8, bv[sel][pt]);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        acc[pt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[nt], bfr, acc[pt][nt], 0, 0, 0);
+        acc[pt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[nt], bfr, acc[pt][nt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int pt = 0; pt < PTW; ++pt) {
+    const long long pix = p0 + pt * 16 + li;
+    if (pix >= g.npool) continue;
+    if (dx_even) {
+      int ox, oy, b;
+      px_decode(pix, g.Wo, g.Ho, ox, oy, b);
+      const size_t base = (((size_t)b * g.H + 2 * oy) * g.W + 2 * ox) * g.Cin_p;
+      const size_t foot[4] = {0, (size_t)g.Cin_p, (size_t)g.W * g.Cin_p, (size_t)g.W * g.Cin_p + g.Cin_p};
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int ci = (wn * NTW + nt) * 16 + 4 * gq;
+        const uint2 v = make_uint2(pack2bf(0.25f * acc[pt][nt][0], 0.25f * acc[pt][nt][1]), pack2bf(0.25f * acc[pt][nt][2], 0.25f * acc[pt][nt][3]));
+#pragma unroll
+        for (int f = 0; f < 4; ++f) *reinterpret_cast<uint2*>(dx_even + base + foot[f] + ci) = v;
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int ci = (wn * NTW + nt) * 16 + 4 * gq;
+        *reinterpret_cast<float4*>(dxs + (size_t)pix * g.Cin_p + ci) = make_float4(acc[pt][nt][0], acc[pt][nt][1], acc[pt][nt][2], acc[pt][nt][3]);
+      }
+    }
+  }
+}
+template <typename T, int MF> struct SkipMfma {
+  static __device__ __forceinline__ void run(const T*, const float*, int, float*, T*, const TailGeom&, int) {}
+};
+template <> struct SkipMfma<bf16_t, 16>  { static __device__ __forceinline__ void run(const bf16_t* d, const float* w, int Cin, float* x, bf16_t* e, const TailGeom& g, int bid) { skip_dxs_mfma_body<1, 1, 2>(d, w, Cin, x, e, g, bid); } };
+template <> struct SkipMfma<bf16_t, 32>  { static __device__ __forceinline__ void run(const bf16_t* d, const float* w, int Cin, float* x, bf16_t* e, const TailGeom& g, int bid) { skip_dxs_mfma_body<1, 2, 2>(d, w, Cin, x, e, g, bid); } };
+template <> struct SkipMfma<bf16_t, 64>  { static __device__ __forceinline__ void run(const bf16_t* d, const float* w, int Cin, float* x, bf16_t* e, const TailGeom& g, int bid) { skip_dxs_mfma_body<1, 4, 4>(d, w, Cin, x, e, g, bid); } };
+template <> struct SkipMfma<bf16_t, 128> { static __device__ __forceinline__ void run(const bf16_t* d, const float* w, int Cin, float* x, bf16_t* e, const TailGeom& g, int bid) { skip_dxs_mfma_body<2, 4, 4>(d, w, Cin, x, e, g, bid); } };
+static inline int skip_mfma_pixels(int cin_p) { return cin_p == 16 ? 128 : 64; }      // pixels per workgroup of the configurations above
+
 // ---- merged launches of the block-tail backward ---------------------------------------------------------------------
 // A kernel boundary costs ~5 us here (drain, L2 write-back, next dispatch) and the late stages' tail kernels are a few
 // microseconds of latency-bound work each, so independent pieces share a launch, the role chosen by workgroup index:
@@ -574,17 +728,19 @@ struct TailFrontArgs {
   uint32_t salt;
   int n_red, n_w, wg_x, wg_y, ppc, Cin;
 };
-template <typename T, int CIV>
+template <typename T, int CIV, int MF>      // MF = Cin_p of the MFMA input-gradient role, 0 = VALU role with CIV channels per thread
 __global__ __launch_bounds__(256) void k_tail_bwd_front(TailFrontArgs<T> a, TailGeom g) {
   int bid = blockIdx.x;
   if (bid < a.n_red) { tail_bwd_reduce_body<T>(a.dout, a.pooled, a.mean, a.invstd, a.seed, a.dropout_p, a.salt, a.partials, g, bid, a.n_red); return; }
   bid -= a.n_red;
   if (bid < a.n_w) {
     const int bx = bid % a.wg_x, r = bid / a.wg_x;
-    w1x1_grad_body<T>(a.dout, a.x, a.wpart, a.ppc, g, bx, r % a.wg_y, r / a.wg_y);
+    if (MF >= 64) w1x1_grad_big_body<T>(a.dout, a.x, a.wpart, a.ppc, g, bx, r % a.wg_y, r / a.wg_y);   // MF >= 64 <=> late stage (launcher)
+    else w1x1_grad_body<T>(a.dout, a.x, a.wpart, a.ppc, g, bx, r % a.wg_y, r / a.wg_y);
     return;
   }
-  skip_dxs_body<T, CIV>(a.dout, a.w1x1, a.Cin, a.dxs, a.dx_even, g, bid - a.n_w);
+  if (MF) SkipMfma<T, MF>::run(a.dout, a.w1x1, a.Cin, a.dxs, a.dx_even, g, bid - a.n_w);
+  else skip_dxs_body<T, CIV>(a.dout, a.w1x1, a.Cin, a.dxs, a.dx_even, g, bid - a.n_w);
 }
 // mid: 1024 threads.  Workgroups [0, n_fin) finalize 16 channels each; the others sum weight-gradient partials, four
 // 256-thread groups per workgroup, each group as in k_sum_partials; (c, ci) of the padded layout goes to dw[c][ci < Cin].
@@ -645,7 +801,12 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
 
   // ---- front: reduction | w1x1 weight-gradient partials | skip input gradient
   const bool even = (g.H % 2 == 0) && (g.W % 2 == 0);
-  int nchunk = 0, ppc = 0, wg_y = g.C / 16, wg_z = (g.Cin_p + 15) / 16;
+  static const int no_mfma = getenv("BX_SKIP_NO_MFMA") ? atoi(getenv("BX_SKIP_NO_MFMA")) : 0;
+  const int mf = (dx_skip && !no_mfma && d->dtype == BX_BF16 && g.C % 32 == 0 && (g.Cin_p == 16 || g.Cin_p == 32 || g.Cin_p == 64 || g.Cin_p == 128))
+                 ? g.Cin_p : 0;
+  const bool wbig = mf >= 64 && g.C % 64 == 0;                 // 64 x 64 weight-gradient tiles (kernel: MF >= 64)
+  BX_REQUIRE(mf < 64 || wbig, "bx_block_tail_bwd: C must be a multiple of 64 when Cin_p >= 64");
+  int nchunk = 0, ppc = 0, wg_y = wbig ? g.C / 64 : g.C / 16, wg_z = wbig ? g.Cin_p / 64 : (g.Cin_p + 15) / 16;
   if (d_w1x1) {
     // up to ~4096 workgroups in total; partial buffer = nchunk * C * Cin_p floats <= 2048*256 + 64*C*Cin_p (workspace formula)
     const int otiles = wg_y * wg_z;
@@ -659,16 +820,21 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
     nchunk = (int)((g.npool + ppc - 1) / ppc);
   }
   const bool narrow = g.npool * (g.Cin_p / 8) < 256 * 256;          // fewer than one workgroup per CU at 8 channels per thread
-  const int n_dxs = dx_skip ? bx_ceil_div(g.npool * (g.Cin_p / (narrow ? 4 : 8)), 256) : 0;
+  const int n_dxs = !dx_skip ? 0 : mf ? bx_ceil_div(g.npool, skip_mfma_pixels(mf)) : bx_ceil_div(g.npool * (g.Cin_p / (narrow ? 4 : 8)), 256);
   const int n_w = nchunk * wg_y * wg_z;
-  const size_t front_lds = dx_skip ? (size_t)64 * g.Cin_p * sizeof(float) : 0;
+  const size_t front_lds = (dx_skip && !mf) ? (size_t)64 * g.Cin_p * sizeof(float) : 0;
   BX_DISPATCH_DTYPE(d->dtype, T, {
     TailFrontArgs<T> a;
     a.dout = (const T*)dout; a.pooled = (const T*)pooled; a.x = (const T*)x; a.mean = save_mean; a.invstd = save_invstd; a.w1x1 = w1x1;
     a.seed = seed; a.partials = partials; a.wpart = wpart; a.dxs = dxs; a.dx_even = even ? (T*)dx_skip : (T*)nullptr;
     a.dropout_p = p; a.salt = d->salt; a.n_red = nblk; a.n_w = n_w; a.wg_x = nchunk > 0 ? nchunk : 1; a.wg_y = wg_y; a.ppc = ppc; a.Cin = Cin;
-    if (narrow) hipLaunchKernelGGL((k_tail_bwd_front<T, 4>), dim3(nblk + n_w + n_dxs), dim3(256), front_lds, s, a, g);
-    else hipLaunchKernelGGL((k_tail_bwd_front<T, 8>), dim3(nblk + n_w + n_dxs), dim3(256), front_lds, s, a, g);
+    const dim3 grid(nblk + n_w + n_dxs);
+    if (mf == 16) hipLaunchKernelGGL((k_tail_bwd_front<T, 8, 16>), grid, dim3(256), front_lds, s, a, g);
+    else if (mf == 32) hipLaunchKernelGGL((k_tail_bwd_front<T, 8, 32>), grid, dim3(256), front_lds, s, a, g);
+    else if (mf == 64) hipLaunchKernelGGL((k_tail_bwd_front<T, 8, 64>), grid, dim3(256), front_lds, s, a, g);
+    else if (mf == 128) hipLaunchKernelGGL((k_tail_bwd_front<T, 8, 128>), grid, dim3(256), front_lds, s, a, g);
+    else if (narrow) hipLaunchKernelGGL((k_tail_bwd_front<T, 4, 0>), grid, dim3(256), front_lds, s, a, g);
+    else hipLaunchKernelGGL((k_tail_bwd_front<T, 8, 0>), grid, dim3(256), front_lds, s, a, g);
   });
   BX_CHECK_LAUNCH("bx_block_tail_bwd(front)");
   // ---- mid: finalize | weight-gradient sum
