@@ -85,6 +85,20 @@ size_t bx_conv3x3_wgrad_workspace(int B, int H, int W, int Ci_p, int Co, int dty
 int bx_conv3x3_wgrad(const void* x, const void* dz, float* dw_oihw, float* dbias, int B, int H, int W,
                      int Cin, int Ci_p, int Co, int dtype, int algo, void* workspace, size_t workspace_bytes,
                      bxStream stream);
+/* Chained form: the fixed-order sum of a layer's weight-gradient partials (a ~6 us launch of its own, 15 per training step)
+ * rides in the NEXT layer's launch instead.  *pending (zero-initialised before the first call) describes partials that still
+ * have to be summed: a valid *pending is reduced by this call's launch and then overwritten with this layer's; the caller
+ * must give consecutive calls DIFFERENT workspaces (the pending partials live in the previous one), keep that workspace and
+ * the previous dw/dbias alive until the next call, and end the chain with bx_conv3x3_wgrad_finish (e.g. at the end of
+ * backward).  Paths that cannot carry a reduce (fp32 / direct kernels) finish the chain themselves. */
+typedef struct {
+  const void* partial; float* dw; float* db;
+  int nsplit, Cin, Co, ma, nb, ztiles, nfrag4, valid;
+} bxWgradPending;
+int bx_conv3x3_wgrad_chained(const void* x, const void* dz, float* dw_oihw, float* dbias, int B, int H, int W, int Cin,
+                             int Ci_p, int Co, int dtype, int algo, void* workspace, size_t workspace_bytes,
+                             bxWgradPending* pending, bxStream stream);
+int bx_conv3x3_wgrad_finish(bxWgradPending* pending, bxStream stream);
 
 /* ---- Block tail: 2x2 pool -> BatchNorm2d -> Dropout -> + conv1x1(bilinear(x))  (M:67-76) ------ */
 typedef struct {

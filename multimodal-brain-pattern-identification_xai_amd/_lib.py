@@ -49,6 +49,11 @@ class EegDeepGrads(C.Structure):
     _fields_ = [(n, vp) for n in ("conv2_w", "bn4_w", "bn4_b", "wq", "bq", "wk", "bk", "wv", "bv", "w1", "b1", "w2", "b2")]
 
 
+class WgradPending(C.Structure):
+    _fields_ = [("partial", vp), ("dw", vp), ("db", vp), ("nsplit", i32), ("Cin", i32), ("Co", i32), ("ma", i32), ("nb", i32),
+                ("ztiles", i32), ("nfrag4", i32), ("valid", i32)]
+
+
 class PackJob(C.Structure):
     _fields_ = [("w_oihw", vp), ("packed_mfma", vp), ("Cout", i32), ("Cin", i32), ("I_p", i32), ("O_p", i32),
                 ("transpose_flip", i32), ("block_begin", i32)]
@@ -73,6 +78,8 @@ SIGNATURES = {
     "bx_conv3x3": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "bx_conv3x3_wgrad_workspace": (sz, [i32, i32, i32, i32, i32, i32, i32]),
     "bx_conv3x3_wgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "bx_conv3x3_wgrad_chained": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, P(WgradPending), vp]),
+    "bx_conv3x3_wgrad_finish": (i32, [P(WgradPending), vp]),
     "bx_block_tail_workspace": (sz, [P(TailDesc)]),
     "bx_block_tail_fwd": (i32, [P(TailDesc), vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "bx_block_tail_bwd": (i32, [P(TailDesc), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),

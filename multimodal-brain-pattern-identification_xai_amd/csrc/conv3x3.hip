@@ -13,7 +13,8 @@ void bx_conv3x3_mfma_pack_launch(const float* w_oihw, void* packed, int Cout, in
 size_t bx_wgrad_mfma_workspace(int B, int H, int W, int Ci_p, int Co);
 int bx_wgrad_mfma_supported(int Ci_p, int Co, int dtype);
 int bx_wgrad_mfma_launch(const void* x, const void* dz, float* dw, float* db, int B, int H, int W, int Cin, int Ci_p,
-                         int Co, void* ws, size_t ws_bytes, hipStream_t s);
+                         int Co, void* ws, size_t ws_bytes, bxWgradPending* pending, hipStream_t s);
+int bx_wgrad_mfma_finish(bxWgradPending* pending, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // Packing: fp32 [9][I_p][O_p]
@@ -265,9 +266,25 @@ extern "C" size_t bx_conv3x3_wgrad_workspace(int B, int H, int W, int Ci_p, int 
   return (size_t)nchunk * ((size_t)9 * Ci_p * Co + Co) * sizeof(float);
 }
 
+static int wgrad_impl(const void* x, const void* dz, float* dw_oihw, float* dbias, int B, int H, int W, int Cin, int Ci_p, int Co, int dtype,
+                      int algo, void* workspace, size_t workspace_bytes, bxWgradPending* pending, bxStream stream);
 extern "C" int bx_conv3x3_wgrad(const void* x, const void* dz, float* dw_oihw, float* dbias, int B, int H, int W,
                                 int Cin, int Ci_p, int Co, int dtype, int algo, void* workspace, size_t workspace_bytes,
                                 bxStream stream) {
+  return wgrad_impl(x, dz, dw_oihw, dbias, B, H, W, Cin, Ci_p, Co, dtype, algo, workspace, workspace_bytes, nullptr, stream);
+}
+extern "C" int bx_conv3x3_wgrad_chained(const void* x, const void* dz, float* dw_oihw, float* dbias, int B, int H, int W,
+                                        int Cin, int Ci_p, int Co, int dtype, int algo, void* workspace, size_t workspace_bytes,
+                                        bxWgradPending* pending, bxStream stream) {
+  BX_REQUIRE(pending, "bx_conv3x3_wgrad_chained: pending is NULL");
+  return wgrad_impl(x, dz, dw_oihw, dbias, B, H, W, Cin, Ci_p, Co, dtype, algo, workspace, workspace_bytes, pending, stream);
+}
+extern "C" int bx_conv3x3_wgrad_finish(bxWgradPending* pending, bxStream stream) {
+  BX_REQUIRE(pending, "bx_conv3x3_wgrad_finish: pending is NULL");
+  return bx_wgrad_mfma_finish(pending, (hipStream_t)stream);
+}
+static int wgrad_impl(const void* x, const void* dz, float* dw_oihw, float* dbias, int B, int H, int W, int Cin, int Ci_p, int Co, int dtype,
+                      int algo, void* workspace, size_t workspace_bytes, bxWgradPending* pending, bxStream stream) {
   BX_DTYPE_OK(dtype);
   BX_REQUIRE(x && dz && dw_oihw && B > 0 && H > 0 && W > 0, "bx_conv3x3_wgrad: bad arguments");
   BX_REQUIRE(Ci_p % 8 == 0 && Co % 16 == 0 && Cin <= Ci_p, "bx_conv3x3_wgrad: need Ci_p%%8==0, Co%%16==0 (Ci_p=%d Co=%d)", Ci_p, Co);
@@ -277,7 +294,11 @@ extern "C" int bx_conv3x3_wgrad(const void* x, const void* dz, float* dw_oihw, f
   if (!workspace || workspace_bytes < need) BX_FAIL(BX_EWORKSPACE, "bx_conv3x3_wgrad: workspace %zu < %zu", workspace_bytes, need);
   if (algo == BX_ALGO_MFMA) {
     if (!bx_wgrad_mfma_supported(Ci_p, Co, dtype)) BX_FAIL(BX_EUNSUPPORTED, "bx_conv3x3_wgrad: MFMA path unsupported for Ci_p=%d Co=%d dtype=%d", Ci_p, Co, dtype);
-    return bx_wgrad_mfma_launch(x, dz, dw_oihw, dbias, B, H, W, Cin, Ci_p, Co, workspace, workspace_bytes, s);
+    return bx_wgrad_mfma_launch(x, dz, dw_oihw, dbias, B, H, W, Cin, Ci_p, Co, workspace, workspace_bytes, pending, s);
+  }
+  if (pending && pending->valid) {                             // the direct kernels cannot carry a reduce: finish the chain first
+    const int rc = bx_wgrad_mfma_finish(pending, s);
+    if (rc) return rc;
   }
   int seg, nseg_x, ipc; long long nitems;
   const int nchunk = wgrad_direct_chunks(B, H, W, Ci_p, Co, &seg, &nseg_x, &nitems, &ipc);

@@ -15,6 +15,7 @@
 //   epilogue (bias, ReLU | ReLU-mask of the producing layer, skip-gradient addend).
 #include <stdlib.h>
 #include "bx_common.h"
+#include <string.h>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -578,6 +579,67 @@ int bx_conv3x3_mfma_launch(const void* x, const void* packed_mfma, const float* 
   }
 }
 
+// sum the partials in a fixed order and scatter to OIHW.  A split is [ytiles][ztiles][9*MA*NB tiles][64 lanes][4 regs]
+// accumulator fragments followed by Co bias sums.  A workgroup covers NO = 256/S float4 groups x S split slices
+// (S = 4, 16 or 64: small outputs get many slices so that the chip is filled and no thread walks hundreds of splits);
+// slices are combined through LDS in slice order.
+struct WgradRedJob { const float* partial; float* dw; float* db; int nsplit, Cin, Co, S, MA, NB, ztiles, nfrag4, nblocks; };
+__device__ __forceinline__ void wgrad_reduce3_body(const WgradRedJob& jb, int bid, float4* sm) {
+  const float* __restrict__ partial = jb.partial;
+  float* __restrict__ dw = jb.dw;
+  float* __restrict__ db = jb.db;
+  const int nsplit = jb.nsplit, Cin = jb.Cin, Co = jb.Co, S = jb.S, MA = jb.MA, NB = jb.NB, ztiles = jb.ztiles, nfrag4 = jb.nfrag4;
+  const size_t per_split = (size_t)nfrag4 * 4 + Co;
+  const int NO = 256 / S;
+  const int o = threadIdx.x % NO, part = threadIdx.x / NO;
+  const size_t e4 = (size_t)bid * NO + o;          // float4 index inside a split
+  const bool live = e4 * 4 < per_split;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    const float* src = partial + e4 * 4;
+    int c = part;
+    for (; c + 3 * S < nsplit; c += 4 * S) {      // four independent loads in flight; adds stay in split order
+      const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)c * per_split);
+      const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)(c + S) * per_split);
+      const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)(c + 2 * S) * per_split);
+      const float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)(c + 3 * S) * per_split);
+      s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+      s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+      s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+      s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+    }
+    for (; c < nsplit; c += S) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * per_split);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (part == 0 && live) {
+    float4 r = sm[o];
+    for (int k = 1; k < S; ++k) { const float4 v = sm[k * NO + o]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+    const float rr[4] = {r.x, r.y, r.z, r.w};
+    if (e4 < (size_t)nfrag4) {
+      const int NT = 9 * MA * NB;
+      const int lane = (int)(e4 & 63), tl = (int)(e4 >> 6);
+      const int i = tl % NT, yz = tl / NT, z = yz % ztiles, y = yz / ztiles;
+      const int n = i % NB, m = (i / NB) % MA, t = i / (NB * MA);
+      const int cout = (z * NB + n) * 16 + (lane & 15), cin0 = (y * MA + m) * 16 + 4 * (lane >> 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (cin0 + j < Cin) dw[((size_t)cout * Cin + cin0 + j) * 9 + t] = rr[j];
+    } else if (db) {
+      const size_t b0 = (e4 - nfrag4) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) db[b0 + j] = rr[j];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_wgrad_reduce3(WgradRedJob jb) {
+  __shared__ float4 sm[256];
+  wgrad_reduce3_body(jb, blockIdx.x, sm);
+}
+
 // ================================================================================================
 // Weight gradient (k_wgrad_mfma):  dW[tap][cin][cout] = sum_pixels X[pixel+tap][cin] * dZ[pixel][cout]
 //   v_mfma_f32_16x16x32_bf16 with the PIXEL index as K:  A = X^T (row = cin, k = 32 pixels), B = dZ (k = pixels,
@@ -601,16 +663,24 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* lds, int off0, int off1) 
 
 template <int MA, int NB, int TW>
 __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dz, float* __restrict__ partial,
-    int H, int W, int Ci_p, int Co, int tiles_x, int tiles_y, int ntiles, int tiles_per_split) {
+    int H, int W, int Ci_p, int Co, int tiles_x, int tiles_y, int ntiles, int tiles_per_split, WgradRedJob prev, int zextra) {
   constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CIT = 16 * MA, COT = 16 * NB, XB = CIT * 2, ZB = COT * 2;
   constexpr int KPW = TH * TW / 32 / 4;                 // K-steps (32 pixels) per wave per tile
   constexpr int XS_BYTES = HH * HWID * XB;             // the dZ tile (TH * TW * ZB bytes) follows the halo tile
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  // chained mode: the first `zextra` z-slices of the grid sum the PREVIOUS layer's partials (its reduce launch is saved; these
+  // light workgroups are dispatched first and overlap with the heavy ones that follow)
+  if ((int)blockIdx.z < zextra) {
+    const int rid = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+    if (rid < prev.nblocks) wgrad_reduce3_body(prev, rid, reinterpret_cast<float4*>(lds));
+    return;
+  }
+  const int bz = (int)blockIdx.z - zextra, gz = (int)gridDim.z - zextra;
   char* xs = lds;
   char* zs = lds + XS_BYTES;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
   const int q = li >> 2, pc = li & 3;
-  const int ci0 = blockIdx.y * CIT, co0 = blockIdx.z * COT;
+  const int ci0 = blockIdx.y * CIT, co0 = bz * COT;
   const bool want_bias = blockIdx.y == 0;
 
   f32x4 acc[9][MA][NB];
@@ -746,10 +816,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const bf16_t* __restrict_
       }
     __syncthreads();
   }
-  const size_t nfrag = (size_t)gridDim.y * gridDim.z * NT * 256;       // floats of accumulator fragments per split
+  const size_t nfrag = (size_t)gridDim.y * gz * NT * 256;              // floats of accumulator fragments per split
   const size_t per_split = nfrag + Co;
   float* out = partial + (size_t)blockIdx.x * per_split;
-  float4* out4 = reinterpret_cast<float4*>(out) + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * NT * 64;
+  float4* out4 = reinterpret_cast<float4*>(out) + ((size_t)blockIdx.y * gz + bz) * NT * 64;
 #pragma unroll
   for (int i = 0; i < NT; ++i)
     if ((i & 3) == wave) {
@@ -770,60 +840,6 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const bf16_t* __restrict_
       const int n = threadIdx.x >> 4, c = threadIdx.x & 15;
       out[nfrag + co0 + threadIdx.x] =
           red[(0 * NB + n) * 16 + c] + red[(1 * NB + n) * 16 + c] + red[(2 * NB + n) * 16 + c] + red[(3 * NB + n) * 16 + c];
-    }
-  }
-}
-
-// sum the partials in a fixed order and scatter to OIHW.  A split is [ytiles][ztiles][9*MA*NB tiles][64 lanes][4 regs]
-// accumulator fragments followed by Co bias sums.  A workgroup covers NO = 256/S float4 groups x S split slices
-// (S = 4, 16 or 64: small outputs get many slices so that the chip is filled and no thread walks hundreds of splits);
-// slices are combined through LDS in slice order.
-__global__ __launch_bounds__(256) void k_wgrad_reduce3(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
-                                                        int nsplit, int Cin, int Co, int S, int MA, int NB, int ztiles, int nfrag4) {
-  __shared__ float4 sm[256];
-  const size_t per_split = (size_t)nfrag4 * 4 + Co;
-  const int NO = 256 / S;
-  const int o = threadIdx.x % NO, part = threadIdx.x / NO;
-  const size_t e4 = (size_t)blockIdx.x * NO + o;          // float4 index inside a split
-  const bool live = e4 * 4 < per_split;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (live) {
-    const float* src = partial + e4 * 4;
-    int c = part;
-    for (; c + 3 * S < nsplit; c += 4 * S) {      // four independent loads in flight; adds stay in split order
-      const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)c * per_split);
-      const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)(c + S) * per_split);
-      const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)(c + 2 * S) * per_split);
-      const float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)(c + 3 * S) * per_split);
-      s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
-      s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
-      s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
-      s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
-    }
-    for (; c < nsplit; c += S) {
-      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * per_split);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-  }
-  sm[threadIdx.x] = s;
-  __syncthreads();
-  if (part == 0 && live) {
-    float4 r = sm[o];
-    for (int k = 1; k < S; ++k) { const float4 v = sm[k * NO + o]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
-    const float rr[4] = {r.x, r.y, r.z, r.w};
-    if (e4 < (size_t)nfrag4) {
-      const int NT = 9 * MA * NB;
-      const int lane = (int)(e4 & 63), tl = (int)(e4 >> 6);
-      const int i = tl % NT, yz = tl / NT, z = yz % ztiles, y = yz / ztiles;
-      const int n = i % NB, m = (i / NB) % MA, t = i / (NB * MA);
-      const int cout = (z * NB + n) * 16 + (lane & 15), cin0 = (y * MA + m) * 16 + 4 * (lane >> 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (cin0 + j < Cin) dw[((size_t)cout * Cin + cin0 + j) * 9 + t] = rr[j];
-    } else if (db) {
-      const size_t b0 = (e4 - nfrag4) * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) db[b0 + j] = rr[j];
     }
   }
 }
@@ -856,31 +872,65 @@ size_t bx_wgrad_mfma_workspace(int B, int H, int W, int Ci_p, int Co) {
   return (size_t)p.nsplit * ((size_t)p.ytiles * p.ztiles * 9 * p.ma * p.nb * 256 + Co) * sizeof(float);
 }
 template <int MA, int NB, int TW>
-static void launch_wgrad(const WgradPlan& p, const void* x, const void* dz, float* ws, int H, int W, int Ci_p, int Co, hipStream_t s) {
-  dim3 grid(p.nsplit, p.ytiles, p.ztiles);
+static void launch_wgrad(const WgradPlan& p, const void* x, const void* dz, float* ws, int H, int W, int Ci_p, int Co, const WgradRedJob& prev,
+                         int zextra, hipStream_t s) {
+  dim3 grid(p.nsplit, p.ytiles, p.ztiles + zextra);
   hipLaunchKernelGGL((k_wgrad_mfma<MA, NB, TW>), grid, dim3(256), p.lds, s, (const bf16_t*)x, (const bf16_t*)dz, ws, H, W, Ci_p, Co,
-                     p.tiles_x, p.tiles_y, p.ntiles, p.tps);
+                     p.tiles_x, p.tiles_y, p.ntiles, p.tps, prev, zextra);
 }
+// slices per output of the partial sum: a stand-alone reduce wants many slices when there are few outputs (fills the chip);
+// a reduce that rides in the next layer's launch wants few workgroups and a short chain of loads per thread
+static int wgrad_reduce_slices(size_t per_split, int nsplit, bool chained) {
+  if (!chained) return per_split >= 65536 ? 4 : per_split >= 8192 ? 16 : 64;
+  int S = 1;
+  while (S < 64 && nsplit > 8 * S) S *= 2;
+  return S;
+}
+static WgradRedJob wgrad_job_from(const bxWgradPending* pd, bool chained) {
+  WgradRedJob jb;
+  jb.partial = (const float*)pd->partial; jb.dw = pd->dw; jb.db = pd->db; jb.nsplit = pd->nsplit; jb.Cin = pd->Cin; jb.Co = pd->Co;
+  jb.MA = pd->ma; jb.NB = pd->nb; jb.ztiles = pd->ztiles; jb.nfrag4 = pd->nfrag4;
+  const size_t per_split = (size_t)pd->nfrag4 * 4 + pd->Co;
+  jb.S = wgrad_reduce_slices(per_split, pd->nsplit, chained);
+  const int per_wg = 256 / jb.S;
+  jb.nblocks = (int)((per_split / 4 + per_wg - 1) / per_wg);
+  return jb;
+}
+int bx_wgrad_mfma_finish(bxWgradPending* pd, hipStream_t s) {
+  if (!pd || !pd->valid) return BX_OK;
+  const WgradRedJob jb = wgrad_job_from(pd, false);
+  hipLaunchKernelGGL(k_wgrad_reduce3, dim3(jb.nblocks), dim3(256), 0, s, jb);
+  pd->valid = 0;
+  BX_CHECK_LAUNCH("bx_conv3x3_wgrad(mfma reduce)");
+  return BX_OK;
+}
+// pending == NULL: partials are reduced right away.  Otherwise: a valid *pending (previous layer) is reduced inside this launch
+// and *pending is overwritten with this layer's unreduced partials (the caller chains it on or calls bx_wgrad_mfma_finish).
 int bx_wgrad_mfma_launch(const void* x, const void* dz, float* dw, float* db, int B, int H, int W, int Cin, int Ci_p,
-                         int Co, void* ws, size_t ws_bytes, hipStream_t s) {
+                         int Co, void* ws, size_t ws_bytes, bxWgradPending* pending, hipStream_t s) {
   const WgradPlan p = wgrad_plan(B, H, W, Ci_p, Co);
   (void)ws_bytes;
   BX_REQUIRE((size_t)B * H * W * (Ci_p > Co ? Ci_p : Co) * 2 < ((size_t)1 << 31), "bx_conv3x3_wgrad(mfma): an activation tensor of 2 GiB or more is not supported");
+  BX_REQUIRE(!pending || !pending->valid || pending->partial != ws, "bx_conv3x3_wgrad(chained): the pending partials live in this call's workspace");
   float* part = (float*)ws;
-#define BX_WG(MA_, NB_) do { if (p.tw == 16) launch_wgrad<MA_, NB_, 16>(p, x, dz, part, H, W, Ci_p, Co, s); \
-                             else launch_wgrad<MA_, NB_, 32>(p, x, dz, part, H, W, Ci_p, Co, s); } while (0)
+  WgradRedJob prev;
+  memset(&prev, 0, sizeof(prev));
+  int zextra = 0;
+  if (pending && pending->valid) {
+    prev = wgrad_job_from(pending, true);
+    zextra = (prev.nblocks + p.nsplit * p.ytiles - 1) / (p.nsplit * p.ytiles);
+  }
+#define BX_WG(MA_, NB_) do { if (p.tw == 16) launch_wgrad<MA_, NB_, 16>(p, x, dz, part, H, W, Ci_p, Co, prev, zextra, s); \
+                             else launch_wgrad<MA_, NB_, 32>(p, x, dz, part, H, W, Ci_p, Co, prev, zextra, s); } while (0)
   if (p.ma == 1 && p.nb == 1) BX_WG(1, 1);
   else if (p.ma == 1 && p.nb == 2) BX_WG(1, 2);
   else if (p.ma == 2 && p.nb == 1) BX_WG(2, 1);
   else BX_WG(2, 2);
 #undef BX_WG
   BX_CHECK_LAUNCH("bx_conv3x3_wgrad(mfma)");
-  const int nfrag4 = p.ytiles * p.ztiles * 9 * p.ma * p.nb * 64;
-  const size_t per_split = (size_t)nfrag4 * 4 + Co;
-  const int S = per_split >= 65536 ? 4 : per_split >= 8192 ? 16 : 64;
-  const int per_wg = 256 / S;                                // float4 groups per workgroup
-  hipLaunchKernelGGL(k_wgrad_reduce3, dim3((unsigned)((per_split / 4 + per_wg - 1) / per_wg)), dim3(256), 0, s, part, dw, db, p.nsplit, Cin, Co, S,
-                     p.ma, p.nb, p.ztiles, nfrag4);
-  BX_CHECK_LAUNCH("bx_conv3x3_wgrad(mfma reduce)");
-  return BX_OK;
+  bxWgradPending cur;
+  cur.partial = part; cur.dw = dw; cur.db = db; cur.nsplit = p.nsplit; cur.Cin = Cin; cur.Co = Co; cur.ma = p.ma; cur.nb = p.nb;
+  cur.ztiles = p.ztiles; cur.nfrag4 = p.ytiles * p.ztiles * 9 * p.ma * p.nb * 64; cur.valid = 1;
+  if (pending) { *pending = cur; return BX_OK; }
+  return bx_wgrad_mfma_finish(&cur, s);
 }

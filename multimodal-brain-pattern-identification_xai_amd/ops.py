@@ -272,15 +272,58 @@ def _conv(x, packed, bias, mask_src, addend, relu: bool, dtype):
     return y
 
 
-def _wgrad(x, dz, w: torch.Tensor, b: torch.Tensor):
+# Chained weight gradients: inside one Block's backward the sum of a layer's partials rides in the next layer's launch
+# (bx_conv3x3_wgrad_chained); BlockFn.backward finishes the chain before it returns (autograd may copy or accumulate a
+# returned gradient right away, so nothing may be pending then).  Per device: the pending descriptor, two partial buffers
+# used alternately (the pending partials must outlive the next launch) and the tensors to keep alive meanwhile.
+WGRAD_CHAIN = _os.environ.get("BX_WGRAD_CHAIN", "1") == "1"
+_WG_CHAIN = {}
+
+
+def _wg_chain_state(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _WG_CHAIN.get(key)
+    if st is None:
+        st = SimpleNamespace(pend=L.WgradPending(), ring=[None, None], slot=0, keep=None, stream=None)
+        _WG_CHAIN[key] = st
+    return st
+
+
+def wgrad_flush(device=None):
+    """Sum the partials of the last chained weight gradient (no-op when nothing is pending)."""
+    for key, st in list(_WG_CHAIN.items()):
+        if device is not None and key != (device.index if device.index is not None else torch.cuda.current_device()):
+            continue
+        if st.pend.valid:
+            L.check(L.load().bx_conv3x3_wgrad_finish(C.byref(st.pend), st.stream), "bx_conv3x3_wgrad_finish")
+        st.keep = None
+
+
+def _wgrad(x, dz, w: torch.Tensor, b: torch.Tensor, chain: bool = False):
+    """chain=True: the caller promises to call wgrad_flush() before the gradients leave its hands."""
     lib = L.load()
     B, H, W, Cip = x.shape
     Co = dz.shape[3]
     dt = bx_dtype(x.dtype)
     algo = WGRAD_ALGO if x.dtype == torch.bfloat16 else L.BX_ALGO_DIRECT
     need = lib.bx_conv3x3_wgrad_workspace(B, H, W, Cip, Co, dt, algo)
-    ws = workspace(need, x.device)
     dw, db = new_grad(w), new_grad(b)
+    if chain and WGRAD_CHAIN and x.dtype == torch.bfloat16 and algo != L.BX_ALGO_DIRECT:
+        st = _wg_chain_state(x.device)
+        if st.pend.valid and st.stream != _stream():
+            wgrad_flush(x.device)                           # never carry a pending reduce across streams
+        buf = st.ring[st.slot]
+        if buf is None or buf.numel() < need:
+            buf = torch.empty(max(int(need), 1 << 20), dtype=torch.uint8, device=x.device)
+            st.ring[st.slot] = buf
+        st.stream = _stream()
+        with _Timed("wgrad"):
+            L.check(lib.bx_conv3x3_wgrad_chained(_p(x), _p(dz), _p(dw), _p(db), B, H, W, w.shape[1], Cip, Co, dt, algo, _p(buf), buf.numel(),
+                                                 C.byref(st.pend), st.stream), "bx_conv3x3_wgrad_chained")
+        st.keep = (buf, dw, db)                             # what the pending reduce reads / writes
+        st.slot ^= 1
+        return dw, db
+    ws = workspace(need, x.device)
     with _Timed("wgrad"):
         L.check(lib.bx_conv3x3_wgrad(_p(x), _p(dz), _p(dw), _p(db), B, H, W, w.shape[1], Cip, Co, dt, algo, _p(ws), ws.numel(), _stream()),
                 "bx_conv3x3_wgrad")
@@ -373,7 +416,7 @@ class BlockFn(torch.autograd.Function):
                     grads_w[k], grads_b[k] = _wgrad(acts[k], dz, wts[k], bss[k])
                 dz.record_stream(side); acts[k].record_stream(side)
             elif need_w:
-                grads_w[k], grads_b[k] = _wgrad(acts[k], dz, wts[k], bss[k])
+                grads_w[k], grads_b[k] = _wgrad(acts[k], dz, wts[k], bss[k], chain=True)
             packed = cfg.prepacked.get(cfg.pack_base + k, True) if cfg.prepacked is not None else None
             if k > 0:
                 dz = _conv(dz, packed or _pack(wts[k], flip=True, dtype=dt), None, acts[k], None, False, dt)
@@ -381,6 +424,8 @@ class BlockFn(torch.autograd.Function):
                     cfg.capture["grad"] = dz
             elif need_dx:
                 dz = _conv(dz, packed or _pack(wts[0], flip=True, dtype=dt), None, None, dx_skip, False, dt)
+        if need_w and side is None:
+            wgrad_flush(x.device)                           # conv1's partial sum: nothing may be pending when the gradients are returned
         dx = dz if need_dx else None
         return (dx, grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2], d_bnw, d_bnb, d_w11, d_b11,
                 None, None, None, None)

@@ -71,6 +71,7 @@ class FlatAdamW:
         """Make the gradient arena hold every parameter's gradient (no-op for slices the kernels wrote)."""
         if self.is_cuda:
             ops.join_side_streams(self.flat_g.device)      # weight-gradient kernels may still run on the side stream
+            ops.wgrad_flush(self.flat_g.device)            # normally done by backward's end callback; no-op then
         base = self.flat_g.data_ptr()
         for p, off in zip(self.params, self.offsets):
             slot = self.flat_g.narrow(0, off, p.numel())

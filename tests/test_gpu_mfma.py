@@ -128,3 +128,53 @@ def test_wgrad_mfma(cin, cip, cout, h, w):
     for name in got:
         assert rel_err(got[name][0], wt.grad) < 1e-4, name          # bf16 inputs are exact in fp32; only summation order differs
         assert rel_err(got[name][1], bias.grad) < 1e-4, name
+
+
+def test_wgrad_chained_reduce_matches_immediate():
+    """bx_conv3x3_wgrad_chained: a layer's partial sum rides in the next layer's launch; four layers of different tilings in a
+    chain + bx_conv3x3_wgrad_finish agree with four bx_conv3x3_wgrad calls (same fixed-order sums up to the slice count,
+    hence 1e-6) and leave nothing pending; re-using the pending workspace is refused."""
+    import ctypes
+    lib = L.load()
+    torch.manual_seed(4)
+    layers = [(16, 32, 32, 64), (64, 64, 16, 32), (8, 16, 64, 128), (256, 256, 8, 16)]
+    B = 4
+    data, want = [], []
+    for cin, cout, h, w in layers:
+        cip = ops.pad8(cin)
+        xn = ops.to_nhwc(torch.randn(B, cin, h, w, device=DEV), torch.bfloat16)
+        dzn = ops.to_nhwc(torch.randn(B, cout, h, w, device=DEV) * 0.1, torch.bfloat16)
+        dw, db = torch.empty(cout, cin, 3, 3, device=DEV), torch.empty(cout, device=DEV)
+        need = lib.bx_conv3x3_wgrad_workspace(B, h, w, cip, cout, L.BX_BF16, L.BX_ALGO_MFMA)
+        ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+        L.check(lib.bx_conv3x3_wgrad(xn.data_ptr(), dzn.data_ptr(), dw.data_ptr(), db.data_ptr(), B, h, w, cin, cip, cout, L.BX_BF16, L.BX_ALGO_MFMA,
+                                     ws.data_ptr(), ws.numel(), 0), "wgrad")
+        data.append((xn, dzn, cin, cip, cout, h, w, need))
+        want.append((dw, db))
+    pend = L.WgradPending()
+    got, bufs = [], []
+    for xn, dzn, cin, cip, cout, h, w, need in data:
+        dw, db = torch.full((cout, cin, 3, 3), float("nan"), device=DEV), torch.full((cout,), float("nan"), device=DEV)
+        ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+        bufs.append(ws)
+        L.check(lib.bx_conv3x3_wgrad_chained(xn.data_ptr(), dzn.data_ptr(), dw.data_ptr(), db.data_ptr(), B, h, w, cin, cip, cout, L.BX_BF16,
+                                             L.BX_ALGO_MFMA, ws.data_ptr(), ws.numel(), ctypes.byref(pend), 0), "wgrad chained")
+        assert pend.valid == 1
+        got.append((dw, db))
+    torch.cuda.synchronize()
+    assert torch.isnan(got[-1][0]).all()                      # the last layer is still pending ...
+    assert not torch.isnan(got[-2][0]).any()                  # ... the one before it was summed inside the last launch
+    L.check(lib.bx_conv3x3_wgrad_finish(ctypes.byref(pend), 0), "finish")
+    assert pend.valid == 0
+    torch.cuda.synchronize()
+    for (dw, db), (rw, rb) in zip(got, want):
+        assert rel_err(dw.cpu(), rw.cpu()) < 1e-6 and rel_err(db.cpu(), rb.cpu()) < 1e-6
+    xn, dzn, cin, cip, cout, h, w, need = data[0]
+    dw, db = torch.empty(cout, cin, 3, 3, device=DEV), torch.empty(cout, device=DEV)
+    L.check(lib.bx_conv3x3_wgrad_chained(xn.data_ptr(), dzn.data_ptr(), dw.data_ptr(), db.data_ptr(), B, h, w, cin, cip, cout, L.BX_BF16,
+                                         L.BX_ALGO_MFMA, bufs[0].data_ptr(), bufs[0].numel(), ctypes.byref(pend), 0), "wgrad chained")
+    rc = lib.bx_conv3x3_wgrad_chained(xn.data_ptr(), dzn.data_ptr(), dw.data_ptr(), db.data_ptr(), B, h, w, cin, cip, cout, L.BX_BF16,
+                                      L.BX_ALGO_MFMA, bufs[0].data_ptr(), bufs[0].numel(), ctypes.byref(pend), 0)
+    assert rc != 0
+    L.check(lib.bx_conv3x3_wgrad_finish(ctypes.byref(pend), 0), "finish")
+    torch.cuda.synchronize()
