@@ -62,6 +62,30 @@ def conv_work(bx, dtype_bytes):
     return out
 
 
+def pmc_conv_traffic(dtype):
+    """HBM bytes per conv3x3-family launch from the newest committed PMC summary (profiles/*_pmc_hbm_traffic.txt written by
+    tools/step_profile.py --pmc: same model, batch and dtype as this benchmark); None when absent or for another dtype."""
+    import glob
+    if dtype != "bf16":
+        return None
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.txt")))
+    for path in reversed(files):
+        tot, launches = 0.0, 0.0
+        for line in open(path):
+            if not line.startswith(("k_conv_mfma", "k_conv3x3", "k_wgrad_mfma", "k_wgrad_reduce")):
+                continue
+            try:
+                wr, fe, n = float(line.split()[-1]), float(line.split()[-2]), float(line.split()[-3])
+            except ValueError:
+                continue
+            tot += n * (fe + wr) * 1e6
+            if not line.startswith("k_wgrad_reduce"):
+                launches += n
+        if launches > 0:
+            return round(tot / launches)
+    return None
+
+
 def main():
     args = parse()
     # stdout carries exactly ONE JSON line: library banners (RCCL prints its version to stdout at init) and any
@@ -229,9 +253,12 @@ def main():
         ach_tf = conv_flops / conv_time / 1e12
         roofline = {"bound": "mfma", "kernel": "conv3x3 fwd+dgrad+wgrad (%d launches/step)" % (n_launch // max(prof_steps, 1)),
                     "achieved": round(ach_tf, 3), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                    "frac": round(ach_tf / MFMA_PEAK_TFLOPS[args.dtype], 5), "traffic": None,
+                    "frac": round(ach_tf / MFMA_PEAK_TFLOPS[args.dtype], 5), "traffic": pmc_conv_traffic(args.dtype),
                     "avg_launch_us": round(conv_time / max(n_launch / prof_steps, 1) * 1e6, 2),
                     "share_of_step": round(conv_time / (elapsed / args.steps), 3)}
+        if roofline["traffic"] is not None:
+            roofline["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, conv3x3 family average; committed summary, not live)"
+            roofline["algorithmic_bytes_per_launch"] = round(conv_bytes / max(n_launch / prof_steps, 1))
         extra["roofline_hbm"] = {"bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(ach_gbs / HBM_PEAK_GBS, 5)}
         extra["conv_ms_per_step"] = {k_: round(sum(v) / prof_steps * 1e3, 3) for k_, v in kinds.items()}
