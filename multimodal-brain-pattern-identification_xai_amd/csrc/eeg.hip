@@ -491,8 +491,8 @@ __global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ d
         float4 a[8], p[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int i = i0 + u * 256;
-          if (i < tot) { a[u] = reinterpret_cast<const float4*>(dsb)[i]; p[u] = reinterpret_cast<const float4*>(p1b)[i]; }
+          const int i = i0 + u * 256, ic = i < tot ? i : 0;      // (clamped, unconditional loads: a conditionally filled array went to scratch memory)
+          a[u] = reinterpret_cast<const float4*>(dsb)[ic]; p[u] = reinterpret_cast<const float4*>(p1b)[ic];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {

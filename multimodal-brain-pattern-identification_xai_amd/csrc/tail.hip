@@ -422,7 +422,7 @@ __device__ __forceinline__ void skip_dxs_body(const T* __restrict__ dout, const 
       for (int i0 = threadIdx.x; i0 < n4; i0 += 256 * 8) {
         float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; if (i < n4) v[u] = src[i]; }
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; v[u] = src[i < n4 ? i : 0]; }   // (conditional fill would put v[] in scratch)
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; if (i < n4) dst[i] = v[u]; }
       }
@@ -628,39 +628,40 @@ __device__ __forceinline__ void skip_dxs_mfma_body(const bf16_t* __restrict__ do
                                                    float* __restrict__ dxs, bf16_t* __restrict__ dx_even, const TailGeom& g, int bid) {
   constexpr int PW = (4 / WN) * PTW * 16;                      // pixels per workgroup
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gq = lane >> 4, li = lane & 15;
-  const int wn = wave % WN, wp = wave / WN;
+  const int wn_ = wave % WN, wp = wave / WN;
   const long long p0 = (long long)bid * PW + wp * PTW * 16;
   tl_f32x4 acc[PTW][NTW];
 #pragma unroll
   for (int pt = 0; pt < PTW; ++pt)
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) acc[pt][nt] = (tl_f32x4){0.f, 0.f, 0.f, 0.f};
-  float wv[2][NTW][8];
-  uint4 bv[2][PTW];
-  auto fetch = [&](int kb, int sel) {
+  // software pipeline with explicit current / next registers (a [2][..] array indexed by a runtime toggle lives in scratch memory)
+  float wv[NTW][8], wn[NTW][8];
+  uint4 bv[PTW], bn[PTW];
+  auto fetch = [&](int kb, float (&w_)[NTW][8], uint4 (&b_)[PTW]) {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-      const int ci = (wn * NTW + nt) * 16 + li;
+      const int ci = (wn_ * NTW + nt) * 16 + li;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) wv[sel][nt][j] = ci < Cin ? w1x1[(size_t)(kb + 8 * gq + j) * Cin + ci] : 0.f;
+      for (int j = 0; j < 8; ++j) w_[nt][j] = ci < Cin ? w1x1[(size_t)(kb + 8 * gq + j) * Cin + ci] : 0.f;
     }
 #pragma unroll
     for (int pt = 0; pt < PTW; ++pt) {
       const long long pix = p0 + pt * 16 + li;
-      bv[sel][pt] = pix < g.npool ? *reinterpret_cast<const uint4*>(dout + (size_t)pix * g.C + kb + 8 * gq) : make_uint4(0, 0, 0, 0);
+      b_[pt] = pix < g.npool ? *reinterpret_cast<const uint4*>(dout + (size_t)pix * g.C + kb + 8 * gq) : make_uint4(0, 0, 0, 0);
     }
   };
-  fetch(0, 0);
-  int sel = 0;
-  for (int kb = 0; kb < g.C; kb += 32, sel ^= 1) {
-    if (kb + 32 < g.C) fetch(kb + 32, sel ^ 1);
+  fetch(0, wv, bv);
+  for (int kb = 0; kb < g.C; kb += 32) {
+    const bool more = kb + 32 < g.C;
+    if (more) fetch(kb + 32, wn, bn);
     tl_bf16x8 ahi[NTW], alo[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
       uint32_t h[4], l[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float a = wv[sel][nt][2 * j], b = wv[sel][nt][2 * j + 1];
+        const float a = wv[nt][2 * j], b = wv[nt][2 * j + 1];
         h[j] = pack2bf(a, b);
         l[j] = pack2bf(a - __uint_as_float(h[j] << 16), b - __uint_as_float(h[j] & 0xffff0000u));
       }
@@ -669,12 +670,20 @@ __device__ __forceinline__ void skip_dxs_mfma_body(const bf16_t* __restrict__ do
     }
 #pragma unroll
     for (int pt = 0; pt < PTW; ++pt) {
-      const tl_bf16x8 bfr = __builtin_bit_cast(tl_bf16x8, bv[sel][pt]);
+      const tl_bf16x8 bfr = __builtin_bit_cast(tl_bf16x8, bv[pt]);
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
         acc[pt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[nt], bfr, acc[pt][nt], 0, 0, 0);
         acc[pt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[nt], bfr, acc[pt][nt], 0, 0, 0);
       }
+    }
+    if (more) {
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[nt][j] = wn[nt][j];
+#pragma unroll
+      for (int pt = 0; pt < PTW; ++pt) bv[pt] = bn[pt];
     }
   }
 #pragma unroll
@@ -688,7 +697,7 @@ __device__ __forceinline__ void skip_dxs_mfma_body(const bf16_t* __restrict__ do
       const size_t foot[4] = {0, (size_t)g.Cin_p, (size_t)g.W * g.Cin_p, (size_t)g.W * g.Cin_p + g.Cin_p};
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
-        const int ci = (wn * NTW + nt) * 16 + 4 * gq;
+        const int ci = (wn_ * NTW + nt) * 16 + 4 * gq;
         const uint2 v = make_uint2(pack2bf(0.25f * acc[pt][nt][0], 0.25f * acc[pt][nt][1]), pack2bf(0.25f * acc[pt][nt][2], 0.25f * acc[pt][nt][3]));
 #pragma unroll
         for (int f = 0; f < 4; ++f) *reinterpret_cast<uint2*>(dx_even + base + foot[f] + ci) = v;
@@ -696,7 +705,7 @@ __device__ __forceinline__ void skip_dxs_mfma_body(const bf16_t* __restrict__ do
     } else {
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
-        const int ci = (wn * NTW + nt) * 16 + 4 * gq;
+        const int ci = (wn_ * NTW + nt) * 16 + 4 * gq;
         *reinterpret_cast<float4*>(dxs + (size_t)pix * g.Cin_p + ci) = make_float4(acc[pt][nt][0], acc[pt][nt][1], acc[pt][nt][2], acc[pt][nt][3]);
       }
     }

@@ -227,6 +227,75 @@ class GraphedTrainStep:
         self.model, self.opt, self.crit, self.ddp = model, optimizer, criterion, ddp
         self.enabled = isinstance(optimizer, FlatAdamW) and optimizer.is_cuda and os.environ.get("BX_GRAPH_LOOPS", "1") != "0"
         self._seen, self._graphs = set(), {}
+        # branch-parallel replay (MultimodalModel only): see _capture_branches
+        self.branches = os.environ.get("BX_BRANCH_GRAPHS", "0") == "1"     # off by default: see _capture_branches
+        self._side = None
+
+    def _capture_branches(self, static_in, static_lab):
+        """The two-branch model as SIX graphs instead of one.  A replayed hipGraph runs its kernels strictly one after the
+        other on this stack, even across forked branches (tools/graph_concurrency_probe.py), but two graph launches on two
+        streams do overlap.  The EEG branch is ~25 small, latency-bound kernels forward and backward that are independent
+        of the spectrogram branch until the fusion head, so the step is cut at the head:
+            main stream:  [zero grads, spectrogram features] -> [head fwd, loss, head bwd] -> [spectrogram bwd] -> [AdamW]
+            side stream:  [EEG features]                  ->            (join)           -> [EEG bwd]        -> (join)
+        Autograd is cut at the two feature tensors (detached leaves feed the head; their .grad seeds the branch backward
+        passes).  Every graph has its own memory pool: graphs that replay concurrently must not share one."""
+        m = self.model
+        em, sm = m.eeg_model, m.spectrogram_model
+        eeg_in, spec_in = static_in
+        cur = torch.cuda.current_stream()
+        s_main, s_side = torch.cuda.Stream(), torch.cuda.Stream()
+        s_main.wait_stream(cur); s_side.wait_stream(cur)
+        g = [torch.cuda.CUDAGraph() for _ in range(6)]
+        with torch.cuda.graph(g[0], stream=s_main):
+            self.opt.zero_grad()
+            sf = sm.features(spec_in)
+        with torch.cuda.graph(g[1], stream=s_side):
+            ef = em.features(eeg_in)
+        with torch.cuda.graph(g[2], stream=s_main):
+            sf_leaf, ef_leaf = sf.detach().requires_grad_(True), ef.detach().requires_grad_(True)
+            out = ops.MultimodalHeadFn.apply(sf_leaf.permute(0, 2, 3, 1), ef_leaf, sm.fc.weight, sm.fc.bias, em.dense.weight, em.dense.bias,
+                                             m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+            loss = self.crit(out, static_lab)
+            loss.backward()
+            d_sf, d_ef = sf_leaf.grad, ef_leaf.grad
+        with torch.cuda.graph(g[3], stream=s_main):
+            torch.autograd.backward([sf], [d_sf])
+        with torch.cuda.graph(g[4], stream=s_side):
+            torch.autograd.backward([ef], [d_ef])
+        with torch.cuda.graph(g[5], stream=s_main):
+            if self.ddp is None:
+                self.opt.step()
+            else:
+                self.opt.gather_grads()
+        cur.wait_stream(s_main); cur.wait_stream(s_side)
+        self._side = s_side
+        ev = [torch.cuda.Event() for _ in range(4)]
+        return ("branches", g, ev, static_in, static_lab, loss.detach(), out.detach(), (sf, ef, sf_leaf, ef_leaf, d_sf, d_ef))
+
+    def _replay_branches(self, entry):
+        _, g, ev, _, _, loss, out, _ = entry
+        cur, side = torch.cuda.current_stream(), self._side
+        ev[0].record(cur)                               # inputs copied, previous step's optimizer update done
+        side.wait_event(ev[0])
+        with torch.cuda.stream(side):
+            g[1].replay()
+            ev[1].record(side)
+        g[0].replay()
+        cur.wait_event(ev[1])
+        g[2].replay()
+        ev[2].record(cur)
+        side.wait_event(ev[2])
+        with torch.cuda.stream(side):
+            g[4].replay()
+            ev[3].record(side)
+        g[3].replay()
+        cur.wait_event(ev[3])
+        g[5].replay()
+        if self.ddp is not None:
+            self.ddp.sync_gradients(self.opt)
+            self.opt.step(gathered=True)
+        return loss, out
 
     def _eager(self, inputs, labels):
         self.opt.zero_grad()
@@ -251,6 +320,19 @@ class GraphedTrainStep:
                 return self._eager(inputs, labels)
             static_in = [t.detach().clone() for t in inputs]
             static_lab = labels.detach().clone()
+            entry = None
+            if self.branches and type(self.model).__name__ == "MultimodalModel" and len(inputs) == 2 and self.model._fusable():
+                try:
+                    torch.cuda.synchronize()
+                    entry = self._capture_branches(static_in, static_lab)
+                except Exception as exc:              # noqa: BLE001
+                    print(f"[brainxai] branch-parallel capture failed ({type(exc).__name__}: {exc}); capturing one graph instead")
+                    self.branches, entry = False, None
+                    torch.cuda.synchronize()
+                    self.opt.zero_grad()
+            if entry is not None:
+                self._graphs[key] = entry
+                return self._replay_entry(entry, inputs, labels)
             try:
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
@@ -268,10 +350,18 @@ class GraphedTrainStep:
                 torch.cuda.synchronize()
                 return self._eager(inputs, labels)
             self._graphs[key] = entry
-        graph, static_in, static_lab, loss, out = entry
+        return self._replay_entry(entry, inputs, labels)
+
+    def _replay_entry(self, entry, inputs, labels):
+        static_in, static_lab = (entry[3], entry[4]) if entry[0] == "branches" else (entry[1], entry[2])
         for dst, src in zip(static_in, inputs):
-            dst.copy_(src, non_blocking=True)
-        static_lab.copy_(labels, non_blocking=True)
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        if static_lab.data_ptr() != labels.data_ptr():
+            static_lab.copy_(labels, non_blocking=True)
+        if entry[0] == "branches":
+            return self._replay_branches(entry)
+        graph, _, _, loss, out = entry
         graph.replay()
         if self.ddp is not None:
             self.ddp.sync_gradients(self.opt)

@@ -546,8 +546,10 @@ def test_gradcam_sweep_matches_eager():
         sweep(eeg[:2], spec[:2])
 
 
-def test_graphed_train_step_matches_eager():
-    """GraphedTrainStep (eager first batch, capture on the second, replay afterwards) walks the same trajectory as eager steps"""
+@pytest.mark.parametrize("branches", [False, True])
+def test_graphed_train_step_matches_eager(branches):
+    """GraphedTrainStep (eager first batch, capture on the second, replay afterwards) walks the same trajectory as eager steps,
+    as one hipGraph and as the six-graph branch-parallel form (EEG branch on a side stream beside the spectrogram branch)"""
     def make():
         torch.manual_seed(9)
         m = brainxai.build_multimodal(19, 2000, 4, dropout=0.5).to(DEV).train()
@@ -564,9 +566,12 @@ def test_graphed_train_step_matches_eager():
         ops.clear_grad_views()
         m2, o2 = make(); ops.manual_seed(1234)
         step = brainxai.GraphedTrainStep(m2, o2, crit)
+        step.branches = branches
         graphed = [float(step([e, s], y)[0]) for (e, s), y in batches]
+        torch.cuda.synchronize()
         p2 = torch.cat([p.detach().flatten() for p in m2.parameters()])
         assert step.enabled and len(step._graphs) == 1
+        assert (next(iter(step._graphs.values()))[0] == "branches") == branches
         np.testing.assert_allclose(graphed, eager, rtol=1e-5)
         assert float((p1 - p2).abs().max()) < 1e-6
     finally:

@@ -41,3 +41,38 @@ with torch.cuda.graph(g2):
     cur.wait_stream(side)
 print(f"serial graph  : {timed(g1):.3f} ms for {2 * N} kernels")
 print(f"forked graph  : {timed(g2):.3f} ms for {2 * N} kernels")
+
+# (c) two separate graphs replayed on two streams: do different graph launches overlap?
+ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+with torch.cuda.graph(ga):
+    chain(a)
+with torch.cuda.graph(gb):
+    chain(b)
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+
+def two():
+    with torch.cuda.stream(s1):
+        ga.replay()
+    with torch.cuda.stream(s2):
+        gb.replay()
+
+
+two(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    two()
+torch.cuda.synchronize()
+print(f"two graphs on two streams: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms for {2 * N} kernels")
+# (d) eager on two streams
+def eager_two():
+    with torch.cuda.stream(s1):
+        chain(a)
+    with torch.cuda.stream(s2):
+        chain(b)
+eager_two(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(5):
+    eager_two()
+torch.cuda.synchronize()
+print(f"eager on two streams     : {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms for {2 * N} kernels (host-bound)")
