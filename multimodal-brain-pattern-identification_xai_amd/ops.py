@@ -103,11 +103,16 @@ def _stream():
 _WS = {}
 
 
+_WS_RETIRED = []
+
+
 def workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only scratch buffer per (device, stream): all uses of one buffer are ordered on its stream."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _WS_RETIRED.append(buf)       # a captured hipGraph may still point at the smaller buffer: keep it mapped
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf
@@ -284,7 +289,7 @@ def _wg_chain_state(device):
     key = device.index if device.index is not None else torch.cuda.current_device()
     st = _WG_CHAIN.get(key)
     if st is None:
-        st = SimpleNamespace(pend=L.WgradPending(), ring=[None, None], slot=0, keep=None, stream=None)
+        st = SimpleNamespace(pend=L.WgradPending(), ring=[None, None], slot=0, keep=None, stream=None, retired=[])
         _WG_CHAIN[key] = st
     return st
 
@@ -314,7 +319,13 @@ def _wgrad(x, dz, w: torch.Tensor, b: torch.Tensor, chain: bool = False):
             wgrad_flush(x.device)                           # never carry a pending reduce across streams
         buf = st.ring[st.slot]
         if buf is None or buf.numel() < need:
-            buf = torch.empty(max(int(need), 1 << 20), dtype=torch.uint8, device=x.device)
+            if buf is not None:
+                # never free a partial buffer: kernels of an already captured hipGraph may point at it (an eager-era buffer
+                # dropped while a later step was being captured was returned to the driver by the next capture's
+                # empty_cache() -> memory access fault on replay)
+                st.retired.append(buf)
+            big = max([int(need), 1 << 20] + [b.numel() for b in st.ring if b is not None])
+            buf = torch.empty(big, dtype=torch.uint8, device=x.device)
             st.ring[st.slot] = buf
         st.stream = _stream()
         with _Timed("wgrad"):

@@ -546,16 +546,17 @@ def test_gradcam_sweep_matches_eager():
         sweep(eeg[:2], spec[:2])
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("branches", [False, True])
-def test_graphed_train_step_matches_eager(branches):
+def test_graphed_train_step_matches_eager(branches, dt):
     """GraphedTrainStep (eager first batch, capture on the second, replay afterwards) walks the same trajectory as eager steps,
     as one hipGraph and as the six-graph branch-parallel form (EEG branch on a side stream beside the spectrogram branch)"""
     def make():
         torch.manual_seed(9)
-        m = brainxai.build_multimodal(19, 2000, 4, dropout=0.5).to(DEV).train()
+        m = brainxai.build_multimodal(19, 2000, 4, dropout=0.5, compute_dtype=dt).to(DEV).train()
         return m, brainxai.FlatAdamW(m.parameters(), lr=1e-3)
     batches = [((O.seeded((4, 1, 19, 2000), 90 + i, "randn").to(DEV), O.seeded((4, 4, 32, 64), 95 + i, "rand").to(DEV)),
-                torch.softmax(O.seeded((4, 6), 99 + i, "randn"), 1).to(DEV)) for i in range(5)]
+                torch.softmax(O.seeded((4, 6), 99 + i, "randn"), 1).to(DEV)) for i in range(7)]
     crit = brainxai.KLDivLoss()
     try:
         m1, o1 = make(); ops.manual_seed(1234)
