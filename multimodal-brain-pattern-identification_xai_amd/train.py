@@ -276,6 +276,12 @@ class GraphedTrainStep:
     def _replay_branches(self, entry):
         _, g, ev, _, _, loss, out, _ = entry
         cur, side = torch.cuda.current_stream(), self._side
+        if os.environ.get("BX_BRANCH_SYNC") == "1":         # debugging aid: the same six graphs with device-wide syncs between stages
+            for k in (1, 0, 2, 4, 3, 5):
+                with torch.cuda.stream(side if k in (1, 4) else cur):
+                    g[k].replay()
+                torch.cuda.synchronize()
+            return loss, out
         ev[0].record(cur)                               # inputs copied, previous step's optimizer update done
         side.wait_event(ev[0])
         with torch.cuda.stream(side):

@@ -8,7 +8,7 @@ import brainxai
 from brainxai import ops
 
 dev = torch.device("cuda", 0)
-B, STEPS = 64, 8
+B, STEPS = int(os.environ.get("TC_B", "64")), 8
 g = torch.Generator().manual_seed(1)
 batches = [((torch.randn(B, 1, 19, 2000, generator=g).to(dev), torch.rand(B, 4, 128, 256, generator=g).to(dev)),
             torch.softmax(torch.randn(B, 6, generator=g), 1).to(dev)) for _ in range(STEPS)]
@@ -16,7 +16,7 @@ crit = brainxai.KLDivLoss()
 res = {}
 for mode in ("eager", "graph", "branches"):
     torch.manual_seed(9)
-    m = brainxai.build_multimodal(19, 2000, 4, dropout=0.5, compute_dtype=torch.bfloat16).to(dev).train()
+    m = brainxai.build_multimodal(19, 2000, 4, dropout=float(os.environ.get("TC_DROPOUT", "0.5")), compute_dtype=torch.bfloat16).to(dev).train()
     opt = brainxai.FlatAdamW(m.parameters(), lr=1e-3)
     ops.manual_seed(1234)
     step = brainxai.GraphedTrainStep(m, opt, crit)
