@@ -137,7 +137,12 @@ __global__ __launch_bounds__(256) void k_eeg_conv1_wgrad_mfma(const bf16_t* __re
   const int TXB = ((g.T + 31) / 32) * 32 + 8;
   bf16_t* xs = lds_em;                          // [2][NP]
   bf16_t* sdc = lds_em + (size_t)2 * g.NP;      // [4][TXB]
-  const int row = blockIdx.x, b = row / g.Ch, ch = row % g.Ch;
+  // Workgroups are dealt to the 8 XCDs round-robin by id; the 19 electrode rows of a sample all read that sample's gradient
+  // rows dd[b] (16 x T fp32), so consecutive rows must land on ONE XCD's L2 instead of eight (PMC: 116 MB fetched per launch
+  // for 57 MB of operands).  XCD k = id % 8 takes the contiguous row range [start_k, start_k + count_k).
+  const int nrows = (int)gridDim.x, xq = nrows >> 3, xr = nrows & 7;
+  const int xk = (int)blockIdx.x & 7, xj = (int)blockIdx.x >> 3;
+  const int row = xk * xq + (xk < xr ? xk : xr) + xj, b = row / g.Ch, ch = row % g.Ch;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gq = lane >> 4, li = lane & 15;
   const int Tn = g.T, T4 = Tn & ~3;
   for (int i = threadIdx.x; i < 4 * (TXB - T4); i += 256)          // the last K-step reads up to TXB - 8: keep the tails zero

@@ -145,7 +145,8 @@ __device__ __forceinline__ void skip_sample(const T* __restrict__ x, const TailG
 }
 
 // forward 3: out = dropout(pooled*scale + shift) + b1x1 + W1x1 . bilinear(x)
-template <typename T>
+template <typename T, int RPT>      // RPT = weight rows per trip of the 1x1 loop (2 RPT loads in flight).  16 was no faster for the late stages:
+                                    // there the 256 one-per-CU workgroups all pull the same 128 KB of weights through L2 (32 MB per launch)
 __global__ __launch_bounds__(256) void k_tail_apply(const T* __restrict__ pooled, const T* __restrict__ x, const float* __restrict__ wT,
     int Cin, const float* __restrict__ b1x1, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, T* __restrict__ out, TailGeom g,
@@ -201,16 +202,16 @@ __global__ __launch_bounds__(256) void k_tail_apply(const T* __restrict__ pooled
       if (dropout_p > 0.f) v *= bx_dropout_scale(sd, salt, (uint64_t)pp * g.C + cg * 8 + j, dropout_p, inv_keep);
       acc[j] = v + bb[j];
     }
-    // wT has Cin_p rows (zero beyond Cin) and Cin_p % 8 == 0: eight rows (16 loads) in flight per trip
-    for (int c0 = 0; c0 < g.Cin_p; c0 += 8) {
-      float4 wa[8], wb[8];
+    // wT has Cin_p rows (zero beyond Cin) and Cin_p % RPT == 0: RPT rows (2 RPT loads) in flight per trip
+    for (int c0 = 0; c0 < g.Cin_p; c0 += RPT) {
+      float4 wa[RPT], wb[RPT];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < RPT; ++u) {
         wa[u] = *reinterpret_cast<const float4*>(wT + (size_t)(c0 + u) * g.C + cg * 8);
         wb[u] = *reinterpret_cast<const float4*>(wT + (size_t)(c0 + u) * g.C + cg * 8 + 4);
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < RPT; ++u) {
         const float xv = xs[slot * xstride + c0 + u];
         acc[0] = fmaf(wa[u].x, xv, acc[0]); acc[1] = fmaf(wa[u].y, xv, acc[1]); acc[2] = fmaf(wa[u].z, xv, acc[2]); acc[3] = fmaf(wa[u].w, xv, acc[3]);
         acc[4] = fmaf(wb[u].x, xv, acc[4]); acc[5] = fmaf(wb[u].y, xv, acc[5]); acc[6] = fmaf(wb[u].z, xv, acc[6]); acc[7] = fmaf(wb[u].w, xv, acc[7]);
@@ -267,7 +268,7 @@ extern "C" int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void
   }
   const bool ev = !d->training;
   BX_DISPATCH_DTYPE(d->dtype, T,
-    hipLaunchKernelGGL((k_tail_apply<T>), dim3(tail_blocks_all(g)), dim3(256), xs_bytes, s, (const T*)pooled, (const T*)x, wT, Cin, b1x1,
+    hipLaunchKernelGGL((k_tail_apply<T, 8>), dim3(tail_blocks_all(g)), dim3(256), xs_bytes, s, (const T*)pooled, (const T*)x, wT, Cin, b1x1,
                        scale, shift, seed, p, d->salt, (T*)out, g, ev ? bn_weight : (const float*)nullptr, bn_bias, (const float*)running_mean,
                        (const float*)running_var, d->eps, save_mean, save_invstd));
   BX_CHECK_LAUNCH("bx_block_tail_fwd(apply)");
@@ -820,7 +821,7 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
     // up to ~4096 workgroups in total; partial buffer = nchunk * C * Cin_p floats <= 2048*256 + 64*C*Cin_p (workspace formula)
     const int otiles = wg_y * wg_z;
     nchunk = (int)((g.npool + 63) / 64);
-    int cap = 4096 / otiles;
+    int cap = otiles == 1 ? 1024 : 4096 / otiles;            // one output tile (first stage): 1024 chunks, the partial sum walks them all
     if (cap < 64) cap = 64;
     while ((size_t)cap * g.C * g.Cin_p > (size_t)2048 * 256 + (size_t)64 * g.C * g.Cin_p) cap /= 2;
     if (nchunk > cap) nchunk = cap;
