@@ -383,24 +383,30 @@ __global__ __launch_bounds__(256) void k_mm_head_fwd(const T* __restrict__ feat,
   float wq[FAST ? 3 : 1][FAST ? 16 : 1], bq[FAST ? 3 : 1], w1r[FAST ? 12 : 1], b1r = 0.f, w2r[FAST ? 2 : 1][FAST ? 4 : 1], b2r[FAST ? 2 : 1];
   if (FAST) {
 #pragma unroll
+    // (clamped indices + selects, never `cond ? p[i] : 0`: each conditional load became an exec-mask branch, ~75 of them in a row)
     for (int r = 0; r < 3; ++r) {
       const int q = wave + 4 * r;
-      const bool live = q < 2 * N, eeg = q < N;
-      const int n = eeg ? q : q - N, len = eeg ? K : C;
+      const bool live = q < 2 * N, eeg = q < N || !live;
+      const int n = !live ? 0 : eeg ? q : q - N, len = eeg ? K : C;
       const float* row = eeg ? dw_ + (size_t)n * K : fcw + (size_t)n * C;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) { const int i = lane + 64 * u; wq[r][u] = (live && i < len) ? row[i] : 0.f; }
-      bq[r] = live ? (eeg ? db_[n] : fcb[n]) : 0.f;
+      for (int u = 0; u < 16; ++u) {
+        const int i = lane + 64 * u;
+        const float v = row[i < len ? i : 0];
+        wq[r][u] = i < len ? v : 0.f;                            // rows q >= 2N load row 0 and are never used (a `live &&` here
+      }                                                           // turned every load into a branch with its own s_waitcnt)
+      bq[r] = eeg ? db_[n] : fcb[n];
     }
+    const int jt = tid < Hd ? tid : 0;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) w1r[i] = (tid < Hd && i < 2 * N) ? w1[(size_t)tid * 2 * N + i] : 0.f;
-    b1r = tid < Hd ? b1[tid] : 0.f;
+    for (int i = 0; i < 12; ++i) w1r[i] = w1[(size_t)jt * 2 * N + (i < 2 * N ? i : 0)];     // entries i >= 2N are never used
+    b1r = b1[jt];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const int n = wave + 4 * r;
+      const int n = wave + 4 * r, nc = n < N ? n : 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int j = lane + 64 * u; w2r[r][u] = (n < N && j < Hd) ? w2[(size_t)n * Hd + j] : 0.f; }
-      b2r[r] = n < N ? b2[n] : 0.f;
+      for (int u = 0; u < 4; ++u) { const int j = lane + 64 * u; const float v = w2[(size_t)nc * Hd + (j < Hd ? j : 0)]; w2r[r][u] = j < Hd ? v : 0.f; }
+      b2r[r] = b2[nc];
     }
   }
   for (int c = tid; c < C; c += 256) {
@@ -409,9 +415,9 @@ __global__ __launch_bounds__(256) void k_mm_head_fwd(const T* __restrict__ feat,
     for (int p0 = 0; p0 < HW; p0 += 16) {
       float v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = p0 + u < HW ? ldf(fp, (size_t)(p0 + u) * C) : 0.f;
+      for (int u = 0; u < 16; ++u) v[u] = ldf(fp, (size_t)(p0 + u < HW ? p0 + u : 0) * C);
 #pragma unroll
-      for (int u = 0; u < 16; ++u) s += v[u];
+      for (int u = 0; u < 16; ++u) s += p0 + u < HW ? v[u] : 0.f;
     }
     s *= inv_hw;
     gs[c] = s;
@@ -504,13 +510,14 @@ __global__ __launch_bounds__(256) void k_mm_head_bwd_in(const float* __restrict_
   float w2c[PN], hid = 0.f, fcc[PN], dwc[PK][PN];
   if (pre) {
 #pragma unroll
-    for (int n = 0; n < PN; ++n) {
-      w2c[n] = (n < N && tid < Hd) ? w2[(size_t)n * Hd + tid] : 0.f;
-      fcc[n] = (n < N && tid < C) ? fcw[(size_t)n * C + tid] : 0.f;
+    for (int n = 0; n < PN; ++n) {                              // clamped indices + selects: no branch per load
+      const int nc = n < N ? n : 0;
+      w2c[n] = w2[(size_t)nc * Hd + (tid < Hd ? tid : 0)];     // entries n >= N / threads beyond the row are never used
+      fcc[n] = fcw[(size_t)nc * C + (tid < C ? tid : 0)];
 #pragma unroll
-      for (int u = 0; u < PK; ++u) { const int k = tid + 256 * u; dwc[u][n] = (n < N && k < K) ? dw_[(size_t)n * K + k] : 0.f; }
+      for (int u = 0; u < PK; ++u) { const int k = tid + 256 * u; dwc[u][n] = dw_[(size_t)nc * K + (k < K ? k : 0)]; }
     }
-    hid = tid < Hd ? hidden[(size_t)b * Hd + tid] : 0.f;
+    hid = hidden[(size_t)b * Hd + (tid < Hd ? tid : 0)];
   }
   lds_fill<8>(w1s, Hd * 2 * N, [&](int i) { return w1[i]; });
   if (tid == 0) {
