@@ -93,6 +93,17 @@ __device__ __forceinline__ float bx_dropout_scale(uint64_t seed, uint32_t salt, 
   return u >= p ? inv_keep : 0.0f;
 }
 
+// ---- guarded loads through a raw buffer resource -----------------------------------------------------------------------
+// `ok ? p[i] : 0.f` compiles to an exec-mask branch around the load, usually with its own s_waitcnt: a batch of such loads
+// becomes a chain of serial memory round trips (tools/isa_wait_audit.py).  A raw buffer load whose offset is past the end of
+// the resource returns zero instead, needs no branch and pipelines like any other load.  The resource covers `bytes` (< 4 GiB).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bx_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float bx_ldf_or0(__amdgpu_buffer_rsrc_t r, int elem, bool ok) {     // fp32 element `elem`, or 0 when !ok
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, ok ? (uint32_t)elem * 4u : 0x80000000u, 0, 0));
+}
+
 // ---- wave / block reductions (wave = 64 lanes) ----------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -114,7 +125,8 @@ __device__ __forceinline__ void lds_fill(float* dst, int n, LoadF load) {
   for (int i0 = (int)threadIdx.x; i0 < n; i0 += step * U) {
     float v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const int i = i0 + u * step; v[u] = i < n ? load(i) : 0.f; }
+    for (int u = 0; u < U; ++u) { const int i = i0 + u * step; v[u] = load(i < n ? i : n - 1); }   // clamped, unconditional: `i < n ? load(i) : 0`
+                                                                                                  // compiles to a branch (and often a full wait) per load
 #pragma unroll
     for (int u = 0; u < U; ++u) { const int i = i0 + u * step; if (i < n) dst[i] = v[u]; }
   }

@@ -221,6 +221,12 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   for (int n = 0; n < NC; ++n)
     bz[n] = bias ? *reinterpret_cast<const float4*>(bias + co_base + n * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
   const uint32_t lane_off = (uint32_t)((((b * H + y0) * W + x0 + li) * Co + co_base + 4 * g) * 2);
+  // Epilogue operands (ReLU mask of the data gradient, residual addend): ALL of a thread's loads are issued before the first
+  // one is consumed.  Loaded inside the store loop each of the MP*NC iterations was its own memory round trip (the ISA had
+  // one full `s_waitcnt vmcnt(0)` per load: 32 serial trips in the <64,4,32> data-gradient launches).  The main loop's
+  // fragment registers are dead here, so the batch does not raise the kernel's register peak.
+  uint32_t offs[MP][NC];
+  u32x2 mk[MP][NC], ad[MP][NC];
 #pragma unroll
   for (int i = 0; i < MP; ++i) {
     const int t = wave * MP + i;
@@ -228,27 +234,43 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
     const bool inb = oy < H && ox < W;
     const uint32_t orow = lane_off + (uint32_t)((((t / TPR) * W + (t % TPR) * 16) * Co) * 2);
 #pragma unroll
+    for (int n = 0; n < NC; ++n) offs[i][n] = inb ? orow + (uint32_t)(n * 32) : 0x80000000u;
+  }
+  if (mask_src) {
+#pragma unroll
+    for (int i = 0; i < MP; ++i)
+#pragma unroll
+      for (int n = 0; n < NC; ++n) mk[i][n] = __builtin_amdgcn_raw_buffer_load_b64(mres, offs[i][n], 0, 0);
+  }
+  if (addend) {
+#pragma unroll
+    for (int i = 0; i < MP; ++i)
+#pragma unroll
+      for (int n = 0; n < NC; ++n) ad[i][n] = __builtin_amdgcn_raw_buffer_load_b64(ares, offs[i][n], 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < MP; ++i) {
+#pragma unroll
     for (int n = 0; n < NC; ++n) {
-      const uint32_t off = inb ? orow + (uint32_t)(n * 32) : 0x80000000u;
       float v[4] = {acc[i][n][0] + bz[n].x, acc[i][n][1] + bz[n].y, acc[i][n][2] + bz[n].z, acc[i][n][3] + bz[n].w};
       if (relu) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
       if (mask_src) {
-        const u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(mres, off, 0, 0);
+        const u32x2 m = mk[i][n];
         // bf16 > 0  <=>  sign bit clear and magnitude non-zero
         const uint32_t mm[4] = {m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16};
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (mm[r] != 0u && mm[r] < 0x8000u) ? v[r] : 0.f;
       }
       if (addend) {
-        const u32x2 a2 = __builtin_amdgcn_raw_buffer_load_b64(ares, off, 0, 0);
+        const u32x2 a2 = ad[i][n];
         v[0] += __uint_as_float(a2.x << 16); v[1] += __uint_as_float(a2.x & 0xffff0000u);
         v[2] += __uint_as_float(a2.y << 16); v[3] += __uint_as_float(a2.y & 0xffff0000u);
       }
       const u32x2 out = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-      __builtin_amdgcn_raw_buffer_store_b64(out, yres, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(out, yres, offs[i][n], 0, 0);
     }
   }
 }
@@ -353,6 +375,9 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
       }
     }
     const uint32_t tile_o = (uint32_t)((((b * H + y0) * W + x0) * Co) * 2) + lane_rel;
+    // epilogue operands: all loads of the tile before the first use (see k_conv_mfma)
+    uint32_t offs[MP][NC];
+    u32x2 mk[MP][NC], ad[MP][NC];
 #pragma unroll
     for (int i = 0; i < MP; ++i) {
       const int t = wave * MP + i;
@@ -360,26 +385,42 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
       const bool inb = oy < H && ox < W;
       const uint32_t orow = tile_o + (uint32_t)((((t / TPR) * W + (t % TPR) * 16) * Co) * 2);
 #pragma unroll
+      for (int n = 0; n < NC; ++n) offs[i][n] = inb ? orow + (uint32_t)(n * 32) : 0x80000000u;
+    }
+    if (mask_src) {
+#pragma unroll
+      for (int i = 0; i < MP; ++i)
+#pragma unroll
+        for (int n = 0; n < NC; ++n) mk[i][n] = __builtin_amdgcn_raw_buffer_load_b64(mres, offs[i][n], 0, 0);
+    }
+    if (addend) {
+#pragma unroll
+      for (int i = 0; i < MP; ++i)
+#pragma unroll
+        for (int n = 0; n < NC; ++n) ad[i][n] = __builtin_amdgcn_raw_buffer_load_b64(ares, offs[i][n], 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < MP; ++i) {
+#pragma unroll
       for (int n = 0; n < NC; ++n) {
-        const uint32_t off = inb ? orow + (uint32_t)(n * 32) : 0x80000000u;
         float v[4] = {acc[i][n][0] + bz[n].x, acc[i][n][1] + bz[n].y, acc[i][n][2] + bz[n].z, acc[i][n][3] + bz[n].w};
         if (relu) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
         if (mask_src) {
-          const u32x2 mk = __builtin_amdgcn_raw_buffer_load_b64(mres, off, 0, 0);
-          const uint32_t mm[4] = {mk.x & 0xffffu, mk.x >> 16, mk.y & 0xffffu, mk.y >> 16};
+          const u32x2 m = mk[i][n];
+          const uint32_t mm[4] = {m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16};
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = (mm[r] != 0u && mm[r] < 0x8000u) ? v[r] : 0.f;
         }
         if (addend) {
-          const u32x2 a2 = __builtin_amdgcn_raw_buffer_load_b64(ares, off, 0, 0);
+          const u32x2 a2 = ad[i][n];
           v[0] += __uint_as_float(a2.x << 16); v[1] += __uint_as_float(a2.x & 0xffff0000u);
           v[2] += __uint_as_float(a2.y << 16); v[3] += __uint_as_float(a2.y & 0xffff0000u);
         }
         const u32x2 out = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        __builtin_amdgcn_raw_buffer_store_b64(out, yres, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(out, yres, offs[i][n], 0, 0);
       }
     }
   }

@@ -29,12 +29,13 @@ __host__ __device__ __forceinline__ int em_np(int T) {      // samples per copy:
 
 // builds the two bf16 copies of one row in LDS: copy0[i] = xpad[i], copy1[i] = xpad[i + 1]  (copy c at xs + c*NP)
 __device__ __forceinline__ void em_build_copies(const float* __restrict__ xrow, bf16_t* xs, int T, int NP) {
+  const __amdgpu_buffer_rsrc_t xres = bx_rsrc(xrow, (uint32_t)T * 4u);
   for (int m0 = threadIdx.x; m0 < NP / 8; m0 += 256) {
     float v[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
       const int t = m0 * 8 + j - EM_OFF;
-      v[j] = (t >= 0 && t < T) ? xrow[t] : 0.f;
+      v[j] = bx_ldf_or0(xres, t, t >= 0 && t < T);          // zero padding without a branch per load
     }
     uint32_t w0[4], w1[4];
 #pragma unroll
@@ -67,11 +68,12 @@ __global__ __launch_bounds__(256) void k_eeg_conv1_mfma(const float* __restrict_
   const int row = blockIdx.x, b = row / g.Ch, ch = row % g.Ch;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gq = lane >> 4, li = lane & 15;
   // B fragments: W[f = li][32 s + 8 gq + j] (k = 8 gq + j, column f), columns 8..15 are zero
+  const __amdgpu_buffer_rsrc_t wres = bx_rsrc(w1, 8u * EM_K * 4u);
   bf16x8 wfr[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wfr[s][j] = li < 8 ? (short)f2bf(w1[li * EM_K + 32 * s + 8 * gq + j]) : (short)0;
+    for (int j = 0; j < 8; ++j) wfr[s][j] = (short)f2bf(bx_ldf_or0(wres, li * EM_K + 32 * s + 8 * gq + j, li < 8));
   em_build_copies(x + (size_t)row * g.T, xs, g.T, g.NP);
   float sa = 0.f, qa = 0.f;
   const int ntile = (g.T + 15) / 16;
