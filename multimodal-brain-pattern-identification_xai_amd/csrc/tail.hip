@@ -129,6 +129,23 @@ __global__ __launch_bounds__(256) void k_pool_stats(const T* __restrict__ y3, T*
   }
 }
 
+// 8 consecutive elements held in their storage form (a load issued early costs 4 registers for bf16, not 8)
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  uint4 r;
+  __device__ __forceinline__ void load(const bf16_t* p, size_t i) { r = *reinterpret_cast<const uint4*>(p + i); }
+  __device__ __forceinline__ void get(float v[8]) const {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+  }
+};
+template <> struct Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p, size_t i) { a = *reinterpret_cast<const float4*>(p + i); b = *reinterpret_cast<const float4*>(p + i + 4); }
+  __device__ __forceinline__ void get(float v[8]) const { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; }
+};
+
 // bilinear sample of the block input at pooled pixel (oy, ox): 8 channels starting at c0
 template <typename T>
 __device__ __forceinline__ void skip_sample(const T* __restrict__ x, const TailGeom& g, int b, int oy, int ox, int c0, float out[8]) {
@@ -147,7 +164,7 @@ __device__ __forceinline__ void skip_sample(const T* __restrict__ x, const TailG
 // forward 3: out = dropout(pooled*scale + shift) + b1x1 + W1x1 . bilinear(x)
 template <typename T, int RPT>      // RPT = weight rows per trip of the 1x1 loop (2 RPT loads in flight).  16 was no faster for the late stages:
                                     // there the 256 one-per-CU workgroups all pull the same 128 KB of weights through L2 (32 MB per launch)
-__global__ __launch_bounds__(256) void k_tail_apply(const T* __restrict__ pooled, const T* __restrict__ x, const float* __restrict__ wT,
+__global__ __launch_bounds__(256, 4) void k_tail_apply(const T* __restrict__ pooled, const T* __restrict__ x, const float* __restrict__ wT,
     int Cin, const float* __restrict__ b1x1, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, T* __restrict__ out, TailGeom g,
     const float* __restrict__ ev_gamma, const float* __restrict__ ev_beta, const float* __restrict__ ev_rmean,
@@ -178,6 +195,12 @@ __global__ __launch_bounds__(256) void k_tail_apply(const T* __restrict__ pooled
   const long long nsteps = (g.npool + (long long)gridDim.x * g.slots - 1) / ((long long)gridDim.x * g.slots);
   for (long long st = 0; st < nsteps; ++st) {
     const long long p0 = (st * gridDim.x + blockIdx.x) * g.slots;
+    // this thread's pooled values do not depend on the staged skip input: request them before the staging round trip
+    Raw8<T> pvr;                                             // kept packed (4 registers for bf16) until it is used
+    {
+      const long long ppq = p0 + slot;
+      pvr.load(pooled, (size_t)(ppq < g.npool ? ppq : 0) * g.C + cg * 8);
+    }
     __syncthreads();
     for (int u = threadIdx.x; u < g.slots * nci8; u += 256) {
       const int sl = u / nci8, c8 = u % nci8;
@@ -195,7 +218,7 @@ __global__ __launch_bounds__(256) void k_tail_apply(const T* __restrict__ pooled
     const long long pp = p0 + slot;
     if (pp >= g.npool) continue;
     float pv[8], acc[8];
-    ld8(pooled, (size_t)pp * g.C + cg * 8, pv);
+    pvr.get(pv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = pv[j] * sc[j] + sh[j];
