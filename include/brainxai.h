@@ -248,6 +248,17 @@ int bx_eeg_deep_bwd(const bxEegDeepDesc* d, const bxEegDeepParams* p, const floa
                     const float* attn, const uint64_t* seed, const void* saved, const bxEegDeepGrads* g, float* dfeat,
                     void* workspace, size_t workspace_bytes, bxStream stream);
 
+/* Stand-alone Attention module (M:109-134): x fp32 [B,L,D] -> out [B,L,D], attn [B,L,L] (softmax weights); D = 32, L <= 32.
+ * qkv_saved fp32 [B,3,L,D] is written by fwd and read by bwd.  bwd: dattn (gradient w.r.t. the returned weights) and dx may
+ * be NULL; parameter gradients are written when non-NULL (then workspace >= bx_attention_workspace(B) bytes). */
+size_t bx_attention_workspace(int B);
+int bx_attention_fwd(const float* x, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,
+                     const float* bv, float* out, float* attn, float* qkv_saved, int B, int L, int D, bxStream stream);
+int bx_attention_bwd(const float* dout, const float* dattn, const float* x, const float* attn, const float* qkv_saved,
+                     const float* wq, const float* wk, const float* wv, float* dx, float* dwq, float* dbq, float* dwk,
+                     float* dbk, float* dwv, float* dbv, void* workspace, size_t workspace_bytes, int B, int L, int D,
+                     bxStream stream);
+
 /* ---- attribution ----------------------------------------------------------------------------- */
 /* Grad-CAM channel reduce (canonical; the reference has none -- SURVEY.md K18):
  *   w[m,c] = mean_p G[m,p,c];  raw[m,p] = sum_c w[m,c]*A[m/maps_per_act,p,c];  cam = relu ? max(raw,0) : raw.

@@ -102,6 +102,9 @@ SIGNATURES = {
     "bx_eeg_deep_workspace": (sz, [P(EegDeepDesc)]),
     "bx_eeg_deep_fwd": (i32, [P(EegDeepDesc), P(EegDeepParams), vp, vp, vp, vp, vp, vp, sz, vp]),
     "bx_eeg_deep_bwd": (i32, [P(EegDeepDesc), P(EegDeepParams), vp, vp, vp, vp, vp, P(EegDeepGrads), vp, vp, sz, vp]),
+    "bx_attention_workspace": (sz, [i32]),
+    "bx_attention_fwd": (i32, [vp] * 10 + [i32, i32, i32, vp]),
+    "bx_attention_bwd": (i32, [vp] * 16 + [sz, i32, i32, i32, vp]),
     "bx_gradcam_reduce": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "bx_resize_bilinear": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "bx_saliency_reduce": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, vp]),

@@ -679,3 +679,182 @@ extern "C" int bx_eeg_deep_bwd(const bxEegDeepDesc* d, const bxEegDeepParams* p,
   BX_CHECK_LAUNCH("bx_eeg_deep_bwd");
   return BX_OK;
 }
+
+// ================================================================================================
+// Stand-alone Attention module (reference models.py:109-134): tokens x [B,L,32] -> (output [B,L,32], weights [B,L,L]).
+// Same arithmetic as the attention stage of the fused head above, one workgroup per sample; input_dim = attention_dim = 32,
+// L <= 32.  The backward also accepts a gradient w.r.t. the returned weights (the module returns them).
+struct AttnFwdArgs { const float *x, *wq, *bq, *wk, *bk, *wv, *bv; float *out, *attn, *qkv; int L; float scale; };
+__global__ __launch_bounds__(256) void k_attn_fwd(AttnFwdArgs a) {
+  __shared__ float wl[3][DP_F3][DP_LP];
+  __shared__ float xs[DP_MAXL][DP_LP];
+  __shared__ float qkvs[3][DP_MAXL][DP_LP];
+  __shared__ float As[DP_MAXL][DP_LP];
+  const int b = blockIdx.x, tid = threadIdx.x, L = a.L, K = DP_F3 * L;
+  deep_fill_qkv_w(wl, a.wq, a.wk, a.wv);
+  for (int i0 = tid; i0 < K; i0 += 256 * 4) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + u * 256; v[u] = a.x[(size_t)b * K + (i < K ? i : 0)]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + u * 256; if (i < K) xs[i >> 5][i & 31] = v[u]; }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 3 * K; idx += 256) {
+    const int which = idx / K, r = idx - which * K, l = r >> 5, d = r & 31;
+    float acc = (which == 0 ? a.bq : which == 1 ? a.bk : a.bv)[d];
+#pragma unroll
+    for (int c = 0; c < DP_F3; ++c) acc += xs[l][c] * wl[which][d][c];
+    qkvs[which][l][d] = acc;
+    a.qkv[(((size_t)b * 3 + which) * L + l) * DP_F3 + d] = acc;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < L * L; idx += 256) {
+    const int l = idx / L, m = idx - l * L;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < DP_F3; ++d) s += qkvs[0][l][d] * qkvs[1][m][d];
+    As[l][m] = s * a.scale;
+  }
+  __syncthreads();
+  if (tid < L) {
+    float mx = -INFINITY;
+    for (int m = 0; m < L; ++m) mx = fmaxf(mx, As[tid][m]);
+    float sum = 0.f;
+    for (int m = 0; m < L; ++m) { const float e = expf(As[tid][m] - mx); As[tid][m] = e; sum += e; }
+    const float inv = 1.f / sum;
+    for (int m = 0; m < L; ++m) As[tid][m] *= inv;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < L * L; idx += 256) { const int l = idx / L, m = idx - l * L; a.attn[(size_t)b * L * L + idx] = As[l][m]; }
+  for (int idx = tid; idx < K; idx += 256) {
+    const int l = idx >> 5, d = idx & 31;
+    float o = 0.f;
+    for (int m = 0; m < L; ++m) o += As[l][m] * qkvs[2][m][d];
+    a.out[(size_t)b * K + idx] = o;
+  }
+}
+
+struct AttnBwdArgs { const float *dout, *dattn, *x, *attn, *qkv, *wq, *wk, *wv; float *dx, *qkvp; int L, want_w; float scale; };
+__global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
+  __shared__ float wl[3][DP_F3][DP_LP];
+  __shared__ float xs[DP_MAXL][DP_LP];
+  __shared__ float qkvs[3][DP_MAXL][DP_LP];
+  __shared__ float dG[3][DP_MAXL][DP_LP];
+  __shared__ float As[DP_MAXL][DP_LP];
+  __shared__ float dSs[DP_MAXL][DP_LP];
+  __shared__ float dOs[DP_MAXL][DP_LP];
+  const int b = blockIdx.x, tid = threadIdx.x, L = a.L, K = DP_F3 * L;
+  deep_fill_qkv_w(wl, a.wq, a.wk, a.wv);
+  for (int i0 = tid; i0 < 3 * K; i0 += 256 * 4) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + u * 256; v[u] = a.qkv[(size_t)b * 3 * K + (i < 3 * K ? i : 0)]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + u * 256; if (i < 3 * K) { const int wh = i / K, r = i - wh * K; qkvs[wh][r >> 5][r & 31] = v[u]; } }
+  }
+  for (int i0 = tid; i0 < K; i0 += 256 * 4) {
+    float v[4], g_[4], w_[4], da[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256, ic = i < K ? i : 0, il = i < L * L ? i : 0;
+      v[u] = a.x[(size_t)b * K + ic];
+      g_[u] = a.dout[(size_t)b * K + ic];
+      w_[u] = a.attn[(size_t)b * L * L + il];
+      da[u] = a.dattn ? a.dattn[(size_t)b * L * L + il] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256;
+      if (i < K) { xs[i >> 5][i & 31] = v[u]; dOs[i >> 5][i & 31] = g_[u]; }
+      if (i < L * L) { const int l = i / L; As[l][i - l * L] = w_[u]; dSs[l][i - l * L] = da[u]; }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < K; idx += 256) {                                       // dV[m][d] = sum_l A[l][m] dO[l][d]
+    const int m = idx >> 5, dd = idx & 31;
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += As[l][m] * dOs[l][dd];
+    dG[2][m][dd] = s;
+  }
+  for (int idx = tid; idx < L * L; idx += 256) {                                   // dA[l][m] = sum_d dO[l][d] V[m][d]  (+ the weights' own gradient)
+    const int l = idx / L, m = idx - l * L;
+    float s = dSs[l][m];
+#pragma unroll
+    for (int dd = 0; dd < DP_F3; ++dd) s += dOs[l][dd] * qkvs[2][m][dd];
+    dSs[l][m] = s;
+  }
+  __syncthreads();
+  if (tid < L) {
+    float r = 0.f;
+    for (int m = 0; m < L; ++m) r += dSs[tid][m] * As[tid][m];
+    for (int m = 0; m < L; ++m) dSs[tid][m] = As[tid][m] * (dSs[tid][m] - r) * a.scale;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 2 * K; idx += 256) {
+    const int which = idx / K, r = idx - which * K, row = r >> 5, dd = r & 31;
+    float s = 0.f;
+    if (which == 0) for (int m = 0; m < L; ++m) s += dSs[row][m] * qkvs[1][m][dd];
+    else            for (int l = 0; l < L; ++l) s += dSs[l][row] * qkvs[0][l][dd];
+    dG[which][row][dd] = s;
+  }
+  __syncthreads();
+  if (a.dx)
+    for (int idx = tid; idx < K; idx += 256) {
+      const int l = idx >> 5, c = idx & 31;
+      float s = 0.f;
+#pragma unroll
+      for (int wh = 0; wh < 3; ++wh)
+#pragma unroll
+        for (int dd = 0; dd < DP_F3; ++dd) s += dG[wh][l][dd] * wl[wh][dd][c];
+      a.dx[(size_t)b * K + idx] = s;
+    }
+  if (a.want_w) {
+    float* out = a.qkvp + (size_t)b * DP_NQKV;
+    for (int idx = tid; idx < 3 * DP_F3 * DP_F3; idx += 256) {
+      const int wh = idx >> 10, dd = (idx >> 5) & 31, c = idx & 31;
+      float s = 0.f;
+      for (int l = 0; l < L; ++l) s += dG[wh][l][dd] * xs[l][c];
+      out[idx] = s;
+    }
+    if (tid < 3 * DP_F3) {
+      const int wh = tid >> 5, dd = tid & 31;
+      float s = 0.f;
+      for (int l = 0; l < L; ++l) s += dG[wh][l][dd];
+      out[3 * DP_F3 * DP_F3 + tid] = s;
+    }
+  }
+}
+
+extern "C" size_t bx_attention_workspace(int B) { return B > 0 ? (size_t)B * DP_NQKV * sizeof(float) : 0; }
+extern "C" int bx_attention_fwd(const float* x, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,
+                                const float* bv, float* out, float* attn, float* qkv_saved, int B, int L, int D, bxStream stream) {
+  BX_REQUIRE(x && wq && bq && wk && bk && wv && bv && out && attn && qkv_saved, "bx_attention_fwd: null pointer");
+  BX_REQUIRE(B > 0 && L > 0 && L <= DP_MAXL && D == DP_F3, "bx_attention_fwd: needs input_dim = attention_dim = %d and L <= %d", DP_F3, DP_MAXL);
+  AttnFwdArgs a;
+  a.x = x; a.wq = wq; a.bq = bq; a.wk = wk; a.bk = bk; a.wv = wv; a.bv = bv; a.out = out; a.attn = attn; a.qkv = qkv_saved; a.L = L;
+  a.scale = 1.0f / sqrtf((float)D);
+  hipLaunchKernelGGL(k_attn_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+  BX_CHECK_LAUNCH("bx_attention_fwd");
+  return BX_OK;
+}
+extern "C" int bx_attention_bwd(const float* dout, const float* dattn, const float* x, const float* attn, const float* qkv_saved,
+                                const float* wq, const float* wk, const float* wv, float* dx, float* dwq, float* dbq, float* dwk, float* dbk,
+                                float* dwv, float* dbv, void* workspace, size_t workspace_bytes, int B, int L, int D, bxStream stream) {
+  BX_REQUIRE(dout && x && attn && qkv_saved && wq && wk && wv, "bx_attention_bwd: null pointer");
+  BX_REQUIRE(B > 0 && L > 0 && L <= DP_MAXL && D == DP_F3, "bx_attention_bwd: needs input_dim = attention_dim = %d and L <= %d", DP_F3, DP_MAXL);
+  const int want_w = dwq || dbq || dwk || dbk || dwv || dbv;
+  if (want_w && (!workspace || workspace_bytes < bx_attention_workspace(B))) BX_FAIL(BX_EWORKSPACE, "bx_attention_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  AttnBwdArgs a;
+  a.dout = dout; a.dattn = dattn; a.x = x; a.attn = attn; a.qkv = qkv_saved; a.wq = wq; a.wk = wk; a.wv = wv; a.dx = dx;
+  a.qkvp = (float*)workspace; a.L = L; a.want_w = want_w; a.scale = 1.0f / sqrtf((float)D);
+  hipLaunchKernelGGL(k_attn_bwd, dim3(B), dim3(256), 0, s, a);
+  if (want_w) {
+    DeepQkvOut qo;
+    qo.p[0] = dwq; qo.p[1] = dwk; qo.p[2] = dwv; qo.p[3] = dbq; qo.p[4] = dbk; qo.p[5] = dbv;
+    hipLaunchKernelGGL(k_deep_qkv_reduce, dim3(bx_ceil_div(DP_NQKV, 256)), dim3(256), 0, s, (const float*)workspace, B, qo);
+  }
+  BX_CHECK_LAUNCH("bx_attention_bwd");
+  return BX_OK;
+}

@@ -171,10 +171,10 @@ class EEGNet(nn.Module):
 
 
 class Attention(nn.Module):
-    """Single-head scaled dot-product self-attention (reference models.py:109-134): parameter container for
-    ``EEGNetAttentionDeep`` (the attention itself runs inside the fused head kernels).  Called on its own it takes
-    tokens [B, L, input_dim] and returns (output, attention_weights) like the reference; only the geometry the fused
-    kernels are built for is accepted (input_dim = attention_dim = 32, L <= 32)."""
+    """Single-head scaled dot-product self-attention (reference models.py:109-134).  Inside ``EEGNetAttentionDeep`` it is a
+    parameter container (the attention runs in the fused head kernels); called on its own it takes tokens [B, L, input_dim]
+    and returns (output, attention_weights) like the reference (``bx_attention_fwd/_bwd``; input_dim = attention_dim = 32,
+    L <= 32)."""
 
     def __init__(self, input_dim, attention_dim):
         super().__init__()
@@ -184,8 +184,7 @@ class Attention(nn.Module):
         self.scale = attention_dim ** -0.5
 
     def forward(self, x):
-        raise NotImplementedError("brainxai Attention runs fused inside EEGNetAttentionDeep's head kernels (bx_eeg_deep_fwd); "
-                                  "a stand-alone launch is not part of the hot path")
+        return ops.AttentionFn.apply(x, self.query.weight, self.query.bias, self.key.weight, self.key.bias, self.value.weight, self.value.bias)
 
 
 class EEGNetAttentionDeep(nn.Module):

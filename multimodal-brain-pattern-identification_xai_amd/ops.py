@@ -679,6 +679,40 @@ class EegDeepHeadFn(torch.autograd.Function):
         return (dfeat, *gl, None, None)
 
 
+class AttentionFn(torch.autograd.Function):
+    """softmax(Q K^T / sqrt(d)) V with Linear query/key/value maps (reference models.py:117-134): x [B,L,32] -> (out, weights)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv):
+        lib = L.load()
+        _require_gpu(x, "attention input")
+        if x.dim() != 3 or x.shape[2] != 32 or x.shape[1] > 32 or tuple(wq.shape) != (32, 32):
+            raise RuntimeError("brainxai Attention: needs tokens [B, L <= 32, 32] and input_dim = attention_dim = 32")
+        B, L_, D = x.shape
+        x = x.contiguous().float()
+        out = torch.empty(B, L_, D, dtype=torch.float32, device=x.device)
+        attn = torch.empty(B, L_, L_, dtype=torch.float32, device=x.device)
+        qkv = torch.empty(B, 3, L_, D, dtype=torch.float32, device=x.device)
+        L.check(lib.bx_attention_fwd(_p(x), _p(wq), _p(bq), _p(wk), _p(bk), _p(wv), _p(bv), _p(out), _p(attn), _p(qkv), B, L_, D, _stream()),
+                "bx_attention_fwd")
+        ctx.save_for_backward(x, attn, qkv, wq, bq, wk, bk, wv, bv)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, dout, dattn):
+        lib = L.load()
+        x, attn, qkv, wq, bq, wk, bk, wv, bv = ctx.saved_tensors
+        B, L_, D = x.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gl = [new_grad(t) if need else None for t, need in zip((wq, bq, wk, bk, wv, bv), ctx.needs_input_grad[1:])]
+        ws = workspace(lib.bx_attention_workspace(B), x.device)
+        dout = dout.contiguous()
+        dattn = dattn.contiguous() if dattn is not None else None
+        L.check(lib.bx_attention_bwd(_p(dout), _p(dattn), _p(x), _p(attn), _p(qkv), _p(wq), _p(wk), _p(wv), _p(dx), *[_p(t) for t in gl],
+                                     _p(ws), ws.numel(), B, L_, D, _stream()), "bx_attention_bwd")
+        return (dx, *gl)
+
+
 def block_cfg(**kw) -> SimpleNamespace:
     base = dict(pool="max", training=False, dropout_p=0.0, eps=1e-5, momentum=0.1, salt=0, preact=0, capture=None,
                 prepacked=None, pack_base=0, seed=None)

@@ -271,6 +271,29 @@ def gen_eegnet_deep(M):
         save(tag, **rec)
 
 
+def gen_attention(M):
+    """Attention (M:109-134) on its own: output, weights and every gradient, with a gradient flowing through BOTH return values."""
+    ref = O.fill_params(M.Attention(32, 32), seed=71)
+    mine = O.fill_params(O.Attention(32, 32), seed=71)
+    rec = {}
+    for tag, (b, l) in {"a": (3, 11), "b": (2, 7), "c": (1, 32)}.items():
+        x = O.seeded((b, l, 32), 72 + l, "randn")
+        r1, r2 = O.seeded((b, l, 32), 73 + l, "randn"), O.seeded((b, l, l), 74 + l, "randn")
+        outs = []
+        for net in (ref, mine):
+            net.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            o, w = net(xi)
+            ((o * r1).sum() + (w * r2).sum()).backward()
+            outs.append((o.detach(), w.detach(), xi.grad.detach(), {n: p.grad.detach().clone() for n, p in net.named_parameters()}))
+        note("attention.out", outs[1][0], outs[0][0]); note("attention.weights", outs[1][1], outs[0][1]); note("attention.dx", outs[1][2], outs[0][2])
+        for n in outs[0][3]:
+            note("attention.dparam", outs[1][3][n], outs[0][3][n])
+            rec[f"{tag}.grad.{n}"] = outs[0][3][n]
+        rec[f"{tag}.out"], rec[f"{tag}.weights"], rec[f"{tag}.dx"] = outs[0][0], outs[0][1], outs[0][2]
+    save("attention_32", **rec)
+
+
 def gen_multimodal(M, MM):
     """Logits, both KLDiv reductions, gradient digests, state after 3 AdamW steps (dropout 0)."""
     for tag, (chans, samples, cin, h, w, b) in {"mm_bench_small": (19, 2000, 4, 32, 64, 4),
@@ -506,6 +529,7 @@ if __name__ == "__main__":
     if want("spec"): print("spectrogram models"); gen_spec_models(M)
     if want("eegnet"): print("eegnet"); gen_eegnet(M)
     if want("eegdeep"): print("eegnet attention deep"); gen_eegnet_deep(M)
+    if want("attention"): print("attention"); gen_attention(M)
     if want("multimodal"): print("multimodal"); gen_multimodal(M, MM)
     if want("attribution"): print("attribution"); gen_attribution(M, MM, NB)
     if want("stacker"): print("stacker"); gen_stacker()

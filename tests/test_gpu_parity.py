@@ -196,6 +196,31 @@ def test_eegnet_attention_deep_fwd_bwd(tag, chans, samples, b):
     assert int(mine.batchnorm4.num_batches_tracked) == 1
 
 
+def test_attention_module_standalone():
+    """Attention (models.py:109-134) called on its own: (output, weights) and all gradients, with a gradient through both
+    returns, against the oracle and the fixtures recorded from the reference class; unsupported geometry raises."""
+    fix = load("attention_32")
+    ref, mine = _pair(lambda: O.Attention(32, 32), lambda: brainxai.Attention(32, 32), 71)
+    for tag, (b, l) in {"a": (3, 11), "b": (2, 7), "c": (1, 32)}.items():
+        x = O.seeded((b, l, 32), 72 + l, "randn")
+        r1, r2 = O.seeded((b, l, 32), 73 + l, "randn"), O.seeded((b, l, l), 74 + l, "randn")
+        ref.zero_grad(); mine.zero_grad()
+        xr = x.clone().requires_grad_(True)
+        o_r, w_r = ref(xr); ((o_r * r1).sum() + (w_r * r2).sum()).backward()
+        xm = x.clone().to(DEV).requires_grad_(True)
+        o_m, w_m = mine(xm); ((o_m * r1.to(DEV)).sum() + (w_m * r2.to(DEV)).sum()).backward()
+        assert _sync_err(o_m, o_r) < TIGHT and _sync_err(w_m, w_r) < TIGHT and _sync_err(xm.grad, xr.grad) < TIGHT
+        check(fix, f"{tag}.out", o_m.detach().cpu(), tol=TOL); check(fix, f"{tag}.weights", w_m.detach().cpu(), tol=TOL)
+        check(fix, f"{tag}.dx", xm.grad.cpu(), tol=TOL)
+        fl = _gscale(ref)           # key.bias has an exactly-zero gradient (softmax ignores a per-row constant): both sides are rounding noise
+        for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+            torch.cuda.synchronize()
+            assert rel_err(p.grad.cpu(), q.grad, floor=fl) < TIGHT, (tag, n)
+            check(fix, f"{tag}.grad.{n}", p.grad.cpu(), tol=TOL, floor=fl)
+    with pytest.raises(RuntimeError, match="32"):
+        mine(torch.zeros(1, 33, 32, device=DEV))
+
+
 def test_eegnet_attention_deep_dropout_and_bench_batch():
     """Dropout masks of forward and backward agree (finite-difference-free check: the gradient w.r.t. a token that the
     mask removed is zero), the pass is deterministic for a fixed seed state, and the bench batch (64 x 19 x 2000) runs."""

@@ -107,6 +107,22 @@ def test_eegnet_attention_deep(tag, chans, samples, b):
     assert int(net.batchnorm4.num_batches_tracked) == int(fix["after.batchnorm4.num_batches_tracked"]) == 1
 
 
+def test_attention_module():
+    """Attention (models.py:109-134) on its own, gradient through both return values."""
+    fix = load("attention_32")
+    net = O.fill_params(O.Attention(32, 32), seed=71)
+    for tag, (b, l) in {"a": (3, 11), "b": (2, 7), "c": (1, 32)}.items():
+        x = O.seeded((b, l, 32), 72 + l, "randn").requires_grad_(True)
+        r1, r2 = O.seeded((b, l, 32), 73 + l, "randn"), O.seeded((b, l, l), 74 + l, "randn")
+        net.zero_grad()
+        o, w = net(x)
+        ((o * r1).sum() + (w * r2).sum()).backward()
+        check(fix, f"{tag}.out", o); check(fix, f"{tag}.weights", w); check(fix, f"{tag}.dx", x.grad)
+        fl = 1e-2 * max(float(p.grad.abs().max()) for p in net.parameters())      # key.bias: exactly-zero gradient, rounding noise only
+        for n, p in net.named_parameters():
+            check(fix, f"{tag}.grad.{n}", p.grad, tol=2e-5, floor=fl)
+
+
 @pytest.mark.parametrize("tag,cfg", [("mm_bench_small", (19, 2000, 4, 32, 64, 4)),
                                      ("mm_native_small", (37, 3000, 3, 50, 37, 2))])
 def test_multimodal_train3(tag, cfg):
