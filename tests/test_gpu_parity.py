@@ -221,6 +221,50 @@ def test_attention_module_standalone():
         mine(torch.zeros(1, 33, 32, device=DEV))
 
 
+@pytest.mark.parametrize("samples,chans,b", [(256, 8, 1), (288, 5, 2), (3000, 37, 1)])
+def test_eegnet_attention_deep_edge_shapes(samples, chans, b):
+    """smallest legal geometry (one attention token: Samples = 256), a ragged one (Samples = 288 -> T/32 = 9, one token, a
+    dropped pooling tail) and batch 1 at the reference's native size, forward + all gradients against the oracle"""
+    ref, mine = _pair(lambda: O.EEGNetAttentionDeep(6, Chans=chans, Samples=samples, dropoutRate=0.0),
+                      lambda: brainxai.EEGNetAttentionDeep(6, Chans=chans, Samples=samples, dropoutRate=0.0), 81)
+    x = O.seeded((b, 1, chans, samples), 82, "randn")
+    r = O.seeded((b, 6), 83, "randn")
+    for mode in ("eval", "train") if b > 1 else ("eval",):         # BatchNorm in train mode needs more than one value per channel
+        ref.train(mode == "train"); mine.train(mode == "train")
+        ref.zero_grad(); mine.zero_grad()
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr); (yr * r).sum().backward()
+        xm = x.clone().to(DEV).requires_grad_(True)
+        ym = mine(xm); (ym * r.to(DEV)).sum().backward()
+        assert _sync_err(ym, yr) < TIGHT, mode
+        _gclose(xm.grad, xr.grad, f"eegdeep edge {samples} {mode} dx")
+        fl = _gscale(ref)
+        for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+            _gclose(p.grad, q.grad, f"eegdeep edge {samples} {mode} d{n}", tol=TIGHT, floor=fl)
+
+
+def test_multimodal_batch_of_one_bf16_and_fp32():
+    """B = 1 through the fused head, the chained weight gradients and the MFMA tail kernels (eval mode: BatchNorm statistics
+    of a single sample are degenerate in train mode), fp32 against the oracle, bf16 against fp32"""
+    ref, mine = _pair(lambda: O.build_multimodal(19, 2000, 4, dropout=0.0), lambda: brainxai.build_multimodal(19, 2000, 4, dropout=0.0), 91)
+    ref.eval(); mine.eval()
+    eeg, spec, r = O.seeded((1, 1, 19, 2000), 92, "randn"), O.seeded((1, 4, 32, 64), 93, "rand"), O.seeded((1, 6), 94, "randn")
+    yr = ref(eeg, spec); (yr * r).sum().backward()
+    out = {}
+    for dt in (torch.float32, torch.bfloat16):
+        brainxai.set_compute_dtype(mine, dt)
+        mine.zero_grad()
+        ym = mine(eeg.to(DEV), spec.to(DEV)); (ym * r.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        out[dt] = (ym.detach().cpu(), {n: p.grad.cpu().clone() for n, p in mine.named_parameters()})
+    assert rel_err(out[torch.float32][0], yr.detach()) < TIGHT
+    fl = _gscale(ref)
+    for (n, q) in ref.named_parameters():
+        assert rel_err(out[torch.float32][1][n], q.grad, floor=fl) < 2e-3, n
+    assert rel_err(out[torch.bfloat16][0], out[torch.float32][0]) < 3e-2
+    assert mine._fusable()
+
+
 def test_eegnet_attention_deep_dropout_and_bench_batch():
     """Dropout masks of forward and backward agree (finite-difference-free check: the gradient w.r.t. a token that the
     mask removed is zero), the pass is deterministic for a fixed seed state, and the bench batch (64 x 19 x 2000) runs."""
