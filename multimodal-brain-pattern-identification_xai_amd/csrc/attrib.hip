@@ -79,9 +79,39 @@ __global__ void k_resize_bilinear(const float* __restrict__ src, float* __restri
     dst[i] = (1.f - ly) * ((1.f - lx) * s[y0 * w + x0] + lx * s[y0 * w + x1]) + ly * ((1.f - lx) * s[y1 * w + x0] + lx * s[y1 * w + x1]);
   }
 }
+// four consecutive output columns per thread (one 16-byte store), 32-bit index arithmetic, one trip per thread: the scalar
+// kernel above spent its time in 64-bit divisions and 4-byte stores (46 us for 384 maps of 128 x 256 = 1.1 TB/s of writes)
+__global__ __launch_bounds__(256) void k_resize_bilinear4(const float* __restrict__ src, float* __restrict__ dst, unsigned n4, int h, int w, int H,
+                                                          int W4, float sy, float sx) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n4) return;
+  const unsigned X4 = i % (unsigned)W4, r = i / (unsigned)W4;
+  const unsigned Y = r % (unsigned)H, m = r / (unsigned)H;
+  int y0, y1; float ly;
+  bilinear_src((int)Y, sy, h, y0, y1, ly);
+  const float* s0 = src + (size_t)m * h * w + (size_t)y0 * w;
+  const float* s1 = src + (size_t)m * h * w + (size_t)y1 * w;
+  float a0[4], a1[4], b0[4], b1[4], lxs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int x0, x1;
+    bilinear_src((int)(X4 * 4 + j), sx, w, x0, x1, lxs[j]);
+    a0[j] = s0[x0]; a1[j] = s0[x1]; b0[j] = s1[x0]; b1[j] = s1[x1];
+  }
+  float o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (1.f - ly) * ((1.f - lxs[j]) * a0[j] + lxs[j] * a1[j]) + ly * ((1.f - lxs[j]) * b0[j] + lxs[j] * b1[j]);
+  reinterpret_cast<float4*>(dst)[i] = make_float4(o[0], o[1], o[2], o[3]);
+}
 extern "C" int bx_resize_bilinear(const float* src, float* dst, int N, int h, int w, int H, int W, bxStream stream) {
   BX_REQUIRE(src && dst && N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bx_resize_bilinear: bad arguments");
   const long long n = (long long)N * H * W;
+  if (W % 4 == 0 && n / 4 < (1ll << 31) && ((uintptr_t)dst & 15) == 0) {
+    hipLaunchKernelGGL(k_resize_bilinear4, dim3(bx_ceil_div(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, (unsigned)(n / 4), h, w, H,
+                       W / 4, (float)h / (float)H, (float)w / (float)W);
+    BX_CHECK_LAUNCH("bx_resize_bilinear");
+    return BX_OK;
+  }
   const int grid = bx_ceil_div(n, 256) > 4096 ? 4096 : bx_ceil_div(n, 256);
   hipLaunchKernelGGL(k_resize_bilinear, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, n, h, w, H, W,
                      (float)h / (float)H, (float)w / (float)W);
