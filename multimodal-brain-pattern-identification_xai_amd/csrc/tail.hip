@@ -162,8 +162,10 @@ __device__ __forceinline__ void skip_sample(const T* __restrict__ x, const TailG
 }
 
 // forward 3: out = dropout(pooled*scale + shift) + b1x1 + W1x1 . bilinear(x)
-template <typename T, int RPT>      // RPT = weight rows per trip of the 1x1 loop (2 RPT loads in flight).  16 was no faster for the late stages:
-                                    // there the 256 one-per-CU workgroups all pull the same 128 KB of weights through L2 (32 MB per launch)
+// RPT = weight rows per trip of the 1x1 loop (2 RPT loads in flight).  The late stages take ~12 us here whatever Cin_p is
+// (32, 64 or 128 rows): neither 16 rows per trip nor 4 pixels per thread (4x fewer weight loads, 14 us) moved it -- the time is
+// the fixed chain of cold round trips after the kernel boundary (scale/shift, skip input, first weight rows), not the loop.
+template <typename T, int RPT>
 __global__ __launch_bounds__(256, 4) void k_tail_apply(const T* __restrict__ pooled, const T* __restrict__ x, const float* __restrict__ wT,
     int Cin, const float* __restrict__ b1x1, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, T* __restrict__ out, TailGeom g,
