@@ -161,7 +161,7 @@ def main():
         opt.zero_grad()
         out = model(eeg, spec)
         loss = crit(out, labels)
-        loss.backward()
+        loss.backward(ops.unit_gradient(loss.device))       # same as loss.backward(): the seed gradient 1.0 is a cached tensor, not a fill launch
         return loss.detach()
 
     def finish():

@@ -566,6 +566,20 @@ class MultimodalHeadFn(torch.autograd.Function):
 _REDUCTIONS = {"mean": 0, "batchmean": 1, "sum": 2}
 
 
+_ONES = {}
+
+
+def unit_gradient(device) -> torch.Tensor:
+    """A cached scalar 1.0 on ``device`` for ``loss.backward(gradient=...)``: autograd would otherwise fill a fresh
+    ones-tensor every step (a launch), and KLDivFn recognises this very tensor and skips its multiply (another launch)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _ONES.get(key)
+    if t is None:
+        t = torch.ones((), dtype=torch.float32, device=device)
+        _ONES[key] = t
+    return t
+
+
 class KLDivFn(torch.autograd.Function):
     """nn.KLDivLoss(reduction)(log_probs, target)  (reference XAI_Multimodality.py:1989,1599)."""
 
@@ -583,6 +597,9 @@ class KLDivFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dlogp,) = ctx.saved_tensors
+        one = _ONES.get(dlogp.device.index if dlogp.device.index is not None else torch.cuda.current_device())
+        if one is not None and g.data_ptr() == one.data_ptr():
+            return dlogp, None, None, None                  # upstream gradient is the cached constant 1: nothing to multiply
         out = torch.empty_like(dlogp)
         g = g.contiguous()
         L.check(L.load().bx_scale_dev(_p(dlogp), _p(g), _p(out), dlogp.numel(), _stream()), "bx_scale_dev")

@@ -188,7 +188,7 @@ def train_step(model, optimizer, eeg, spec, labels, criterion, ddp=None):
     optimizer.zero_grad()
     out = model(eeg, spec)
     loss = criterion(out, labels)
-    loss.backward()
+    loss.backward(ops.unit_gradient(loss.device) if loss.is_cuda and loss.dim() == 0 else None)
     if ddp is not None:
         ddp.sync_gradients(optimizer)
         if isinstance(optimizer, FlatAdamW):
@@ -257,7 +257,7 @@ class GraphedTrainStep:
             out = ops.MultimodalHeadFn.apply(sf_leaf.permute(0, 2, 3, 1), ef_leaf, sm.fc.weight, sm.fc.bias, em.dense.weight, em.dense.bias,
                                              m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
             loss = self.crit(out, static_lab)
-            loss.backward()
+            loss.backward(ops.unit_gradient(loss.device) if loss.is_cuda and loss.dim() == 0 else None)
             d_sf, d_ef = sf_leaf.grad, ef_leaf.grad
         with torch.cuda.graph(g[3], stream=s_main):
             torch.autograd.backward([sf], [d_sf])
@@ -307,7 +307,7 @@ class GraphedTrainStep:
         self.opt.zero_grad()
         out = self.model(*inputs)
         loss = self.crit(out, labels)
-        loss.backward()
+        loss.backward(ops.unit_gradient(loss.device) if loss.is_cuda and loss.dim() == 0 else None)
         if self.ddp is not None:
             self.ddp.sync_gradients(self.opt)
             self.opt.step(gathered=True)
@@ -346,7 +346,7 @@ class GraphedTrainStep:
                     self.opt.zero_grad()
                     out = self.model(*static_in)
                     loss = self.crit(out, static_lab)
-                    loss.backward()
+                    loss.backward(ops.unit_gradient(loss.device) if loss.is_cuda and loss.dim() == 0 else None)
                     if self.ddp is None:
                         self.opt.step()
                 entry = (graph, static_in, static_lab, loss.detach(), out.detach())
@@ -539,7 +539,7 @@ def train_and_validate_eeg_distributed(model, train_loader, valid_loader, epochs
             optimizer.zero_grad()
             out = ddp(data)
             loss = criterion(out, labels)
-            loss.backward()
+            loss.backward(ops.unit_gradient(loss.device) if loss.is_cuda and loss.dim() == 0 else None)
             if wd > 0 and flat and optimizer.is_cuda:
                 optimizer.gather_grads()
                 reg = torch.empty((), dtype=torch.float32, device=device)
