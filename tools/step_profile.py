@@ -104,13 +104,43 @@ def pmc_summarize(fetch_dir, write_dir, steps):
         print(f"{k[:60]:60s} {v['fetch'][0] / steps:13.2f} {v['fetch'][1] / nf / 1e6:10.2f} {v['write'][1] / nw / 1e6:10.2f}")
 
 
+def sq_summarize(d, steps):
+    """Per-kernel SQ counters from one `rocprofv3 --kernel-trace --pmc <names...>` pass of this script (eager steps):
+    sums over the launches of the last `steps` steps, plus a few ratios."""
+    db = sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True))[-1]
+    con = sqlite3.connect(db)
+    q = ("select s.kernel_name, d.start, p.name, e.value from rocpd_pmc_event e join rocpd_kernel_dispatch d on e.event_id = d.event_id "
+         "join rocpd_info_kernel_symbol s on d.kernel_id = s.id join rocpd_info_pmc p on e.pmc_id = p.id order by d.start")
+    rows = list(con.execute(q))
+    names = sorted({r[0] for r in rows})
+    dem = subprocess.run(["c++filt"], input="\n".join(n.replace(".kd", "") for n in names), capture_output=True, text=True).stdout.split("\n")
+    short = {n: re.sub(r"\(.*", "", dm).replace("void ", "") for n, dm in zip(names, dem)}
+    starts = sorted({r[1] for r in rows if short[r[0]].startswith("k_adamw")})
+    lo, hi = starts[-steps - 1], starts[-1]
+    agg, counters = {}, []
+    for n, st, c, v in rows:
+        if not (lo < st <= hi):
+            continue
+        if c not in counters:
+            counters.append(c)
+        agg.setdefault(short[n], {}).setdefault(c, 0.0)
+        agg[short[n]][c] += float(v)
+    print("# per-kernel SQ counters, sums over %d eager training steps (B=64, bf16)" % steps)
+    print("%-44s " % "kernel" + " ".join("%14s" % c[-14:] for c in counters))
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0.0)):
+        print("%-44s " % k[:44] + " ".join("%14.4g" % v.get(c, 0.0) for c in counters))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--summarize", default=None)
     ap.add_argument("--pmc", nargs=2, default=None, metavar=("FETCH_DIR", "WRITE_DIR"))
+    ap.add_argument("--sq", default=None, metavar="DIR")
     a = ap.parse_args()
-    if a.pmc:
+    if a.sq:
+        sq_summarize(a.sq, a.steps)
+    elif a.pmc:
         pmc_summarize(a.pmc[0], a.pmc[1], a.steps)
     elif a.summarize:
         summarize(a.summarize, a.steps)
