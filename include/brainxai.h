@@ -325,6 +325,8 @@ int bx_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float 
 int bx_sumsq(const float* x, size_t n, float* out, bxStream stream);
 /* dropout seed stream: out[0] = ++state[0] (a forward call and its backward read the same `out`). */
 int bx_seed_next(uint64_t* state, uint64_t* out, bxStream stream);
+/* two independent counters advanced by one launch (the two branches of the multimodal model draw one seed each per step) */
+int bx_seed_next2(uint64_t* state_a, uint64_t* out_a, uint64_t* state_b, uint64_t* out_b, bxStream stream);
 
 #ifdef __cplusplus
 }

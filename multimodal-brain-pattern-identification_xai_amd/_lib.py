@@ -122,6 +122,7 @@ SIGNATURES = {
     "bx_adamw_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, f32, vp, vp]),
     "bx_sumsq": (i32, [vp, sz, vp, vp]),
     "bx_seed_next": (i32, [vp, vp, vp]),
+    "bx_seed_next2": (i32, [vp, vp, vp, vp, vp]),
 }
 
 _lib = None

@@ -259,6 +259,16 @@ extern "C" int bx_sumsq(const float* x, size_t n, float* out, bxStream stream) {
 }
 
 __global__ void k_seed_next(uint64_t* state, uint64_t* out) { const uint64_t v = state[0] + 1; state[0] = v; out[0] = v; }
+__global__ void k_seed_next2(uint64_t* sa, uint64_t* oa, uint64_t* sb, uint64_t* ob) {
+  if (threadIdx.x == 0) { const uint64_t v = sa[0] + 1; sa[0] = v; oa[0] = v; }
+  else { const uint64_t v = sb[0] + 1; sb[0] = v; ob[0] = v; }
+}
+extern "C" int bx_seed_next2(uint64_t* state_a, uint64_t* out_a, uint64_t* state_b, uint64_t* out_b, bxStream stream) {
+  BX_REQUIRE(state_a && out_a && state_b && out_b && state_a != state_b, "bx_seed_next2: bad arguments");
+  hipLaunchKernelGGL(k_seed_next2, dim3(1), dim3(2), 0, (hipStream_t)stream, state_a, out_a, state_b, out_b);
+  BX_CHECK_LAUNCH("bx_seed_next2");
+  return BX_OK;
+}
 extern "C" int bx_seed_next(uint64_t* state, uint64_t* out, bxStream stream) {
   BX_REQUIRE(state && out, "bx_seed_next: null pointer");
   hipLaunchKernelGGL(k_seed_next, dim3(1), dim3(1), 0, (hipStream_t)stream, state, out);

@@ -104,11 +104,12 @@ class Spectrogram_Model(nn.Module):
         for bi, blk in enumerate(blocks):
             blk._prepacked, blk._pack_base = plan, 3 * bi
 
-    def features(self, x):
+    def features(self, x, seed=None):
         self._pack_all()
         blocks = [getattr(self, f"block{i}") for i in range(1, 6)]
         if self.training and x.is_cuda and any(b.dropout.p > 0 for b in blocks):
-            seed = ops.next_seed(x.device)
+            if seed is None:
+                seed = ops.next_seed(x.device)
             for b in blocks:
                 b._seed = seed
         try:
@@ -150,14 +151,14 @@ class EEGNet(nn.Module):
         self.compute_dtype = torch.float32
         self.salt = 100
 
-    def features(self, x):
+    def features(self, x, seed=None):
         if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != self.Chans:
             raise RuntimeError(f"EEGNet expected [B,1,{self.Chans},T], got {tuple(x.shape)}")
         g = self._geom
         bn1, bn2, bn3 = self.batchnorm1, self.batchnorm2, self.batchnorm3
         cfg = SimpleNamespace(F1=g.F1, D=g.D, F2=g.F2, K1=g.K1, K2=g.K2, P1=g.P1, P2=g.P2, training=self.training,
                               eps=bn1.eps, momentum=0.1 if bn1.momentum is None else bn1.momentum,
-                              dropout_p=self.dropout.p if self.training else 0.0, salt=self.salt, dtype=self.compute_dtype)
+                              dropout_p=self.dropout.p if self.training else 0.0, salt=self.salt, dtype=self.compute_dtype, seed=seed)
         bufs = (bn1.running_mean, bn1.running_var, bn1.num_batches_tracked, bn2.running_mean, bn2.running_var,
                 bn2.num_batches_tracked, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked)
         return ops.EegFeaturesFn.apply(x, self.conv1.weight, bn1.weight, bn1.bias, self.depthwiseConv.weight, bn2.weight, bn2.bias,
@@ -284,9 +285,12 @@ class MultimodalModel(nn.Module):
             e.record_stream(cur)
         elif self._fusable():
             # one launch for GAP+fc, dense and the fusion head (same arithmetic as the three separate ops below)
-            ef = self.eeg_model.features(eeg_data)
-            sf = self.spectrogram_model.features(spectrogram_data)
             em, sm = self.eeg_model, self.spectrogram_model
+            ss = se = None
+            if self.training and em.dropout.p > 0 and any(getattr(sm, f"block{i}").dropout.p > 0 for i in range(1, 6)):
+                ss, se = ops.next_seed_pair(eeg_data.device)    # both branches' dropout seeds from one launch
+            ef = em.features(eeg_data, seed=se)
+            sf = sm.features(spectrogram_data, seed=ss)
             if ef.shape[1] != em.dense.in_features:
                 raise RuntimeError(f"EEGNet: {ef.shape[1]} features but dense expects {em.dense.in_features} (Samples mismatch)")
             return ops.MultimodalHeadFn.apply(sf.permute(0, 2, 3, 1), ef, sm.fc.weight, sm.fc.bias, em.dense.weight, em.dense.bias,

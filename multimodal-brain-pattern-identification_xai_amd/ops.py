@@ -145,6 +145,14 @@ def next_seed(device, lane: str = "spec") -> torch.Tensor:
     return out
 
 
+def next_seed_pair(device):
+    """(spectrogram-lane seed, EEG-lane seed) from ONE launch; same values as two next_seed() calls."""
+    out = torch.empty(2, dtype=torch.int64, device=device)
+    L.check(L.load().bx_seed_next2(_p(seed_state(device, "spec")), out.data_ptr(), _p(seed_state(device, "eeg")), out.data_ptr() + 8, _stream()),
+            "bx_seed_next2")
+    return out[0:1], out[1:2]
+
+
 # Gradient arena hook: the trainer / DDP wrapper registers, per parameter, a callable returning a fresh
 # view into its flat fp32 gradient buffer, so weight-gradient kernels write there directly.
 _GRAD_VIEW = {}
@@ -626,7 +634,11 @@ class EegFeaturesFn(torch.autograd.Function):
                              _p(bufs[4]), _p(bufs[5]), _p(sepw), _p(bn3w), _p(bn3b), _p(bufs[6]), _p(bufs[7]), _p(bufs[8]))
         T2 = (T // cfg.P1) // cfg.P2
         feat = torch.empty(B, cfg.F2 * T2, dtype=torch.float32, device=x.device)
-        seed = next_seed(x.device, "eeg") if (cfg.training and cfg.dropout_p > 0) else None
+        seed = None
+        if cfg.training and cfg.dropout_p > 0:
+            seed = getattr(cfg, "seed", None)
+            if seed is None:
+                seed = next_seed(x.device, "eeg")
         L.check(lib.bx_eeg_features_fwd(C.byref(desc), C.byref(params), _p(x), _p(seed), _p(feat), _p(saved), _p(ws), ws.numel(), _stream()),
                 "bx_eeg_features_fwd")
         ctx.desc, ctx.params, ctx.seed, ctx.bufs = desc, params, seed, bufs
