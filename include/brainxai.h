@@ -70,6 +70,10 @@ typedef struct {
   int Cout, Cin, I_p, O_p, transpose_flip, block_begin;
 } bxPackJob;
 int bx_conv3x3_pack_many(const bxPackJob* jobs_device, int njobs, int total_blocks, bxStream stream);
+/* The same launch also converts the batch: src fp32 NCHW [B,C,H,W] -> dst bf16 NHWC [B,H,W,Cp] (what bx_nchw_to_nhwc does;
+ * the two are independent and both sit at the start of every training step). */
+int bx_conv3x3_pack_many_layout(const bxPackJob* jobs_device, int njobs, int total_blocks, const float* src_nchw,
+                                void* dst_nhwc_bf16, int B, int C, int H, int W, int Cp, bxStream stream);
 /* y = epi(conv3x3(x, Wp) + bias);  x [B,H,W,Ci] -> y [B,H,W,Co], both `dtype`.
  *   bias (fp32 [Co]) may be NULL; flags & BX_EPI_RELU applies max(.,0);
  *   relu_mask_src (dtype [B,H,W,Co], may be NULL): y *= (relu_mask_src > 0)  -- the ReLU backward

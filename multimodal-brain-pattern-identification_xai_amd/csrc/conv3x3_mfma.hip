@@ -65,7 +65,23 @@ void bx_conv3x3_mfma_pack_launch(const float* w_oihw, void* packed, int Cout, in
 
 // Many pack jobs in ONE launch (all 3x3 convolutions of the model, forward and data-gradient operands): the job
 // table lives in device memory and is built once by the host (parameter pointers are stable under FlatAdamW).
-__global__ __launch_bounds__(256) void k_pack_mfma_many(const bxPackJob* __restrict__ jobs, int njobs) {
+// Optional second role (workgroups >= npack): the batch's fp32 NCHW -> bf16 NHWC(Cp) conversion, which is independent of
+// the packing and otherwise a launch of its own at the start of every step (lsrc == nullptr: no such workgroups).
+__global__ __launch_bounds__(256) void k_pack_mfma_many(const bxPackJob* __restrict__ jobs, int njobs, int npack, const float* __restrict__ lsrc,
+                                                        bf16_t* __restrict__ ldst, int C, int Cp, int HW, int nbx) {
+  if ((int)blockIdx.x >= npack) {
+    const int lb = (int)blockIdx.x - npack, b = lb / nbx, r = (lb - b * nbx) * 256 + (int)threadIdx.x;
+    if (r >= HW) return;
+    for (int c0 = 0; c0 < Cp; c0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int c = c0 + j < C ? c0 + j : C - 1; v[j] = lsrc[((size_t)b * C + c) * HW + r]; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = c0 + j < C ? v[j] : 0.f;
+      st8(ldst, ((size_t)b * HW + r) * Cp + c0, v);
+    }
+    return;
+  }
   // job lookup in one memory round trip: lanes compare their job's first block with this block, ballot counts them
   __shared__ int sj;
   if (threadIdx.x < 64) {
@@ -84,7 +100,7 @@ __global__ __launch_bounds__(256) void k_pack_mfma_many(const bxPackJob* __restr
   const size_t n = (size_t)(jb.I_p / ck) * ks * jb.O_p * 32;
   const float* __restrict__ w = (const float*)jb.w_oihw;
   bf16_t* __restrict__ wp = (bf16_t*)jb.packed_mfma;
-  const int nblk = (j + 1 < njobs ? jobs[j + 1].block_begin : (int)gridDim.x) - jb.block_begin;
+  const int nblk = (j + 1 < njobs ? jobs[j + 1].block_begin : npack) - jb.block_begin;
   for (size_t i0 = (size_t)(blockIdx.x - jb.block_begin) * 2048 + threadIdx.x; i0 < n; i0 += (size_t)nblk * 2048) {
     float v[8];
 #pragma unroll
@@ -114,8 +130,21 @@ __global__ __launch_bounds__(256) void k_pack_mfma_many(const bxPackJob* __restr
 }
 extern "C" int bx_conv3x3_pack_many(const bxPackJob* jobs_device, int njobs, int total_blocks, bxStream stream) {
   BX_REQUIRE(jobs_device && njobs > 0 && total_blocks > 0, "bx_conv3x3_pack_many: bad arguments");
-  hipLaunchKernelGGL(k_pack_mfma_many, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs);
+  hipLaunchKernelGGL(k_pack_mfma_many, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs, total_blocks,
+                     (const float*)nullptr, (bf16_t*)nullptr, 0, 0, 0, 1);
   BX_CHECK_LAUNCH("bx_conv3x3_pack_many");
+  return BX_OK;
+}
+extern "C" int bx_conv3x3_pack_many_layout(const bxPackJob* jobs_device, int njobs, int total_blocks, const float* src_nchw, void* dst_nhwc_bf16,
+                                           int B, int C, int H, int W, int Cp, bxStream stream) {
+  BX_REQUIRE(jobs_device && njobs > 0 && total_blocks > 0 && src_nchw && dst_nhwc_bf16, "bx_conv3x3_pack_many_layout: bad arguments");
+  BX_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Cp % 8 == 0 && C <= Cp, "bx_conv3x3_pack_many_layout: Cp must be a multiple of 8 and >= C");
+  const long long HW = (long long)H * W;
+  const long long nbx = (HW + 255) / 256;
+  BX_REQUIRE(HW < (1ll << 31) && nbx * B + total_blocks < (1ll << 31), "bx_conv3x3_pack_many_layout: input too large");
+  hipLaunchKernelGGL(k_pack_mfma_many, dim3((unsigned)(total_blocks + nbx * B)), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs,
+                     total_blocks, src_nchw, (bf16_t*)dst_nhwc_bf16, C, Cp, (int)HW, (int)nbx);
+  BX_CHECK_LAUNCH("bx_conv3x3_pack_many_layout");
   return BX_OK;
 }
 

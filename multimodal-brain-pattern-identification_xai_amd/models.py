@@ -88,24 +88,30 @@ class Spectrogram_Model(nn.Module):
         self.log_softmax = nn.LogSoftmax(dim=1)
         self.compute_dtype = torch.float32
 
-    def _pack_all(self):
-        """bf16 MFMA path: ONE launch packs the forward and data-gradient operands of all 15 convolutions."""
+    def _pack_all(self, x=None):
+        """bf16 MFMA path: ONE launch packs the forward and data-gradient operands of all 15 convolutions -- and, when the raw
+        batch ``x`` (fp32 NCHW, no gradient wanted) is given, converts it to the internal layout as well (returned, else None)."""
         blocks = [getattr(self, f"block{i}") for i in range(1, 6)]
         for blk in blocks:
             blk._prepacked = None
         if self.compute_dtype != torch.bfloat16 or ops.CONV_ALGO == ops.L.BX_ALGO_DIRECT or not self.fc.weight.is_cuda:
-            return
+            return None
         weights = [getattr(b, f"conv{k}").weight for b in blocks for k in (1, 2, 3)]
         plan = getattr(self, "_pack_plan", None)
         if plan is None or plan.key != tuple(w.data_ptr() for w in weights):
             plan = ops.PackPlan(weights)
             self._pack_plan = plan
-        plan.run()
+        raw = (x is not None and x.is_cuda and x.dim() == 4 and x.shape[1] == blocks[0].in_channels and not x.requires_grad
+               and not _is_internal(x, torch.bfloat16) and blocks[0].compute_dtype == torch.bfloat16)
+        xi = plan.run(x if raw else None)
         for bi, blk in enumerate(blocks):
             blk._prepacked, blk._pack_base = plan, 3 * bi
+        return xi
 
     def features(self, x, seed=None):
-        self._pack_all()
+        xi = self._pack_all(x)
+        if xi is not None:
+            x = xi                                          # already in the internal layout (same launch as the weight packing)
         blocks = [getattr(self, f"block{i}") for i in range(1, 6)]
         if self.training and x.is_cuda and any(b.dropout.p > 0 for b in blocks):
             if seed is None:

@@ -264,9 +264,19 @@ class PackPlan:
         raw = bytes(memoryview(jobs)) if entries else b"\0" * 8
         self.jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
 
-    def run(self):
+    def run(self, x_nchw=None):
+        """Pack every operand; with ``x_nchw`` (fp32 NCHW, no gradient needed) the same launch also produces the batch in the
+        internal bf16 channels-last layout and returns it as a logical-NCHW view."""
+        if x_nchw is not None and self.njobs:
+            B, Cc, H, W = x_nchw.shape
+            src = x_nchw.detach().to(torch.float32).contiguous()
+            out = torch.empty(B, H, W, pad8(Cc), dtype=torch.bfloat16, device=x_nchw.device)
+            L.check(L.load().bx_conv3x3_pack_many_layout(_p(self.jobs_dev), self.njobs, self.nblocks, _p(src), _p(out), B, Cc, H, W, pad8(Cc),
+                                                         _stream()), "bx_conv3x3_pack_many_layout")
+            return out.permute(0, 3, 1, 2)
         if self.njobs:
             L.check(L.load().bx_conv3x3_pack_many(_p(self.jobs_dev), self.njobs, self.nblocks, _stream()), "bx_conv3x3_pack_many")
+        return None
 
     def get(self, i, flip):
         return self.views.get((i, flip))
