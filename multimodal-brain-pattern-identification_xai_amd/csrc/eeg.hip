@@ -451,9 +451,36 @@ __global__ __launch_bounds__(256) void k_eeg_act_bwd(const float* __restrict__ d
     partials[(size_t)b * 32 + threadIdx.x * 16 + f] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 // finalize: dgamma, dbeta, coefficients a = gamma*invstd, k1 = s1/N, k2 = s2/N (zero in eval mode)
-__global__ void k_eeg_bn_bwd_finalize(const float* __restrict__ partials, int nblk, double count, int F, int training,
+// Workgroups > 0 (optional second role): fixed-order sum of an unrelated, already finished set of weight-gradient partials
+// (sum_src [nchunk][n] -> sum_dst[n], as k_sum_partials with S slices) that would otherwise be a launch of its own.
+__global__ __launch_bounds__(1024) void k_eeg_bn_bwd_finalize(const float* __restrict__ partials, int nblk, double count, int F, int training,
                                       const float* __restrict__ gamma, const float* __restrict__ inv, float* __restrict__ coef,
-                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                      const float* __restrict__ sum_src, float* __restrict__ sum_dst, int nchunk, int n, int S) {
+  if (blockIdx.x > 0) {
+    __shared__ float sm[1024];
+    const int NO = 256 / S, grp = threadIdx.x >> 8, t = threadIdx.x & 255;
+    const int o = t % NO, sl = t / NO;
+    const int i = (((int)blockIdx.x - 1) * 4 + grp) * NO + o;
+    float a = 0.f;
+    if (i < n) {
+      int k = sl;
+      for (; k + 3 * S < nchunk; k += 4 * S) {
+        const float v0 = sum_src[(size_t)k * n + i], v1 = sum_src[(size_t)(k + S) * n + i];
+        const float v2 = sum_src[(size_t)(k + 2 * S) * n + i], v3 = sum_src[(size_t)(k + 3 * S) * n + i];
+        a += v0; a += v1; a += v2; a += v3;
+      }
+      for (; k < nchunk; k += S) a += sum_src[(size_t)k * n + i];
+    }
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+      float r = sm[grp * 256 + o];
+      for (int k = 1; k < S; ++k) r += sm[grp * 256 + k * NO + o];
+      sum_dst[i] = r;
+    }
+    return;
+  }
   // partial layout [blk][2][16] regardless of F
   double s[2] = {0.0, 0.0};
   sum_partials_256<2>(partials, nblk, 16, 0, 16, s);
@@ -895,7 +922,8 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
   hipLaunchKernelGGL(k_eeg_act_bwd, dim3(g.B, g.F2), dim3(256), 0, s, dfeat, smap, st.mean3, st.inv3, st.sc3, st.sh3, du3, part, g.F2, g.T1, g.T2, g.P2,
                      seed, pdrop, d->salt + 1);
   BX_CHECK_LAUNCH("eeg act3 bwd");
-  hipLaunchKernelGGL(k_eeg_bn_bwd_finalize, dim3(1), dim3(1024), 0, s, part, g.B, (double)g.B * g.T1, g.F2, tr, p->bn3_w, st.inv3, coef3, gr->bn3_w, gr->bn3_b);
+  hipLaunchKernelGGL(k_eeg_bn_bwd_finalize, dim3(1), dim3(1024), 0, s, part, g.B, (double)g.B * g.T1, g.F2, tr, p->bn3_w, st.inv3, coef3, gr->bn3_w, gr->bn3_b,
+                     (const float*)nullptr, (float*)nullptr, 0, 0, 4);
   BX_CHECK_LAUNCH("eeg bn3 bwd finalize");
   {
     const long long n = (long long)g.B * g.F2 * g.T1;
@@ -910,16 +938,18 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
       BX_FAIL(BX_EHIP, "bx_eeg_features_bwd: cannot reserve %zu bytes of LDS", lds);
     hipLaunchKernelGGL(k_eeg_sep_bwd, dim3(g.B, 4), dim3(256), lds, s, du3, p1, p->sep_w, dp1, sepp, g);
     BX_CHECK_LAUNCH("eeg sep bwd");
-    if (gr->sep_w) {
-      BX_SUM_PARTIALS(sepp, gr->sep_w, g.B * 4, 4096, s);
-      BX_CHECK_LAUNCH("eeg sep wgrad reduce");
-    }
   }
   // pool1/dropout/ELU/BN2
   hipLaunchKernelGGL(k_eeg_act_bwd, dim3(g.B, g.FD), dim3(256), 0, s, dp1, dmap, st.mean2, st.inv2, st.sc2, st.sh2, du2, part, g.FD, g.T, g.T1, g.P1,
                      seed, pdrop, d->salt);
   BX_CHECK_LAUNCH("eeg act2 bwd");
-  hipLaunchKernelGGL(k_eeg_bn_bwd_finalize, dim3(1), dim3(1024), 0, s, part, g.B, (double)g.B * g.T, g.FD, tr, p->bn2_w, st.inv2, coef2, gr->bn2_w, gr->bn2_b);
+  {
+    // BN2 finalize; the separable convolution's weight-gradient partials (finished two launches ago) are summed by extra workgroups
+    const int S2 = bx_partial_slices(4096, g.B * 4);
+    const int nsum = gr->sep_w ? bx_ceil_div(4096, 4 * (256 / S2)) : 0;
+    hipLaunchKernelGGL(k_eeg_bn_bwd_finalize, dim3(1 + nsum), dim3(1024), 0, s, part, g.B, (double)g.B * g.T, g.FD, tr, p->bn2_w, st.inv2, coef2, gr->bn2_w,
+                       gr->bn2_b, (const float*)sepp, gr->sep_w, g.B * 4, 4096, S2);
+  }
   BX_CHECK_LAUNCH("eeg bn2 bwd finalize");
   {
     const long long n = (long long)g.B * g.FD * g.T;
