@@ -922,9 +922,11 @@ static WgradPlan wgrad_plan(int B, int H, int W, int Ci_p, int Co) {
   p.tw = W <= 16 ? 16 : 32;
   p.tiles_x = (W + p.tw - 1) / p.tw; p.tiles_y = (H + 7) / 8; p.ntiles = p.tiles_x * p.tiles_y * B;
   p.ytiles = (Ci_p + 16 * p.ma - 1) / (16 * p.ma); p.ztiles = Co / (16 * p.nb);
-  // (2,2) tiles run one workgroup per CU (register bound): aim at two rounds of 256; lighter tiles at four
+  // two rounds of 256 workgroups for every tile shape: with the partial sum riding in the next layer's launch, more (smaller)
+  // splits only add partial traffic (sweep of BX_WGRAD_WANT on the training step: 384 1.789, 512 1.733, 576 1.745, 768 1.870,
+  // 1024 1.882 ms; the lighter tiles used to run at 1024)
   static const int want_env = getenv("BX_WGRAD_WANT") ? atoi(getenv("BX_WGRAD_WANT")) : 0;
-  int want = (want_env ? want_env : (p.ma * p.nb == 4 ? 512 : 1024)) / (p.ytiles * p.ztiles);
+  int want = (want_env ? want_env : 512) / (p.ytiles * p.ztiles);
   if (want < 1) want = 1;
   if (want > p.ntiles) want = p.ntiles;
   p.tps = (p.ntiles + want - 1) / want;
