@@ -625,7 +625,8 @@ static int launch_conv_nc(const void* x, const void* wp, const float* bias, cons
   // output channels per workgroup: 64 while that still launches >= 512 workgroups, else 32 (keeps two per CU in flight)
   const int tw = W <= 16 ? 16 : 32;
   const long long tiles = (long long)((W + tw - 1) / tw) * ((H + 7) / 8) * B;
-  if (Co % 64 == 0 && tiles * (Co / 64) >= 512) return launch_conv_tw<CK, 4>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
+  static const long long nc4_min = getenv("BX_CONV_NC4_MIN") ? atoll(getenv("BX_CONV_NC4_MIN")) : 512;
+  if (Co % 64 == 0 && tiles * (Co / 64) >= nc4_min) return launch_conv_tw<CK, 4>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
   if (Co % 32 == 0) return launch_conv_tw<CK, 2>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
   return launch_conv_tw<CK, 1>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
 }

@@ -9,7 +9,7 @@
 // the partials in double precision.  No atomics: results are run-to-run deterministic.
 #include "bx_common.h"
 
-#define TAIL_MAX_BLOCKS 512
+#define TAIL_MAX_BLOCKS 2048        // layout bound of the partial buffers; the launch cap is tail_block_cap()
 
 struct TailGeom {
   int B, H, W, Ho, Wo, C, Cin_p, ncg, slots;
@@ -29,13 +29,17 @@ static int make_geom(const bxTailDesc* d, TailGeom* g) {
   return 0;
 }
 // kernels without per-workgroup partials take one pixel group per workgroup (no serial grid-stride trips)
+static int tail_block_cap() {          // workgroups of the statistics / reduction passes (BX_TAIL_BLOCKS, default 512)
+  static const int cap = [] { const char* e = getenv("BX_TAIL_BLOCKS"); int v = e ? atoi(e) : 512; return v < 1 ? 1 : v > TAIL_MAX_BLOCKS ? TAIL_MAX_BLOCKS : v; }();
+  return cap;
+}
 static int tail_blocks_all(const TailGeom& g) {
   long long nb = (g.npool + g.slots - 1) / g.slots;
   return (int)(nb > 65535 ? 65535 : nb);
 }
 static int tail_blocks(const TailGeom& g) {
   long long nb = (g.npool + g.slots - 1) / g.slots;
-  return (int)(nb > TAIL_MAX_BLOCKS ? TAIL_MAX_BLOCKS : nb);
+  return (int)(nb > tail_block_cap() ? tail_block_cap() : nb);
 }
 
 // pooled-pixel index -> (sample, row, column) with 32-bit unsigned divisions (the launchers check B*H*W < 2^31): the
