@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Print VGPR / AGPR / spill / LDS / occupancy per kernel of one csrc file (hipcc -Rpass-analysis=kernel-resource-usage)."""
+"""Print VGPR / AGPR / spill / scratch / LDS / occupancy per kernel of one csrc file (hipcc -Rpass-analysis=kernel-resource-usage).
+`scratch` (bytes per lane) can be non-zero with zero spills: a register array indexed at run time, or filled under a condition,
+is placed in scratch memory."""
 import re, subprocess, sys
 src = sys.argv[1]
 pat = sys.argv[2] if len(sys.argv) > 2 else ""
@@ -16,5 +18,5 @@ for line in out.splitlines():
         k, v = t.split(":", 1); cur[k.strip()] = v.strip()
         if k.strip().startswith("LDS Size"):
             if pat in cur["name"]:
-                print(f"{cur['name'][:60]:60s} VGPR {cur.get('VGPRs','?'):>4s} AGPR {cur.get('AGPRs','?'):>4s} spill {cur.get('VGPR Spill', cur.get('VGPRs Spill','?')):>3s} "
+                print(f"{cur['name'][:60]:60s} VGPR {cur.get('VGPRs','?'):>4s} AGPR {cur.get('AGPRs','?'):>4s} spill {cur.get('VGPR Spill', cur.get('VGPRs Spill','?')):>3s} scratch {cur.get('ScratchSize [bytes/lane]','?'):>4s} "
                       f"occ {cur.get('Occupancy [waves/SIMD]','?'):>2s} LDS {cur.get('LDS Size [bytes/block]','?')}")
