@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
 """Headline benchmark: multimodal (SpectrogramCNN + EEGNet + fusion) TRAINING samples/sec on synthetic
 [64,4,128,256] spectrograms + [64,10000,19] raw EEG per GPU (BASELINE.json configs[1]; configs[2] under
---gpus 8), with Grad-CAM maps/sec, the dominant kernel's roofline and the CPU oracle timed beside it.
+--gpus 8), the Grad-CAM sweep of configs[3] (10 000 samples, all classes), the dominant kernel's roofline and the CPU
+oracle timed beside it.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                                   # 1 GPU, 100 timed steps, finishes in a couple of minutes
+    python bench.py --gpus N --steps K --warmup W     # N > 1: starts N rank processes itself (torch.distributed.run), or
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W        # ... is started by a launcher, one rank per GPU
 
-A step = zero_grad -> forward -> KLDiv -> backward -> (RCCL all-reduce of the flat gradient arena) -> fused
-AdamW over one B=64 batch per rank, inputs resident in HBM.  Prints ONE JSON line on rank 0.
+A step = zero_grad -> forward -> KLDiv -> backward -> (RCCL all-reduce of the flat gradient arena, in two buckets overlapped
+with the early stages' backward) -> fused AdamW over one B=64 batch per rank, inputs resident in HBM, replayed from hipGraphs
+by brainxai.GraphedTrainStep -- the same object the product's epoch loops use.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -27,48 +31,54 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 B, CIN, H, W, CHANS, RAW_LEN, T = 64, 4, 128, 256, 19, 10000, 2000
+SWEEP_SAMPLES = 10000          # configs[3]
+# per Grad-CAM sample (eval, BN folded) forward 7.85 M elements = 15.7 MB bf16 (31.4 MB fp32), 1.90 GFLOP; plus the six
+# upsampled fp32 maps it writes (6 x 128 x 256 x 4 B)
+GRADCAM_BYTES = {"bf16": 15.7e6 + 6 * H * W * 4, "f32": 31.4e6 + 6 * H * W * 4}
+GRADCAM_FLOPS = 1.90e9
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gradcam", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (stackers, pre-processing, IG, EEGNetAttentionDeep)")
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying captured hipGraphs")
     return ap.parse_args()
 
 
 def conv_work(bx, dtype_bytes):
-    """Algorithmic FLOPs / bytes of every conv3x3 launch of one training step:
-    forward 15 launches, data-gradient 10 (block1.conv1's is skipped: the input needs no gradient... but
-    conv1 of blocks 2-5 do), weight-gradient 15.  Returns dict kind -> (flops, bytes, launches)."""
-    stages = [(8, 16, 128, 256), (16, 32, 64, 128), (32, 64, 32, 64), (64, 128, 16, 32), (128, 256, 8, 16)]
+    """Algorithmic FLOPs / bytes of every conv3x3 launch of one training step: forward 15 launches,
+    data-gradient 14 (block1.conv1's input needs no gradient), weight-gradient 15.  TRUE channel counts (block1.conv1 has
+    4 input planes; the kernels pad them to 8, which is their business).  Returns kind -> [flops, bytes, launches]."""
+    stages = [(CIN, 16, 128, 256), (16, 32, 64, 128), (32, 64, 32, 64), (64, 128, 16, 32), (128, 256, 8, 16)]
     out = {"fwd": [0.0, 0.0, 0], "dgrad": [0.0, 0.0, 0], "wgrad": [0.0, 0.0, 0]}
-    for si, (cin_p, c, h, w) in enumerate(stages):
+    for si, (cin, c, h, w) in enumerate(stages):
         px = bx * h * w
-        for k, ci in enumerate((cin_p, c, c)):
+        for k, ci in enumerate((cin, c, c)):
             fl = 2.0 * 9 * ci * c * px
             by = px * (ci + c) * dtype_bytes
             out["fwd"][0] += fl; out["fwd"][1] += by; out["fwd"][2] += 1
             out["wgrad"][0] += fl; out["wgrad"][1] += by; out["wgrad"][2] += 1
             if not (si == 0 and k == 0):
-                extra = px * (ci if k else 0) * dtype_bytes      # ReLU-mask read (conv2/3) or skip addend (conv1)
+                # + the ReLU-mask source (conv2/3) or the skip-path addend (conv1) read by the fused epilogue
                 out["dgrad"][0] += fl; out["dgrad"][1] += by + px * ci * dtype_bytes; out["dgrad"][2] += 1
-                del extra
     return out
 
 
 def pmc_conv_traffic(dtype):
     """HBM bytes per conv3x3-family launch from the newest committed PMC summary (profiles/*_pmc_hbm_traffic.txt written by
-    tools/step_profile.py --pmc: same model, batch and dtype as this benchmark); None when absent or for another dtype."""
-    import glob
+    tools/step_profile.py --pmc: same model, batch and dtype as this benchmark, FETCH_SIZE x2 + WRITE_SIZE collected in separate
+    rocprofv3 passes as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process, so the line
+    names the file (and its date) the figure comes from.  (bytes, source) or (None, None)."""
     if dtype != "bf16":
-        return None
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.txt")))
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.txt")))
     for path in reversed(files):
         tot, launches = 0.0, 0.0
         for line in open(path):
@@ -82,12 +92,54 @@ def pmc_conv_traffic(dtype):
             if not line.startswith("k_wgrad_reduce"):
                 launches += n
         if launches > 0:
-            return round(tot / launches)
-    return None
+            stamp = time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(path)))
+            return round(tot / launches), f"profiles/{os.path.basename(path)} ({stamp})"
+    return None, None
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes through torch.distributed.run -- BEFORE this
+    process makes any GPU call (it never does: a process that has initialised the GPU must not exec or fork GPU workers) -- and
+    relay rank 0's JSON line.  Exit code = the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("BX_BENCH_FORCE_LAUNCH", None)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)        # stderr of the ranks passes through
+    line = None
+    for ln in proc.stdout.decode(errors="replace").splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            line = ln
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write(f"[bench] {args.gpus}-rank run failed (exit code {proc.returncode}, JSON line {'missing' if line is None else 'present'})\n")
+        sys.exit(proc.returncode or 1)
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+    sys.exit(0)
+
+
+def timed(fn, reps, sync):
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return time.perf_counter() - t0
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("BX_BENCH_FORCE_LAUNCH") == "1"):
+        have = torch.cuda.device_count()                 # counting devices does not initialise the GPU on this stack
+        if have < args.gpus:
+            sys.exit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
+        launch_ranks(args)
     # stdout carries exactly ONE JSON line: library banners (RCCL prints its version to stdout at init) and any
     # other chatter are routed to stderr for the whole run; the JSON goes to the saved descriptor at the end
     sys.stdout.flush()
@@ -97,12 +149,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    sync = torch.cuda.synchronize
     force_dist = os.environ.get("BX_BENCH_FORCE_DIST") == "1"      # exercise the data-parallel path with a 1-rank RCCL group
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -112,6 +165,14 @@ def main():
     import brainxai
     from brainxai import ops
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    extra = {}
+
+    def all_max(seconds):
+        if world > 1:
+            tt = torch.tensor([seconds], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt)
+        return seconds
 
     # ---- synthetic inputs, seed 42 + rank, generated on the host like a DataLoader would
     g = torch.Generator().manual_seed(42 + rank)
@@ -124,205 +185,173 @@ def main():
     raw = raw.to(dev)
     labels = torch.softmax(torch.randn(B, 6, generator=g), 1).to(dev)
     eeg = brainxai.stack_eeg(raw)                      # [B,1,19,2000], resident
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        brainxai.stack_eeg(raw)
-    torch.cuda.synchronize()
-    stacker_sps = 3 * B / (time.perf_counter() - t0)
-    # the notebook's native montage chain, raw frames [B,10000,20] -> [B,1,37,3000]
-    frames = torch.randn(B, 10000, 20, device=dev) * 50
-    brainxai.stack_eeg_montage(frames)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
+    stacker_sps = montage_sps = specprep_sps = None
+    if not args.no_extras:
+        stacker_sps = 10 * B / timed(lambda: brainxai.stack_eeg(raw), 10, sync)
+        # the notebook's native montage chain, raw frames [B,10000,20] -> [B,1,37,3000]
+        frames = torch.randn(B, 10000, 20, device=dev) * 50
         brainxai.stack_eeg_montage(frames)
-    torch.cuda.synchronize()
-    montage_sps = 3 * B / (time.perf_counter() - t0)
-    del frames
-    # the notebook's native spectrogram chain, parquet values [B,320,400] -> [B,3,400,300]
-    sframes = torch.rand(B, 320, 400, device=dev) * 40
-    brainxai.preprocess_spectrograms(sframes)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
+        montage_sps = 3 * B / timed(lambda: brainxai.stack_eeg_montage(frames), 3, sync)
+        del frames
+        # the notebook's native spectrogram chain, parquet values [B,320,400] -> [B,3,400,300]
+        sframes = torch.rand(B, 320, 400, device=dev) * 40
         brainxai.preprocess_spectrograms(sframes)
-    torch.cuda.synchronize()
-    specprep_sps = 3 * B / (time.perf_counter() - t0)
-    del sframes
+        specprep_sps = 3 * B / timed(lambda: brainxai.preprocess_spectrograms(sframes), 3, sync)
+        del sframes
 
     torch.manual_seed(42)
     model = brainxai.build_multimodal(CHANS, T, CIN, dropout=0.5, compute_dtype=cdt).to(dev).train()
     ddp = brainxai.DataParallel(model) if (world > 1 or force_dist) else None
     opt = brainxai.FlatAdamW(model.parameters(), lr=1e-3)
     crit = brainxai.KLDivLoss()
-
-    def fwd_bwd():
-        opt.zero_grad()
-        out = model(eeg, spec)
-        loss = crit(out, labels)
-        loss.backward(ops.unit_gradient(loss.device))       # same as loss.backward(): the seed gradient 1.0 is a cached tensor, not a fill launch
-        return loss.detach()
-
-    def finish():
-        if ddp is not None:
-            ddp.sync_gradients(opt)           # ONE RCCL all-reduce(AVG) of the flat gradient arena
-            opt.step(gathered=True)
-        else:
-            opt.step()
+    # the product's own step object: first call eager, second captured (one hipGraph; data-parallel: two, with the first
+    # gradient bucket's all-reduce between them), later calls replayed.  The benchmark batch IS the graph's static input.
+    stepper = brainxai.GraphedTrainStep(model, opt, crit, ddp=ddp, adopt_inputs=True)
+    if args.no_graph:
+        stepper.enabled = False
+    inputs = [eeg, spec]
 
     def step():
-        loss = fwd_bwd()
-        finish()
-        return loss, None
+        return stepper(inputs, labels)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 3)):               # >= 3 so that capture and the first replay are outside the timed region
         loss, _ = step()
-    # ---- hipGraph: ~130 launches per step are captured once and replayed.  Single GPU: the whole step.  Multi GPU:
-    # forward+backward are replayed, the all-reduce and the fused AdamW (2 launches) are issued eagerly after it.
-    graph, graph_covers_all = None, ddp is None
-    if not args.no_graph:
-        try:
-            torch.cuda.synchronize()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()                                    # allocate everything once on the capture stream
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                g_loss = fwd_bwd()
-                if graph_covers_all:
-                    finish()
-            graph.replay()
-            if not graph_covers_all:
-                finish()
-            torch.cuda.synchronize()
-        except Exception as exc:                          # noqa: BLE001
-            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
-            graph = None
+    graphed = bool(stepper._graphs)
     # ---- timed region: exactly K steps between barrier + synchronize on both sides
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        if graph is not None:
-            graph.replay()
-            if not graph_covers_all:
-                finish()
-        else:
-            loss, _ = step()
-    torch.cuda.synchronize()
+        loss, _ = step()
+    sync()
     if world > 1:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if graph is not None:
-        loss = g_loss
-    # ---- per-kernel HIP-event timing of the conv family: the same step launched eagerly right after the timed
-    # region (events cannot bracket kernels inside a replayed graph), same buffers, same data
-    prof = []
-    ops.CONV_PROFILE = prof
-    prof_steps = min(args.steps, 5)
-    for _ in range(prof_steps):
-        step()
-    torch.cuda.synchronize()
-    ops.CONV_PROFILE = None
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt)
+    elapsed = all_max(time.perf_counter() - t0)
     loss_val = float(loss)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
-    # ---- dominant kernel (conv3x3 family): HIP-event durations recorded around each launch in the timed region
+    # ---- the same step with the stacker in the loop (SURVEY 8(d) "end-to-end" figure): raw EEG [64,10000,19] -> stack -> step
+    def e2e():
+        inputs[0].copy_(brainxai.stack_eeg(raw))
+        step()
+    e2e()
+    e2e_n = min(args.steps, 50)
+    e2e_elapsed = all_max(timed(e2e, e2e_n, sync))
+    extra["end_to_end_samples_per_sec"] = round(world * B * e2e_n / e2e_elapsed, 1)
+    extra["end_to_end_note"] = "raw EEG [64,10000,19] -> GPU stacker -> training step, one stream, nothing overlapped"
+
+    # ---- per-kernel HIP-event timing of the conv family: the same step launched eagerly right after the timed
+    # region (events cannot bracket kernels inside a replayed graph), same buffers, same data
+    prof = []
+    was_enabled, stepper.enabled = stepper.enabled, False
+    step()
+    ops.CONV_PROFILE = prof
+    prof_steps = min(args.steps, 5)
+    for _ in range(prof_steps):
+        step()
+    sync()
+    ops.CONV_PROFILE = None
+    stepper.enabled = was_enabled
+
+    # ---- dominant kernel family (conv3x3 forward / data gradient / weight gradient): HIP-event durations around each launch
     kinds = {}
     for kind, ev0, ev1 in prof:
         kinds.setdefault(kind, []).append(ev0.elapsed_time(ev1) * 1e-3)
-    work = conv_work(B, 2 if args.dtype == "bf16" else 4)
+    dbytes = 2 if args.dtype == "bf16" else 4
+    work = conv_work(B, dbytes)
     conv_time = sum(sum(v) for v in kinds.values()) / prof_steps            # seconds per step in conv kernels
-    conv_flops = sum(w[0] for w in work.values())
-    conv_bytes = sum(w[1] for w in work.values())
-    n_launch = sum(len(v) for v in kinds.values())
+    conv_flops = sum(w_[0] for w_ in work.values())
+    conv_bytes = sum(w_[1] for w_ in work.values())
+    n_launch = sum(len(v) for v in kinds.values()) / max(prof_steps, 1)
     roofline = None
-    extra = {}
     if conv_time > 0:
         ach_gbs = conv_bytes / conv_time / 1e9
         ach_tf = conv_flops / conv_time / 1e12
-        roofline = {"bound": "mfma", "kernel": "conv3x3 fwd+dgrad+wgrad (%d launches/step)" % (n_launch // max(prof_steps, 1)),
-                    "achieved": round(ach_tf, 3), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                    "frac": round(ach_tf / MFMA_PEAK_TFLOPS[args.dtype], 5), "traffic": pmc_conv_traffic(args.dtype),
-                    "avg_launch_us": round(conv_time / max(n_launch / prof_steps, 1) * 1e6, 2),
-                    "share_of_step": round(conv_time / (elapsed / args.steps), 3)}
-        if roofline["traffic"] is not None:
-            roofline["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, conv3x3 family average; committed summary, not live)"
-            roofline["algorithmic_bytes_per_launch"] = round(conv_bytes / max(n_launch / prof_steps, 1))
-        extra["roofline_hbm"] = {"bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(ach_gbs / HBM_PEAK_GBS, 5)}
+        ai = conv_flops / conv_bytes
+        ridge = MFMA_PEAK_TFLOPS[args.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
+        traffic, source = pmc_conv_traffic(args.dtype)
+        # the family's arithmetic intensity (~150 FLOP/B in bf16) is below the ridge (312 FLOP/B): HBM is the binding roof
+        bound = "hbm" if ai < ridge else "mfma"
+        roofline = {"bound": bound, "kernel": "conv3x3 fwd+dgrad+wgrad (%d launches/step)" % round(n_launch),
+                    "achieved": round(ach_gbs if bound == "hbm" else ach_tf, 2), "peak": HBM_PEAK_GBS if bound == "hbm" else MFMA_PEAK_TFLOPS[args.dtype],
+                    "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                    "frac": round((ach_gbs / HBM_PEAK_GBS) if bound == "hbm" else (ach_tf / MFMA_PEAK_TFLOPS[args.dtype]), 5),
+                    "traffic": traffic, "traffic_source": source,
+                    "traffic_unit": "HBM bytes per launch, family average (PMC FETCH_SIZE x2 + WRITE_SIZE; from the committed summary named in traffic_source, not measured in this run)",
+                    "algorithmic_bytes_per_launch": round(conv_bytes / max(n_launch, 1)),
+                    "arithmetic_intensity_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
+                    "avg_launch_us": round(conv_time / max(n_launch, 1) * 1e6, 2),
+                    "share_of_step": round(conv_time / (elapsed / args.steps), 3),
+                    "timing": "HIP events around each launch, %d eagerly launched steps right after the timed region" % prof_steps}
+        extra["roofline_mfma"] = {"achieved": round(ach_tf, 2), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                                  "frac": round(ach_tf / MFMA_PEAK_TFLOPS[args.dtype], 5)}
         extra["conv_ms_per_step"] = {k_: round(sum(v) / prof_steps * 1e3, 3) for k_, v in kinds.items()}
+        extra["conv_roofline_by_kind"] = {k_: {"hbm_frac": round(work[k_][1] / (sum(v) / prof_steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                               "mfma_frac": round(work[k_][0] / (sum(v) / prof_steps) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 4)}
+                                          for k_, v in kinds.items()}
     # whole-step algorithmic roofline (5.71 GFLOP and 52.2 MB bf16 / 104.5 MB fp32 per sample)
     per_sample_bytes = 52.2e6 if args.dtype == "bf16" else 104.5e6
     extra["step_roofline"] = {"hbm_frac": round(per_sample_bytes * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                               "mfma_frac": round(5.71e9 * B / (elapsed / args.steps) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 5)}
 
-    # ---- Grad-CAM maps/sec (configs[3] shape: eval, target block5, all 6 classes, upsampled to 128x256)
+    # ---- configs[3]: Grad-CAM sweep over 10 000 samples (this rank's contiguous shard of them), eval mode, target block5,
+    # all 6 classes, maps upsampled to 128x256: 156 batches of 64 + one of 16 per 10 000 (the ragged tail has its own capture)
     gradcam = None
     if not args.no_gradcam:
         model.eval()
-        for _ in range(2):
-            brainxai.grad_cam(model, eeg, spec, class_idx="all")
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            maps = brainxai.grad_cam(model, eeg, spec, class_idx="all")
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        lo, hi = brainxai.shard_bounds(SWEEP_SAMPLES, rank, world)
+        n_mine = hi - lo
+        gg = torch.Generator(device=dev).manual_seed(4200 + rank)
+        sweep_spec = torch.rand(n_mine, CIN, H, W, generator=gg, device=dev)
+        sweep_eeg = torch.randn(n_mine, 1, CHANS, T, generator=gg, device=dev)
+        sweep = brainxai.GradCamSweep(model, sweep_eeg[:B], sweep_spec[:B], class_idx="all")
+        checksum = torch.zeros((), dtype=torch.float64, device=dev)
+
+        def run_sweep(accumulate=False):
+            nb = 0
+            for b0 in range(0, n_mine, B):
+                maps = sweep(sweep_eeg[b0:b0 + B], sweep_spec[b0:b0 + B])
+                if accumulate:
+                    checksum.add_(maps.sum(dtype=torch.float64))
+                nb += 1
+            return nb
+        nb = run_sweep(accumulate=True)                     # also captures the tail batch's graph
+        sync()
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt)
-        eager_maps = world * reps * maps.shape[0] * maps.shape[1] / dt
-        # the sweep form: the same launches replayed from a hipGraph (what a 10 000-sample sweep uses)
-        sweep = brainxai.GradCamSweep(model, eeg, spec, class_idx="all")
-        sweep(eeg, spec)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        reps = 20
-        for _ in range(reps):
-            maps = sweep(eeg, spec)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt)
-        gradcam = {"maps_per_sec": round(world * reps * maps.shape[0] * maps.shape[1] / dt, 1),
-                   "samples_per_sec": round(world * reps * B / dt, 1), "classes": int(maps.shape[1]), "target": "spectrogram_model.block5",
-                   "mode": "hipGraph sweep (GradCamSweep); eager grad_cam() calls: %.0f maps/s" % eager_maps}
-        del sweep
-        # configs[4]-style integrated gradients (n_steps=50, zero baselines) on 8 samples of the batch: 50 fwd + dgrad sweeps
-        ig_in = (eeg[:8], spec[:8])
-        brainxai.integrated_gradients(model, ig_in, None, n_steps=50)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        brainxai.integrated_gradients(model, ig_in, None, n_steps=50)
-        torch.cuda.synchronize()
-        gradcam["ig50_samples_per_sec"] = round(8 / (time.perf_counter() - t0), 2)
+            dist.barrier()
+        dt = all_max(timed(run_sweep, 1, sync))
+        sps = SWEEP_SAMPLES / dt if world > 1 else n_mine / dt
+        eager_dt = timed(lambda: brainxai.grad_cam(model, sweep_eeg[:B], sweep_spec[:B], class_idx="all"), 5, sync)
+        gradcam = {"maps_per_sec": round(6 * sps, 1), "samples_per_sec": round(sps, 1), "classes": 6, "target": "spectrogram_model.block5",
+                   "workload": "configs[3]: %d samples (%d batches of %d%s per rank), eval mode, all classes, maps upsampled to %dx%d" % (
+                       SWEEP_SAMPLES, nb, B, " incl. a ragged tail of %d" % (n_mine % B) if n_mine % B else "", H, W),
+                   "mode": "hipGraph replay per batch (GradCamSweep); eager grad_cam() calls: %.0f maps/s" % (world * 5 * B * 6 / eager_dt),
+                   "roofline": {"bound": "hbm", "achieved": round(sps / world * GRADCAM_BYTES[args.dtype] / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(sps / world * GRADCAM_BYTES[args.dtype] / 1e9 / HBM_PEAK_GBS, 5),
+                                "algorithmic_bytes_per_sample": GRADCAM_BYTES[args.dtype],
+                                "mfma_frac": round(sps / world * GRADCAM_FLOPS / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 5),
+                                "note": "per GPU; SURVEY 8(d): forward 15.7 MB (bf16) + 1.90 GFLOP per sample, + the 6 upsampled fp32 maps written"},
+                   "map_checksum": float(checksum)}
+        del sweep, sweep_spec, sweep_eeg
+        if not args.no_extras:
+            # configs[4]-style integrated gradients (n_steps=50, zero baselines) on 8 samples of the batch: 50 fwd + dgrad sweeps
+            ig_in = (eeg[:8], spec[:8])
+            brainxai.integrated_gradients(model, ig_in, None, n_steps=50)
+            gradcam["ig50_samples_per_sec"] = round(world * 8 / all_max(timed(lambda: brainxai.integrated_gradients(model, ig_in, None, n_steps=50), 1, sync)), 2)
         model.train()
 
     # ---- measured device-to-device copy rate (quote the box's own streaming rate next to the 8 TB/s spec)
     if rank == 0:
         src = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
         dst = torch.empty_like(src)
-        dst.copy_(src); torch.cuda.synchronize()
+        dst.copy_(src); sync()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
             dst.copy_(src)
-        e1.record(); torch.cuda.synchronize()
+        e1.record(); sync()
         extra["measured_copy_GBps"] = round(10 * 2 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)   # read + write bytes
         del src, dst
 
@@ -346,25 +375,31 @@ def main():
             O.train_step(ref, ropt, ce, cs, cl)
         cdt_s = time.perf_counter() - t0
         cpu = {"value": round(args.cpu_steps * B / cdt_s, 2), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"{args.cpu_steps} training steps of the same B={B} batch (oracle/ref_torch.py, fp32, "
+               "sample": f"{args.cpu_steps} training steps of the same B={B} batch after 1 warm-up step (oracle/ref_torch.py, fp32, "
                          f"{torch.get_num_threads()} torch threads; host shows {os.cpu_count()} CPUs, share is 16)"}
         if gradcam is not None:
             ref.eval()
             t0 = time.perf_counter()
-            O.grad_cam(ref, ce[:16], cs[:16], class_idx="all")
-            cpu["gradcam_maps_per_sec"] = round(16 * 6 / (time.perf_counter() - t0), 2)
-        fr = O.synthetic_frames(batch=4, seed=3)
+            for i in range(3):
+                O.grad_cam(ref, ce[16 * i:16 * i + 16], cs[16 * i:16 * i + 16], class_idx="all")
+            cpu["gradcam_maps_per_sec"] = round(3 * 16 * 6 / (time.perf_counter() - t0), 2)
+            cpu["gradcam_sample"] = "3 batches of 16 samples, forward hook + one autograd pass per class"
         t0 = time.perf_counter()
-        for f in fr:
-            O.montage_transform(f)
-        cpu["montage_stacker_samples_per_sec"] = round(4 / (time.perf_counter() - t0), 2)     # one host core, numpy/scipy
-        sf = O.synthetic_spectrogram_frames(batch=4, seed=3).astype("float64")
-        t0 = time.perf_counter()
-        for f in sf:
-            O.spectrogram_transform(f)
-        cpu["spectrogram_prep_samples_per_sec"] = round(4 / (time.perf_counter() - t0), 2)
+        O.stack_eeg_batch(raw[:16].cpu().numpy())
+        cpu["stacker_samples_per_sec"] = round(16 / (time.perf_counter() - t0), 2)                 # one host core, numpy/scipy (dataset.py:73-104)
+        if not args.no_extras:
+            fr = O.synthetic_frames(batch=4, seed=3)
+            t0 = time.perf_counter()
+            for f in fr:
+                O.montage_transform(f)
+            cpu["montage_stacker_samples_per_sec"] = round(4 / (time.perf_counter() - t0), 2)     # one host core, numpy/scipy
+            sf = O.synthetic_spectrogram_frames(batch=4, seed=3).astype("float64")
+            t0 = time.perf_counter()
+            for f in sf:
+                O.spectrogram_transform(f)
+            cpu["spectrogram_prep_samples_per_sec"] = round(4 / (time.perf_counter() - t0), 2)
 
-    if rank == 0:
+    if rank == 0 and not args.no_extras:
         # SURVEY 8(a) row C': the deeper EEG-only variant (EEGNetAttentionDeep), eager train steps on the same EEG batch
         deep = brainxai.set_compute_dtype(brainxai.EEGNetAttentionDeep(6, Chans=CHANS, Samples=T), cdt).to(dev).train()
         dopt = brainxai.FlatAdamW(deep.parameters(), lr=1e-3)
@@ -376,12 +411,8 @@ def main():
             dopt.step()
         for _ in range(3):
             deep_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            deep_step()
-        torch.cuda.synchronize()
-        extra["eegnet_attention_deep_train_samples_per_sec"] = round(10 * B / (time.perf_counter() - t0), 1)
+        extra["eegnet_attention_deep_train_samples_per_sec"] = round(10 * B / timed(deep_step, 10, sync), 1)
+        dopt.close()
         del deep, dopt
     if rank == 0:
         line = {"metric": "samples/sec train (multimodal SpectrogramCNN+EEGNet fusion, B=64/GPU, 4x128x256 spectro + 10000x19 EEG)",
@@ -390,8 +421,13 @@ def main():
                 "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": "configs[1]: multimodal train step, B=64 per GPU, spec [64,4,128,256] + EEG [64,1,19,2000] (stacked from [64,10000,19])",
                            "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": "AdamW(1e-3) fused flat arena",
-                           "loss": "KLDivLoss(mean)", "dropout": 0.5, "params": sum(p.numel() for p in model.parameters())},
-                "hip_graph": graph is not None, "final_loss": round(loss_val, 6), "gradcam": gradcam, "stacker_samples_per_sec": round(stacker_sps, 1), "montage_stacker_samples_per_sec": round(montage_sps, 1), "spectrogram_prep_samples_per_sec": round(specprep_sps, 1),
+                           "loss": "KLDivLoss(mean)", "dropout": 0.5, "params": sum(p.numel() for p in model.parameters()),
+                           "gradient_exchange": None if ddp is None else ("two arena buckets, all-reduce(AVG) overlapped with the early stages' backward"
+                                                                           if stepper.plan is not None else "one all-reduce(AVG) of the flat arena")},
+                "hip_graph": graphed, "final_loss": round(loss_val, 6), "gradcam": gradcam,
+                "stacker_samples_per_sec": None if stacker_sps is None else round(stacker_sps, 1),
+                "montage_stacker_samples_per_sec": None if montage_sps is None else round(montage_sps, 1),
+                "spectrogram_prep_samples_per_sec": None if specprep_sps is None else round(specprep_sps, 1),
                 "roofline": roofline, "cpu_baseline": cpu}
         line.update(extra)
         os.write(real_stdout, (json.dumps(line) + "\n").encode())

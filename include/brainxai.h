@@ -270,6 +270,14 @@ int bx_attention_bwd(const float* dout, const float* dattn, const float* x, cons
  * sample sharing one activation).  cam fp32 [n_maps,HW]; weights_out fp32 [n_maps,C] may be NULL. */
 int bx_gradcam_reduce(const void* A, const void* G, float* cam, float* weights_out, int n_maps, int maps_per_act,
                       int HW, int C, int relu, int dtype, bxStream stream);
+/* Grad-CAM at the last stage of the multimodal model in one launch (canonical definition; the reference ships none, SURVEY fact
+ * 3; heads = models.py:103-106 and XAI_Multimodality.py:1095-1105).  A: stage output NHWC [B,HW,C] (dtype); eeg_logp fp32 [B,N]
+ * (EEG branch's log-probs); fc_* = Spectrogram_Model.fc, w1/b1 = fc1 [Hd,2N], w2/b2 = fc2 [N,Hd].  class_mode -2: every class
+ * (nm = N maps per sample), -1: each sample's arg-max class, >= 0: that class (nm = 1).  Outputs: out_logp fp32 [B,N] (nullable),
+ * cam fp32 [B*nm,HW] (ReLU'd iff relu), raw fp32 [B*nm,HW] (pre-ReLU, nullable), weights_out fp32 [B*nm,C] (nullable). */
+int bx_gradcam_head(const void* A, const float* eeg_logp, const float* fc_w, const float* fc_b, const float* w1, const float* b1,
+                    const float* w2, const float* b2, float* out_logp, float* cam, float* raw, float* weights_out, int B, int HW,
+                    int C, int N, int Hd, int class_mode, int relu, int dtype, bxStream stream);
 /* Bilinear resize (align_corners=False) of fp32 maps [N,h,w] -> [N,H,W]  (F.interpolate). */
 int bx_resize_bilinear(const float* src, float* dst, int N, int h, int w, int H, int W, bxStream stream);
 /* Saliency reduce (NB:3121-3129): out[b,p] = scale * max_c |g[b,p,c]|, g NHWC `dtype` (first C of Cs). */
@@ -325,8 +333,19 @@ int bx_spec_preprocess(const float* raw, const int* offsets, float* out, int B, 
 /* p, g, m, v fp32 [n]; step_count device float[1]: incremented by this call, then used as t. */
 int bx_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float grad_scale, float* step_count, bxStream stream);
+/* The same step with the hyper-parameters in DEVICE memory, hyper fp32[8] = {lr, beta1, beta2, eps, weight_decay, grad_scale,
+ * l2_lambda, unused} (a captured hipGraph follows a learning-rate schedule without re-capture), and with the DDP loop's manual
+ * L2 penalty fused in (root/src/training/training_distributed.py:52-57: total_loss = loss + l2_lambda * sum p^2): 2*l2_lambda*p
+ * is added to the scaled gradient before the moment updates; when sumsq_partials (fp32[bx_adamw_partials(n)]) and l2_value
+ * (fp32[1]) are given, l2_value[0] = l2_lambda * sum p^2 over the parameters BEFORE this update (fixed-order sum). */
+size_t bx_adamw_partials(size_t n);
+int bx_adamw_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, float* step_count,
+                      float* sumsq_partials, float* l2_value, bxStream stream);
 /* sum of squares of a flat fp32 arena -> out[1] (DDP loop's manual L2 term, DDP:52-53). */
 int bx_sumsq(const float* x, size_t n, float* out, bxStream stream);
+/* attribution seeds: seed fp32 [rows,N], row r = onehot(class of sample r % B); class_mode >= 0: that class, -1: arg-max of
+ * logp fp32 [B,N] (first maximum).  Replaces the reference's output[0, argmax] indexing (XAI_Multimodality.py:3110-3111). */
+int bx_class_seed(const float* logp, float* seed, int rows, int B, int N, int class_mode, bxStream stream);
 /* dropout seed stream: out[0] = ++state[0] (a forward call and its backward read the same `out`). */
 int bx_seed_next(uint64_t* state, uint64_t* out, bxStream stream);
 /* two independent counters advanced by one launch (the two branches of the multimodal model draw one seed each per step) */

@@ -107,6 +107,7 @@ SIGNATURES = {
     "bx_attention_fwd": (i32, [vp] * 10 + [i32, i32, i32, vp]),
     "bx_attention_bwd": (i32, [vp] * 16 + [sz, i32, i32, i32, vp]),
     "bx_gradcam_reduce": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "bx_gradcam_head": (i32, [vp] * 12 + [i32] * 8 + [vp]),
     "bx_resize_bilinear": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "bx_saliency_reduce": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "bx_axpby": (i32, [vp, vp, sz, f32, f32, vp]),
@@ -121,7 +122,10 @@ SIGNATURES = {
     "bx_spec_preprocess": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_double),
                                  f32, vp, vp, sz, vp]),
     "bx_adamw_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, f32, vp, vp]),
+    "bx_adamw_partials": (sz, [sz]),
+    "bx_adamw_step_dev": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
     "bx_sumsq": (i32, [vp, sz, vp, vp]),
+    "bx_class_seed": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "bx_seed_next": (i32, [vp, vp, vp]),
     "bx_seed_next2": (i32, [vp, vp, vp, vp, vp]),
 }

@@ -65,6 +65,169 @@ extern "C" int bx_gradcam_reduce(const void* A, const void* G, float* cam, float
 }
 
 // ------------------------------------------------------------------------------------------------
+// Grad-CAM at the LAST stage of the multimodal model in ONE launch (one workgroup per sample).  The stage output A feeds
+// GAP -> fc -> LogSoftmax -> [cat with the EEG log-probs] -> fc1 -> ReLU -> fc2 -> LogSoftmax directly, so the gradient of a class
+// score with respect to A is the same at every position, dgap/HW, and the Grad-CAM channel weights are w = dgap/HW: the kernel
+// runs the two heads forward, their backward for every requested class (class_mode -2: all N classes, -1: the sample's arg-max
+// class, >= 0: that class), and the channel reduce cam[p] = sum_k w[k] A[p][k] -- what used to be 4 library launches plus 7
+// framework launches (argmax, scatter, four repeat_interleave, ...) and a materialised gradient tensor [B*N, HW, C].
+template <typename T>
+__global__ __launch_bounds__(256) void k_gradcam_head(const T* __restrict__ A, const float* __restrict__ e_lp, const float* __restrict__ fcw,
+                                                       const float* __restrict__ fcb, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ out_lp,
+                                                       float* __restrict__ cam, float* __restrict__ raw, float* __restrict__ wout,
+                                                       int HW, int C, int N, int Hd, int class_mode, int relu) {
+  extern __shared__ float sm[];
+  float* gap = sm;                 // [C]
+  float* w = gap + C;              // [C]
+  float* hid = w + C;              // [Hd]
+  float* dhid = hid + Hd;          // [Hd]
+  float* cat = dhid + Hd;          // [2N]   EEG log-probs | spectrogram log-probs
+  float* lp = cat + 2 * N;         // [N]    fused output log-probs
+  float* dz = lp + N;              // [N]
+  float* ds = dz + N;              // [N]
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const T* a = A + (size_t)b * HW * C;
+  const float inv_hw = 1.f / (float)HW;
+  // ---- forward: GAP.  C/8 channel groups x (256 / (C/8)) position slots run in parallel (16-byte loads, coalesced along C),
+  // then a fixed-order column sum over the slots
+  {
+    const int ncg = C / 8, slots = 256 / ncg;                // host guarantees C = 8 * 2^k <= 2048
+    float* part = ds + N;                                     // [slots][C] scratch behind the small vectors
+    const int cg = tid % ncg, slot = tid / ncg;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p = slot; p < HW; p += slots) {
+      float v[8];
+      ld8(a, (size_t)p * C + cg * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[slot * C + cg * 8 + j] = acc[j];
+    __syncthreads();
+    for (int k = tid; k < C; k += 256) {
+      float t = 0.f;
+      for (int sl = 0; sl < slots; ++sl) t += part[sl * C + k];
+      gap[k] = t * inv_hw;
+    }
+  }
+  if (tid < N) cat[tid] = e_lp[(size_t)b * N + tid];
+  __syncthreads();
+  // ---- fc + LogSoftmax (spectrogram branch head)
+  for (int n = wave; n < N; n += 4) {
+    float acc = 0.f;
+    for (int k = lane; k < C; k += 64) acc = fmaf(fcw[(size_t)n * C + k], gap[k], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) ds[n] = acc + fcb[n];             // logits parked in ds
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mx = -INFINITY;
+    for (int n = 0; n < N; ++n) mx = fmaxf(mx, ds[n]);
+    float se = 0.f;
+    for (int n = 0; n < N; ++n) se += expf(ds[n] - mx);
+    const float lse = mx + logf(se);
+    for (int n = 0; n < N; ++n) cat[N + n] = ds[n] - lse;
+  }
+  __syncthreads();
+  // ---- fusion head forward
+  for (int j = tid; j < Hd; j += 256) {
+    float acc = b1[j];
+    for (int i = 0; i < 2 * N; ++i) acc = fmaf(w1[(size_t)j * 2 * N + i], cat[i], acc);
+    hid[j] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  for (int n = wave; n < N; n += 4) {
+    float acc = 0.f;
+    for (int j = lane; j < Hd; j += 64) acc = fmaf(w2[(size_t)n * Hd + j], hid[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) dz[n] = acc + b2[n];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mx = -INFINITY;
+    for (int n = 0; n < N; ++n) mx = fmaxf(mx, dz[n]);
+    float se = 0.f;
+    for (int n = 0; n < N; ++n) se += expf(dz[n] - mx);
+    const float lse = mx + logf(se);
+    for (int n = 0; n < N; ++n) { lp[n] = dz[n] - lse; if (out_lp) out_lp[(size_t)b * N + n] = lp[n]; }
+  }
+  __syncthreads();
+  int first = class_mode, nm = 1;
+  if (class_mode == -2) { first = 0; nm = N; }
+  else if (class_mode == -1) {                          // first maximum, like torch.argmax
+    first = 0;
+    for (int n = 1; n < N; ++n) if (lp[n] > lp[first]) first = n;
+  }
+  for (int ci = 0; ci < nm; ++ci) {
+    const int c = first + ci;
+    // ---- backward of the fused head for the score y_c = lp[c]:  d logits = onehot(c) - softmax
+    if (tid < N) dz[tid] = (tid == c ? 1.f : 0.f) - expf(lp[tid]);
+    __syncthreads();
+    for (int j = tid; j < Hd; j += 256) {
+      float acc = 0.f;
+      for (int n = 0; n < N; ++n) acc = fmaf(w2[(size_t)n * Hd + j], dz[n], acc);
+      dhid[j] = hid[j] > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    for (int i = wave; i < N; i += 4) {                  // gradient w.r.t. the spectrogram branch's log-probs
+      float acc = 0.f;
+      for (int j = lane; j < Hd; j += 64) acc = fmaf(w1[(size_t)j * 2 * N + N + i], dhid[j], acc);
+      acc = wave_sum(acc);
+      if (lane == 0) ds[i] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {                                      // through LogSoftmax: dz_s = ds - softmax * sum(ds)
+      float tot = 0.f;
+      for (int i = 0; i < N; ++i) tot += ds[i];
+      for (int i = 0; i < N; ++i) ds[i] -= expf(cat[N + i]) * tot;
+    }
+    __syncthreads();
+    float* wdst = wout ? wout + ((size_t)b * nm + ci) * C : nullptr;
+    for (int k = tid; k < C; k += 256) {                 // through fc and the mean over positions: w = W_fc^T dz_s / HW
+      float acc = 0.f;
+      for (int i = 0; i < N; ++i) acc = fmaf(fcw[(size_t)i * C + k], ds[i], acc);
+      acc *= inv_hw;
+      w[k] = acc;
+      if (wdst) wdst[k] = acc;
+    }
+    __syncthreads();
+    const size_t mbase = ((size_t)b * nm + ci) * HW;
+    for (int p = wave; p < HW; p += 4) {
+      float acc = 0.f;
+      for (int k0 = lane * 8; k0 < C; k0 += 512) {
+        float v[8];
+        ld8(a, (size_t)p * C + k0, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf(w[k0 + j], v[j], acc);
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) {
+        cam[mbase + p] = relu ? fmaxf(acc, 0.f) : acc;
+        if (raw) raw[mbase + p] = acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int bx_gradcam_head(const void* A, const float* eeg_logp, const float* fc_w, const float* fc_b, const float* w1, const float* b1,
+                               const float* w2, const float* b2, float* out_logp, float* cam, float* raw, float* weights_out, int B, int HW,
+                               int C, int N, int Hd, int class_mode, int relu, int dtype, bxStream stream) {
+  BX_DTYPE_OK(dtype);
+  BX_REQUIRE(A && eeg_logp && fc_w && fc_b && w1 && b1 && w2 && b2 && cam, "bx_gradcam_head: null pointer");
+  BX_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C >= 8 && C <= 2048 && 256 % (C / 8) == 0 && N > 0 && N <= 64 && Hd > 0 && Hd <= 4096,
+             "bx_gradcam_head: unsupported sizes (C=%d must be 8*2^k <= 2048, N=%d <= 64, Hd=%d <= 4096)", C, N, Hd);
+  BX_REQUIRE(class_mode >= -2 && class_mode < N, "bx_gradcam_head: class %d out of range", class_mode);
+  const size_t lds = ((size_t)2 * C + 2 * Hd + 5 * N + (size_t)(256 / (C / 8)) * C) * sizeof(float);
+  BX_DISPATCH_DTYPE(dtype, T,
+    hipLaunchKernelGGL((k_gradcam_head<T>), dim3(B), dim3(256), lds, (hipStream_t)stream, (const T*)A, eeg_logp, fc_w, fc_b, w1, b1, w2, b2,
+                       out_logp, cam, raw, weights_out, HW, C, N, Hd, class_mode, relu));
+  BX_CHECK_LAUNCH("bx_gradcam_head");
+  return BX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ void k_resize_bilinear(const float* __restrict__ src, float* __restrict__ dst, long long n, int h, int w, int H, int W,
                                   float sy, float sx) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {

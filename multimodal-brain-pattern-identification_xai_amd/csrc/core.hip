@@ -237,6 +237,79 @@ extern "C" int bx_adamw_step(float* p, const float* g, float* m, float* v, size_
   return BX_OK;
 }
 
+// The same update with (i) every hyper-parameter read from a device buffer -- a captured hipGraph then follows a learning-rate
+// schedule without being re-captured -- and (ii) the DDP loop's manual L2 penalty (training_distributed.py:52-53,
+// total_loss = loss + lambda * sum p^2) folded in: its gradient 2*lambda*p joins g before the moments are updated (identical on
+// every rank, so adding it after the all-reduce equals adding it before) and each workgroup leaves sum p^2 of its slice (of the
+// parameters BEFORE the update, i.e. of the forward pass's weights) in sumsq_partials[blockIdx.x] for a fixed-order total.
+// hyper[8] = {lr, beta1, beta2, eps, weight_decay, grad_scale, l2_lambda, unused}.
+__global__ __launch_bounds__(256) void k_adamw_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n, const float* __restrict__ hyper,
+                                                   const float* __restrict__ step, float* __restrict__ sumsq_partials) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], gscale = hyper[5], l2 = 2.f * hyper[6];
+  const float t = step[0];
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  const size_t n4 = n / 4;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float ss = 0.f;
+  if (i < n4) {
+    float4 pv = reinterpret_cast<float4*>(p)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    ss = pv.x * pv.x + pv.y * pv.y + pv.z * pv.z + pv.w * pv.w;
+    adamw_one(pv.x, gv.x * gscale + l2 * pv.x, mv.x, vv.x, lr, b1, b2, eps, wd, 1.f, step_size, inv_sqrt_bc2);
+    adamw_one(pv.y, gv.y * gscale + l2 * pv.y, mv.y, vv.y, lr, b1, b2, eps, wd, 1.f, step_size, inv_sqrt_bc2);
+    adamw_one(pv.z, gv.z * gscale + l2 * pv.z, mv.z, vv.z, lr, b1, b2, eps, wd, 1.f, step_size, inv_sqrt_bc2);
+    adamw_one(pv.w, gv.w * gscale + l2 * pv.w, mv.w, vv.w, lr, b1, b2, eps, wd, 1.f, step_size, inv_sqrt_bc2);
+    reinterpret_cast<float4*>(p)[i] = pv; reinterpret_cast<float4*>(m)[i] = mv; reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t j = n4 * 4 + threadIdx.x;
+    float pj = p[j], mj = m[j], vj = v[j];
+    ss += pj * pj;
+    adamw_one(pj, g[j] * gscale + l2 * pj, mj, vj, lr, b1, b2, eps, wd, 1.f, step_size, inv_sqrt_bc2);
+    p[j] = pj; m[j] = mj; v[j] = vj;
+  }
+  if (sumsq_partials) {                                      // wave-uniform branch
+    __shared__ float part[4];
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) sumsq_partials[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+  }
+}
+// fixed-order sum of the per-workgroup partials, scaled by hyper[6] (= lambda): out[0] = lambda * sum p^2
+__global__ __launch_bounds__(1024) void k_l2_finalize(const float* __restrict__ part, size_t n, const float* __restrict__ hyper,
+                                                       float* __restrict__ out) {
+  __shared__ double wsum[16];
+  double acc = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += 1024) acc += (double)part[i];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += wsum[w];
+    out[0] = (float)(t * (double)hyper[6]);
+  }
+}
+extern "C" size_t bx_adamw_partials(size_t n) { return (n / 4 + 255) / 256 + 1; }
+extern "C" int bx_adamw_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, float* step_count,
+                                 float* sumsq_partials, float* l2_value, bxStream stream) {
+  BX_REQUIRE(p && g && m && v && hyper && step_count, "bx_adamw_step_dev: null pointer");
+  BX_REQUIRE((sumsq_partials == nullptr) == (l2_value == nullptr), "bx_adamw_step_dev: sumsq_partials and l2_value go together");
+  if (n == 0) return BX_OK;
+  BX_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "bx_adamw_step_dev: arenas must be 16-byte aligned");
+  hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step_count);
+  const size_t nblk = (n / 4 + 255) / 256;
+  const unsigned grid = (unsigned)(nblk ? nblk : 1);
+  hipLaunchKernelGGL(k_adamw_dev, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper, step_count, sumsq_partials);
+  if (sumsq_partials)
+    hipLaunchKernelGGL(k_l2_finalize, dim3(1), dim3(1024), 0, (hipStream_t)stream, sumsq_partials, (size_t)grid, hyper, l2_value);
+  BX_CHECK_LAUNCH("bx_adamw_step_dev");
+  return BX_OK;
+}
+
 __global__ void k_sumsq(const float* __restrict__ x, size_t n, float* __restrict__ out) {
   // single workgroup, fixed order -> deterministic
   __shared__ float part[16];
@@ -255,6 +328,26 @@ extern "C" int bx_sumsq(const float* x, size_t n, float* out, bxStream stream) {
   BX_REQUIRE(x && out, "bx_sumsq: null pointer");
   hipLaunchKernelGGL(k_sumsq, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);
   BX_CHECK_LAUNCH("bx_sumsq");
+  return BX_OK;
+}
+
+// gradient seeds for attribution: seed[r][:] = onehot(class of sample r % B), the class being class_mode (>= 0) or the arg-max of
+// logp[r % B] (first maximum, like torch.argmax) -- replaces zeros + argmax + scatter_ (+ repeat) framework launches
+__global__ void k_class_seed(const float* __restrict__ logp, float* __restrict__ seed, int R, int B, int N, int class_mode) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  int c = class_mode;
+  if (c < 0) {
+    const float* row = logp + (size_t)(r % B) * N;
+    c = 0;
+    for (int n = 1; n < N; ++n) if (row[n] > row[c]) c = n;
+  }
+  for (int n = 0; n < N; ++n) seed[(size_t)r * N + n] = n == c ? 1.f : 0.f;
+}
+extern "C" int bx_class_seed(const float* logp, float* seed, int rows, int B, int N, int class_mode, bxStream stream) {
+  BX_REQUIRE(seed && rows > 0 && B > 0 && N > 0 && class_mode < N && (class_mode >= 0 || logp), "bx_class_seed: bad arguments");
+  hipLaunchKernelGGL(k_class_seed, dim3(bx_ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream, logp, seed, rows, B, N, class_mode);
+  BX_CHECK_LAUNCH("bx_class_seed");
   return BX_OK;
 }
 

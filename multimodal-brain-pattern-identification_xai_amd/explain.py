@@ -43,9 +43,14 @@ def _resolve(model, dotted):
     return mod
 
 
-def _one_hot_rows(idx: torch.Tensor, n: int) -> torch.Tensor:
-    seed = torch.zeros(idx.shape[0], n, dtype=torch.float32, device=idx.device)
-    seed.scatter_(1, idx[:, None], 1.0)
+def _class_seed(out: torch.Tensor, class_mode: int, rows=None) -> torch.Tensor:
+    """[rows, n_classes] one-hot gradient seeds: row r selects class ``class_mode`` (>= 0) or the arg-max class of
+    ``out[r % B]`` (-1); one library launch (bx_class_seed)."""
+    B, n = out.shape
+    rows = B if rows is None else rows
+    seed = torch.empty(rows, n, dtype=torch.float32, device=out.device)
+    logp = out.detach().float().contiguous()
+    L.check(L.load().bx_class_seed(_p(logp), _p(seed), rows, B, n, int(class_mode), _stream()), "bx_class_seed")
     return seed
 
 
@@ -73,46 +78,33 @@ _TARGET = re.compile(r"^(?:spectrogram_model\.)?block([1-5])(?:\.conv([1-3]))?$"
 
 
 def _grad_cam_last_stage(model, eeg, spec, class_idx, upsample, relu, return_parts):
-    """Default target (the last stage feeds the heads directly): no autograd at all.  One forward, then the
-    backward of the two tiny heads for ALL requested classes at once (the class axis is folded into the batch of
-    bx_fusion_head_bwd / bx_gap_fc_lsm_bwd), then the fused channel reduce -- a handful of launches per batch."""
+    """Default target (the last stage feeds the heads directly): no autograd and no framework arithmetic at all.  The two
+    branches run forward, then ONE launch (bx_gradcam_head) does both heads forward, their backward for every requested class
+    and the activation x gradient channel reduce; a second launch upsamples the maps."""
     lib = L.load()
     sm = model.spectrogram_model
+    if class_idx is None:
+        mode = -1
+    elif isinstance(class_idx, str):
+        if class_idx != "all":
+            raise ValueError(class_idx)
+        mode = -2
+    else:
+        mode = int(class_idx)
     with torch.no_grad():
         e = model.eeg_model(eeg).contiguous()
         A = sm.features(spec).permute(0, 2, 3, 1).contiguous()
         B, h, w, C = A.shape
         N, Hd = model.fc2.out_features, model.fc1.out_features
+        nm = N if mode == -2 else 1
         dev = A.device
-        gap = torch.empty(B, C, dtype=torch.float32, device=dev)
-        s_lp = torch.empty(B, N, dtype=torch.float32, device=dev)
-        L.check(lib.bx_gap_fc_lsm_fwd(_p(A), _p(sm.fc.weight), _p(sm.fc.bias), _p(gap), _p(s_lp), B, h * w, C, N, ops.bx_dtype(A.dtype), _stream()),
-                "bx_gap_fc_lsm_fwd")
-        hidden = torch.empty(B, Hd, dtype=torch.float32, device=dev)
         out = torch.empty(B, N, dtype=torch.float32, device=dev)
-        L.check(lib.bx_fusion_head_fwd(_p(e), _p(s_lp), _p(model.fc1.weight), _p(model.fc1.bias), _p(model.fc2.weight), _p(model.fc2.bias),
-                                       _p(hidden), _p(out), B, N, Hd, _stream()), "bx_fusion_head_fwd")
-        if class_idx is None:
-            nm, cls = 1, out.argmax(1)
-        elif isinstance(class_idx, str):
-            if class_idx != "all":
-                raise ValueError(class_idx)
-            nm, cls = N, torch.arange(N, device=dev).repeat(B)
-        else:
-            nm, cls = 1, torch.full((B,), int(class_idx), dtype=torch.int64, device=dev)
-        rep = (lambda t: t.repeat_interleave(nm, 0).contiguous()) if nm > 1 else (lambda t: t)
-        seeds = _one_hot_rows(cls, N)                                       # [B*nm, N], map index = sample*nm + class
-        d_s = torch.empty(B * nm, N, dtype=torch.float32, device=dev)
-        # keep the repeated operands alive until the launches are queued (a temporary freed right after data_ptr()
-        # would hand its memory to the next allocation)
-        r_out, r_hid, r_e, r_s = rep(out), rep(hidden), rep(e), rep(s_lp)
-        L.check(lib.bx_fusion_head_bwd(_p(seeds), _p(r_out), _p(r_hid), _p(r_e), _p(r_s), _p(model.fc1.weight),
-                                       _p(model.fc2.weight), None, _p(d_s), None, None, None, None, B * nm, N, Hd, _stream()), "bx_fusion_head_bwd")
-        G = torch.empty(B * nm, h, w, C, dtype=A.dtype, device=dev)
-        L.check(lib.bx_gap_fc_lsm_bwd(_p(d_s), _p(r_s), _p(gap), _p(sm.fc.weight), _p(G), None, None, B * nm, h * w, C, N,
-                                      ops.bx_dtype(A.dtype), _stream()), "bx_gap_fc_lsm_bwd")
-        cam, wts = _reduce(A, G, nm, relu=relu)
-        raw = _reduce(A, G, nm, relu=False)[0] if (return_parts and relu) else cam
+        cam = torch.empty(B * nm, h, w, dtype=torch.float32, device=dev)
+        raw = torch.empty_like(cam) if return_parts else None
+        wts = torch.empty(B * nm, C, dtype=torch.float32, device=dev) if return_parts else None
+        L.check(lib.bx_gradcam_head(_p(A), _p(e), _p(sm.fc.weight), _p(sm.fc.bias), _p(model.fc1.weight), _p(model.fc1.bias),
+                                    _p(model.fc2.weight), _p(model.fc2.bias), _p(out), _p(cam), _p(raw), _p(wts), B, h * w, C, N, Hd, mode,
+                                    1 if relu else 0, ops.bx_dtype(A.dtype), _stream()), "bx_gradcam_head")
         if upsample:
             cam = resize_bilinear(cam, spec.shape[-2:])
     stacked = isinstance(class_idx, str)
@@ -123,10 +115,11 @@ def _grad_cam_last_stage(model, eeg, spec, class_idx, upsample, relu, return_par
 
 
 class GradCamSweep:
-    """Grad-CAM at the default target replayed from a captured hipGraph -- for sweeps over many batches of one shape
-    (BASELINE configs[3]: 10 000 samples, all classes).  The ~45 launches of `grad_cam` are captured once on static input
-    buffers; a call copies the batch in and replays them, so the sweep runs at GPU speed instead of at the host's launch
-    rate.  The returned tensor is the graph's static output buffer: clone it if it must outlive the next call.
+    """Grad-CAM at the default target replayed from captured hipGraphs -- for sweeps over many batches (BASELINE configs[3]:
+    10 000 samples, all classes).  The launches of `grad_cam` are captured once per batch shape on static input buffers (the
+    ragged last batch of a sweep gets its own capture the first time it is seen); a call copies the batch in and replays them,
+    so the sweep runs at GPU speed instead of at the host's launch rate.  The returned tensor is that graph's static output
+    buffer: clone it if it must outlive the next call with the same shape.
 
         sweep = GradCamSweep(model, eeg_batch, spec_batch, class_idx="all")
         for eeg, spec in loader:
@@ -137,7 +130,13 @@ class GradCamSweep:
         if not (eeg.is_cuda and spec.is_cuda):
             raise RuntimeError("brainxai.GradCamSweep needs CUDA tensors; there is no CPU path")
         self.model, self.args = model, (class_idx, upsample, relu)
-        self.eeg, self.spec = eeg.detach().clone().contiguous(), spec.detach().clone().contiguous()
+        self._graphs = {}
+        self._capture(eeg, spec)
+
+    def _capture(self, eeg, spec):
+        model = self.model
+        class_idx, upsample, relu = self.args
+        s_eeg, s_spec = eeg.detach().clone().contiguous(), spec.detach().clone().contiguous()
         was_training = model.training
         model.eval()
         try:
@@ -145,22 +144,74 @@ class GradCamSweep:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):                       # allocate workspaces / pack tables on the capture stream
-                    _grad_cam_last_stage(model, self.eeg, self.spec, class_idx, upsample, relu, False)
+                    _grad_cam_last_stage(model, s_eeg, s_spec, class_idx, upsample, relu, False)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = _grad_cam_last_stage(model, self.eeg, self.spec, class_idx, upsample, relu, False)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = _grad_cam_last_stage(model, s_eeg, s_spec, class_idx, upsample, relu, False)
         finally:
             model.train(was_training)
+        entry = (graph, s_eeg, s_spec, out)
+        self._graphs[(tuple(eeg.shape), tuple(spec.shape))] = entry
+        return entry
 
     def __call__(self, eeg, spec):
-        if eeg.shape != self.eeg.shape or spec.shape != self.spec.shape:
-            raise RuntimeError(f"GradCamSweep was captured for {tuple(self.eeg.shape)} / {tuple(self.spec.shape)}")
-        self.eeg.copy_(eeg, non_blocking=True)
-        self.spec.copy_(spec, non_blocking=True)
-        self.graph.replay()
-        return self.out
+        entry = self._graphs.get((tuple(eeg.shape), tuple(spec.shape)))
+        if entry is None:
+            if eeg.shape[0] != spec.shape[0] or eeg.shape[0] == 0:
+                raise RuntimeError(f"GradCamSweep: bad batch {tuple(eeg.shape)} / {tuple(spec.shape)}")
+            entry = self._capture(eeg, spec)
+        graph, s_eeg, s_spec, out = entry
+        s_eeg.copy_(eeg, non_blocking=True)
+        s_spec.copy_(spec, non_blocking=True)
+        graph.replay()
+        return out
+
+
+def shard_bounds(n: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of ``n`` samples for ``rank`` of ``world``: sizes differ by at most one, lower ranks take the
+    remainder, every sample belongs to exactly one rank (attribution sweeps shard by sample, no collective)."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def sharded_sweep(fn, n_samples, batch_size, fetch, rank=None, world=None, gather=True, group=None):
+    """Run an attribution ``fn`` over ``n_samples`` samples sharded contiguously over the ranks of the process group
+    (BASELINE configs[3] / configs[4]).  ``fetch(lo, hi)`` returns the inputs (a tuple of tensors) of samples [lo, hi) already on
+    this rank's device; ``fn(*inputs)`` returns a tensor whose first axis is the sample axis (e.g. Grad-CAM maps [b, 6, H, W]
+    from a GradCamSweep, or integrated-gradients attributions).  Each rank walks its shard in batches of ``batch_size`` (the last
+    one ragged).  ``gather=True``: rank 0 returns the [n_samples, ...] result in sample order (one padded ``dist.gather``), the
+    other ranks None; ``gather=False``: every rank returns (lo, its shard's result).  Without a process group: one shard."""
+    import torch.distributed as dist
+    have_pg = dist.is_available() and dist.is_initialized()
+    if rank is None:
+        rank = dist.get_rank(group) if have_pg else 0
+    if world is None:
+        world = dist.get_world_size(group) if have_pg else 1
+    lo, hi = shard_bounds(n_samples, rank, world)
+    parts = []
+    for b0 in range(lo, hi, batch_size):
+        b1 = min(hi, b0 + batch_size)
+        parts.append(fn(*fetch(b0, b1)).clone())         # clone: fn may return a static graph buffer
+    mine = torch.cat(parts) if parts else None
+    if not gather:
+        return lo, mine
+    if world == 1:
+        return mine
+    # every rank needs the trailing shape to build its padded block: take it from a rank that has samples
+    cap = shard_bounds(n_samples, 0, world)[1]           # rank 0 holds the largest shard
+    if mine is None:
+        raise RuntimeError("sharded_sweep(gather=True) needs at least one sample per rank; use gather=False for tiny sweeps")
+    pad = torch.zeros(cap, *mine.shape[1:], dtype=mine.dtype, device=mine.device)
+    pad[:mine.shape[0]] = mine
+    blocks = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, blocks, dst=0, group=group)
+    if rank != 0:
+        return None
+    sizes = [shard_bounds(n_samples, r, world) for r in range(world)]
+    return torch.cat([blk[:b - a] for blk, (a, b) in zip(blocks, sizes)])
 
 
 def grad_cam(model, eeg, spec, target_layer="spectrogram_model.block5", class_idx=None, upsample=True, relu=True,
@@ -205,13 +256,13 @@ def grad_cam(model, eeg, spec, target_layer="spectrogram_model.block5", class_id
         n_cls = out.shape[1]
         B = out.shape[0]
         if class_idx is None:
-            seeds = [_one_hot_rows(out.detach().argmax(1), n_cls)]
+            seeds = [_class_seed(out, -1)]
         elif isinstance(class_idx, str):
             if class_idx != "all":
                 raise ValueError(class_idx)
-            seeds = [_one_hot_rows(torch.full((B,), c, dtype=torch.int64, device=out.device), n_cls) for c in range(n_cls)]
+            seeds = [_class_seed(out, c) for c in range(n_cls)]
         else:
-            seeds = [_one_hot_rows(torch.full((B,), int(class_idx), dtype=torch.int64, device=out.device), n_cls)]
+            seeds = [_class_seed(out, int(class_idx))]
         try:
             grads = []
             for sd in seeds:
@@ -253,7 +304,7 @@ def saliency(model, eeg, spec, reference_quirk=False):
         e = eeg.detach().clone().float().requires_grad_(True)
         s = spec.detach().clone().float().requires_grad_(True)
         out = model(e, s)
-        seed = _one_hot_rows(out.detach().argmax(1), out.shape[1])
+        seed = _class_seed(out, -1)
         ge, gs = torch.autograd.grad(out, (e, s), grad_outputs=seed)
     B, Cc, H, W = gs.shape
     g_nhwc = ops.to_nhwc(gs, torch.float32)
@@ -303,11 +354,9 @@ def integrated_gradients(model, inputs, baselines=None, target=None, n_steps=50,
     steps_dev = torch.tensor([float(w) for w in steps], dtype=torch.float32, device=eeg.device)
     per_pass = max(1, max_batch // B)
     with _eval_frozen(model):
-        if target is None:
-            with torch.no_grad():
-                tgt = model(eeg, spec).argmax(1)
-        else:
-            tgt = torch.full((B,), int(target), dtype=torch.int64, device=eeg.device)
+        with torch.no_grad():
+            base_out = model(eeg, spec)                     # arg-max class of the un-interpolated input (Captum: target of the input)
+        tmode = -1 if target is None else int(target)
         for k0 in range(0, n_steps, per_pass):
             ks = range(k0, min(n_steps, k0 + per_pass))
             xe = torch.empty(len(ks), *eeg.shape, dtype=torch.float32, device=eeg.device)
@@ -319,7 +368,7 @@ def integrated_gradients(model, inputs, baselines=None, target=None, n_steps=50,
             xe = xe.flatten(0, 1).requires_grad_(True)
             xs = xs.flatten(0, 1).requires_grad_(True)
             out = model(xe, xs)
-            seed = _one_hot_rows(tgt.repeat(len(ks)), out.shape[1])
+            seed = _class_seed(base_out, tmode, rows=len(ks) * B)      # row k*B + b -> class of sample b
             ge, gs = torch.autograd.grad(out, (xe, xs), grad_outputs=seed)
             ge, gs = ge.contiguous(), gs.contiguous()
             L.check(lib_.bx_ig_accumulate(_p(ge), _p(w_dev), _p(acc_e), acc_e.numel(), len(ks), _stream()), "bx_ig_accumulate")
@@ -361,7 +410,7 @@ def expected_gradients(model, x, background, nsamples=200, seed=0, max_batch=256
                 xi.requires_grad_(True)
                 y = model(xi)
                 for c in range(n_cls):
-                    seed_c = _one_hot_rows(torch.full((len(ks),), c, dtype=torch.int64, device=x.device), n_cls)
+                    seed_c = _class_seed(y, c)
                     (g,) = torch.autograd.grad(y, xi, grad_outputs=seed_c, retain_graph=True)
                     g = g.contiguous()
                     L.check(lib.bx_mul(_p(g), _p(diff), _p(g), g.numel(), _stream()), "bx_mul")

@@ -48,6 +48,7 @@ class Block(nn.Module):
         self.salt = 0
         self._preact = 0          # set by explain.grad_cam for targets "blockN.convK"
         self._capture = None
+        self._keep = None         # set by ops.keep_block_activations (parity tooling)
         self._prepacked, self._pack_base = None, 0      # set per forward by Spectrogram_Model (one pack launch for all stages)
         self._seed = None                               # idem: one dropout seed launch for all stages
 
@@ -64,7 +65,8 @@ class Block(nn.Module):
         bn = self.bn
         cfg = ops.block_cfg(pool=self.pool_type, training=self.training, dropout_p=self.dropout.p if self.training else 0.0,
                             eps=bn.eps, momentum=0.1 if bn.momentum is None else bn.momentum, salt=self.salt,
-                            preact=self._preact, capture=self._capture, prepacked=self._prepacked, pack_base=self._pack_base, seed=self._seed)
+                            preact=self._preact, capture=self._capture, prepacked=self._prepacked, pack_base=self._pack_base, seed=self._seed,
+                            keep=self._keep)
         out = ops.BlockFn.apply(xi, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.conv3.weight,
                                 self.conv3.bias, bn.weight, bn.bias, self.conv1x1.weight, self.conv1x1.bias,
                                 bn.running_mean, bn.running_var, bn.num_batches_tracked, cfg)
@@ -108,7 +110,10 @@ class Spectrogram_Model(nn.Module):
             blk._prepacked, blk._pack_base = plan, 3 * bi
         return xi
 
-    def features(self, x, seed=None):
+    def features(self, x, seed=None, cut=None):
+        """``cut = (k, fn)``: the activation leaving stage k is handed to ``fn`` and its return value feeds stage k+1 -- the
+        data-parallel step uses it to cut autograd there (fn detaches), so that the gradients of the late stages (88 % of the
+        parameter bytes, finished first) can be all-reduced while the early stages' backward still runs."""
         xi = self._pack_all(x)
         if xi is not None:
             x = xi                                          # already in the internal layout (same launch as the weight packing)
@@ -119,8 +124,10 @@ class Spectrogram_Model(nn.Module):
             for b in blocks:
                 b._seed = seed
         try:
-            for b in blocks:
+            for i, b in enumerate(blocks, start=1):
                 x = b(x)
+                if cut is not None and cut[0] == i:
+                    x = cut[1](x)
         finally:
             for b in blocks:
                 b._prepacked, b._seed = None, None
@@ -277,7 +284,20 @@ class MultimodalModel(nn.Module):
         self.fc2 = nn.Linear(128, num_classes)
         self.log_softmax = nn.LogSoftmax(dim=1)
 
-    def forward(self, eeg_data, spectrogram_data):
+    def forward(self, eeg_data, spectrogram_data, cut=None):
+        """``cut``: see Spectrogram_Model.features (build extension used by the overlapped data-parallel step; the reference's
+        signature is the two positional inputs, XAI_Multimodality.py:1095)."""
+        if cut is not None:
+            if not self._fusable():
+                raise RuntimeError("brainxai MultimodalModel: cut= needs the un-hooked reference architecture (fused head path)")
+            em, sm = self.eeg_model, self.spectrogram_model
+            ss = se = None
+            if self.training and em.dropout.p > 0 and any(getattr(sm, f"block{i}").dropout.p > 0 for i in range(1, 6)):
+                ss, se = ops.next_seed_pair(eeg_data.device)
+            ef = em.features(eeg_data, seed=se)
+            sf = sm.features(spectrogram_data, seed=ss, cut=cut)
+            return ops.MultimodalHeadFn.apply(sf.permute(0, 2, 3, 1), ef, sm.fc.weight, sm.fc.bias, em.dense.weight, em.dense.bias,
+                                              self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
         if ops.OVERLAP and eeg_data.is_cuda and ops.CONV_PROFILE is None:
             # the EEG branch (small, latency-bound kernels) runs on a side stream beside the spectrogram branch; autograd
             # replays each branch's backward on the stream its forward ran on, so the backward overlaps too

@@ -153,30 +153,62 @@ def next_seed_pair(device):
     return out[0:1], out[1:2]
 
 
-# Gradient arena hook: the trainer / DDP wrapper registers, per parameter, a callable returning a fresh
-# view into its flat fp32 gradient buffer, so weight-gradient kernels write there directly.
+# Gradient arena hook: the trainer (FlatAdamW) registers, per parameter, the slice of its flat fp32 gradient buffer, so
+# weight-gradient kernels write there directly.  Entries are keyed by the parameter's storage address (saved tensors are new
+# objects, the storage identifies the parameter) and carry a weak reference to the Parameter: a dead reference (the model was
+# dropped and the address reused) is ignored, and a live one lets new_grad() refuse to ALIAS an existing ``.grad``.
+import weakref as _weakref
+
 _GRAD_VIEW = {}
+_GRAD_KEYS = {}
+_GRAD_NEXT = [0]
 
 
 def register_grad_views(params, flat: torch.Tensor):
-    off = 0
+    """Returns a registration key for unregister_grad_views()."""
+    off, ptrs = 0, []
     for p_ in params:
         n = p_.numel()
-        _GRAD_VIEW[p_.data_ptr()] = (flat, off, tuple(p_.shape))
+        _GRAD_VIEW[p_.data_ptr()] = (flat, off, tuple(p_.shape), _weakref.ref(p_))
+        ptrs.append(p_.data_ptr())
         off += n
-    return off
+    _GRAD_NEXT[0] += 1
+    _GRAD_KEYS[_GRAD_NEXT[0]] = (ptrs, flat)
+    return _GRAD_NEXT[0]
+
+
+def unregister_grad_views(key):
+    ent = _GRAD_KEYS.pop(key, None) if key is not None else None
+    if ent is None:
+        return
+    ptrs, flat = ent
+    for ptr in ptrs:
+        cur = _GRAD_VIEW.get(ptr)
+        if cur is not None and cur[0] is flat:
+            del _GRAD_VIEW[ptr]
 
 
 def clear_grad_views():
     _GRAD_VIEW.clear()
+    _GRAD_KEYS.clear()
 
 
 def new_grad(param: torch.Tensor) -> torch.Tensor:
-    ent = _GRAD_VIEW.get(param.data_ptr())   # saved tensors are new objects; storage identifies the parameter
+    ent = _GRAD_VIEW.get(param.data_ptr())
     if ent is None:
         return torch.empty_like(param, dtype=torch.float32)
-    flat, off, shape = ent
-    return flat.narrow(0, off, param.numel()).view(shape)
+    flat, off, shape, ref = ent
+    owner = ref()
+    if owner is None or owner.data_ptr() != param.data_ptr() or tuple(owner.shape) != tuple(param.shape):
+        del _GRAD_VIEW[param.data_ptr()]                  # stale: that optimizer's model is gone, the address was reused
+        return torch.empty_like(param, dtype=torch.float32)
+    view = flat.narrow(0, off, param.numel()).view(shape)
+    if owner.grad is not None and owner.grad.data_ptr() == view.data_ptr():
+        # the kernels WRITE the arena slice and autograd would then add the slice to itself (p.grad += g, same memory):
+        # a second backward without zero_grad(), zero_grad(set_to_none=False), or a parameter used twice in one graph
+        raise RuntimeError("brainxai: this parameter's .grad already is its gradient-arena slice; gradient accumulation over several "
+                           "backward passes is not supported with FlatAdamW -- call optimizer.zero_grad() (set_to_none=True) first")
+    return view
 
 
 def pad8(c: int) -> int:
@@ -407,6 +439,8 @@ class BlockFn(torch.autograd.Function):
         ctx.save_for_backward(x, acts[1], acts[2], y3, pooled, mean, invstd, w1, b1, w2, b2, w3, b3, bnw, bnb, w11, b11)
         if pre is not None:
             cfg.capture["act"] = pre
+        if cfg.keep is not None:                            # debugging / parity tooling: see keep_block_activations()
+            cfg.keep["acts"] = (acts[1], acts[2], y3)
         return out
 
     @staticmethod
@@ -420,7 +454,9 @@ class BlockFn(torch.autograd.Function):
         dout = dout.contiguous()
         dz3 = torch.empty_like(y3)
         dx_skip = torch.empty_like(x) if need_dx else None
-        d_bnw, d_bnb = new_grad(bnw), new_grad(bnb)
+        # arena slices only for gradients autograd asked for (a frozen attribution pass must not touch the trainer's arena)
+        need_bn = ctx.needs_input_grad[7] or ctx.needs_input_grad[8]
+        d_bnw, d_bnb = (new_grad(bnw), new_grad(bnb)) if need_bn else (torch.empty_like(bnw), torch.empty_like(bnb))
         d_w11, d_b11 = (new_grad(w11), new_grad(b11)) if need_w else (None, None)
         ws = workspace(lib.bx_block_tail_workspace(C.byref(desc)), x.device)
         L.check(lib.bx_block_tail_bwd(C.byref(desc), _p(dout), _p(y3), _p(x), _p(pooled), _p(w11), w11.shape[1], _p(bnw), _p(mean), _p(invstd),
@@ -456,6 +492,8 @@ class BlockFn(torch.autograd.Function):
         if need_w and side is None:
             wgrad_flush(x.device)                           # conv1's partial sum: nothing may be pending when the gradients are returned
         dx = dz if need_dx else None
+        if not need_bn:
+            d_bnw = d_bnb = None
         return (dx, grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2], d_bnw, d_bnb, d_w11, d_b11,
                 None, None, None, None)
 
@@ -754,6 +792,19 @@ class AttentionFn(torch.autograd.Function):
 
 def block_cfg(**kw) -> SimpleNamespace:
     base = dict(pool="max", training=False, dropout_p=0.0, eps=1e-5, momentum=0.1, salt=0, preact=0, capture=None,
-                prepacked=None, pack_base=0, seed=None)
+                prepacked=None, pack_base=0, seed=None, keep=None)
     base.update(kw)
     return SimpleNamespace(**base)
+
+
+def keep_block_activations(model, on=True):
+    """Parity tooling: make every Block of ``model`` keep the post-ReLU outputs of its three convolutions from its next
+    forward (they are saved for backward anyway; this only exposes them).  Returns {module name: dict}; after a forward
+    ``dict["acts"]`` holds (y1, y2, y3) as channels-last tensors [B,H,W,C].  ``on=False`` switches it off again."""
+    out = {}
+    for name, mod in model.named_modules():
+        if hasattr(mod, "_keep"):
+            mod._keep = {} if on else None
+            if on:
+                out[name] = mod._keep
+    return out

@@ -20,26 +20,40 @@ from .ops import _p, _stream
 
 
 # ------------------------------------------------------------------------------------------------
-class FlatAdamW:
+class FlatAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics over ONE flat fp32 parameter arena and ONE flat gradient arena.
 
     Construction re-points every parameter's ``.data`` at a slice of the arena (values preserved) and
     registers matching slices of the gradient arena with the autograd Functions, so weight-gradient
     kernels write straight into it.  ``step`` is a single fused kernel launch; the data-parallel
     wrapper all-reduces the gradient arena in place.
+
+    It IS a ``torch.optim.Optimizer`` (one param group), so ``torch.optim.lr_scheduler`` classes drive it like any other
+    optimizer (the reference's DDP loop steps a ReduceLROnPlateau, training_distributed.py:98-101).  The hyper-parameters
+    live in a small device buffer that ``step`` refreshes only when ``param_groups[0]`` changed, so a step replayed from a
+    hipGraph follows the schedule too.  ``l2_lambda`` > 0 fuses the reference's manual L2 penalty
+    (training_distributed.py:52-57) into the same launch: the gradient 2*lambda*p is added on the fly and
+    ``l2_value`` (device scalar) receives lambda * sum p^2 of the weights the step started from.
+
+    Gradient accumulation over several backward passes is not supported: the weight-gradient kernels WRITE their arena
+    slice (``backward()`` twice without ``zero_grad()`` raises instead of silently doubling the last gradient).
     """
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, allow_host=False):
-        self.params = [p for p in params if p.requires_grad]
-        if not self.params:
+        plist = [p for p in params if p.requires_grad]
+        if not plist:
             raise ValueError("FlatAdamW: no trainable parameters")
-        dev = self.params[0].device
+        dev = plist[0].device
         if dev.type != "cuda" and not allow_host:
             # no silent CPU fallback: host tensors are only accepted when a test of the data-parallel plumbing
             # (gloo, no GPU) asks for it explicitly
             raise RuntimeError("brainxai.FlatAdamW: parameters must live on the GPU (allow_host=True is for the gloo logic tests only)")
-        if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
+        if any(p.device != dev or p.dtype != torch.float32 for p in plist):
             raise ValueError("FlatAdamW: parameters must be float32 on one device")
+        super().__init__(plist, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise ValueError("FlatAdamW: one parameter group only")
+        self.params = plist
         self.n = sum(p.numel() for p in self.params)
         self.flat_p = torch.empty(self.n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(self.n, dtype=torch.float32, device=dev)
@@ -52,13 +66,43 @@ class FlatAdamW:
                 p.data = view
                 self.offsets.append(off)
                 off += p.numel()
-        ops.register_grad_views(self.params, self.flat_g)
+        self._grad_key = ops.register_grad_views(self.params, self.flat_g)
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.step_t = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
         self.grad_scale = 1.0
+        self.l2_lambda = 0.0
         self.is_cuda = dev.type == "cuda"
+        if self.is_cuda:
+            self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
+            self._hyper_host = [torch.zeros(8, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._hyper_slot, self._hyper_seen = 0, None
+            self.l2_value = torch.zeros((), dtype=torch.float32, device=dev)
+            self._l2_partials = torch.zeros(int(L.load().bx_adamw_partials(self.n)), dtype=torch.float32, device=dev)
+            self.refresh_hyper()
+
+    def close(self):
+        """Forget the gradient-arena registration (otherwise done when the optimizer is garbage-collected)."""
+        ops.unregister_grad_views(getattr(self, "_grad_key", None))
+        self._grad_key = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def refresh_hyper(self):
+        """Push param_groups[0] / grad_scale / l2_lambda to the device buffer when they changed since the last call."""
+        g = self.param_groups[0]
+        vals = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                float(self.grad_scale), float(self.l2_lambda), 0.0)
+        if vals != self._hyper_seen:
+            self._hyper_slot ^= 1
+            host = self._hyper_host[self._hyper_slot]
+            host.copy_(torch.tensor(vals, dtype=torch.float32))
+            self.hyper.copy_(host, non_blocking=True)
+            self._hyper_seen = vals
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -67,13 +111,15 @@ class FlatAdamW:
             else:
                 p.grad.zero_()
 
-    def gather_grads(self):
-        """Make the gradient arena hold every parameter's gradient (no-op for slices the kernels wrote)."""
+    def gather_grads(self, first=0, last=None):
+        """Make the gradient arena hold the gradients of parameters [first, last) (default: all); a no-op for slices the
+        kernels wrote, zero for parameters that received no gradient."""
         if self.is_cuda:
             ops.join_side_streams(self.flat_g.device)      # weight-gradient kernels may still run on the side stream
             ops.wgrad_flush(self.flat_g.device)            # normally done by backward's end callback; no-op then
         base = self.flat_g.data_ptr()
-        for p, off in zip(self.params, self.offsets):
+        last = len(self.params) if last is None else last
+        for p, off in zip(self.params[first:last], self.offsets[first:last]):
             slot = self.flat_g.narrow(0, off, p.numel())
             if p.grad is None:
                 slot.zero_()
@@ -81,19 +127,25 @@ class FlatAdamW:
                 slot.copy_(p.grad.reshape(-1))
 
     @torch.no_grad()
-    def step(self, gathered=False):
+    def step(self, closure=None, gathered=False):
+        if closure is not None:
+            raise RuntimeError("FlatAdamW.step: closures are not supported")
         if not gathered:
             self.gather_grads()
         g = self.param_groups[0]
         if self.is_cuda:
-            L.check(L.load().bx_adamw_step(_p(self.flat_p), _p(self.flat_g), _p(self.exp_avg), _p(self.exp_avg_sq), self.n, g["lr"],
-                                           g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], float(self.grad_scale),
-                                           _p(self.step_t), _stream()), "bx_adamw_step")
+            capturing = torch.cuda.is_current_stream_capturing()
+            if not capturing:
+                self.refresh_hyper()                       # (inside a capture nothing can have changed since the eager step before it)
+            want_l2 = self.l2_lambda > 0
+            L.check(L.load().bx_adamw_step_dev(_p(self.flat_p), _p(self.flat_g), _p(self.exp_avg), _p(self.exp_avg_sq), self.n,
+                                               _p(self.hyper), _p(self.step_t), _p(self._l2_partials) if want_l2 else None,
+                                               _p(self.l2_value) if want_l2 else None, _stream()), "bx_adamw_step_dev")
         else:  # host tensors: only reached by the gloo/CPU logic tests of the data-parallel wrapper
             self.step_t += 1
             t = float(self.step_t)
             b1, b2 = g["betas"]
-            gr = self.flat_g * self.grad_scale
+            gr = self.flat_g * self.grad_scale + 2.0 * self.l2_lambda * self.flat_p
             self.flat_p.mul_(1 - g["lr"] * g["weight_decay"])
             self.exp_avg.mul_(b1).add_(gr, alpha=1 - b1)
             self.exp_avg_sq.mul_(b2).addcmul_(gr, gr, value=1 - b2)
@@ -102,13 +154,15 @@ class FlatAdamW:
 
     def state_dict(self):
         return {"flat_adamw": 1, "step": self.step_t.clone(), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
-                "param_groups": [dict(g) for g in self.param_groups]}
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
         if "flat_adamw" not in sd:
             raise ValueError("FlatAdamW.load_state_dict: not a FlatAdamW state")
         self.step_t.copy_(sd["step"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.param_groups = [dict(g) for g in sd["param_groups"]]
+        for k, v in sd["param_groups"][0].items():
+            if k != "params":
+                self.param_groups[0][k] = v
 
 
 # ------------------------------------------------------------------------------------------------
@@ -151,6 +205,14 @@ class DataParallel(nn.Module):
     def forward(self, *args, **kw):
         return self.module(*args, **kw)
 
+    def reduce_async(self, flat_slice):
+        """Start the mean all-reduce of one contiguous slice of a gradient arena (RCCL over xGMI on GPUs; it runs on the
+        process group's own stream, ordered behind what the current stream has queued so far).  ``wait()`` on the result makes
+        the current stream wait for it.  None without an initialised process group."""
+        if not dist.is_initialized():
+            return None
+        return _Reduction(flat_slice, self.group, self.world_size)
+
     def sync_gradients(self, optimizer=None):
         if not dist.is_initialized():
             return          # plain single-process use; with an initialised group the collective runs even for world_size 1
@@ -174,6 +236,48 @@ class DataParallel(nn.Module):
                 off += g.numel()
 
 
+class _Cut:
+    """``cut`` callback of Spectrogram_Model.features: remembers the activation and continues from a detached leaf, so that
+    ``loss.backward()`` stops there (late stages + heads + EEG branch) and ``finish()`` runs the rest (early stages)."""
+
+    def __call__(self, x):
+        self.x = x
+        self.leaf = x.detach().requires_grad_(True)
+        return self.leaf
+
+    def finish(self):
+        torch.autograd.backward([self.x], [self.leaf.grad])
+
+
+class _Reduction:
+    """Handle of an asynchronous mean all-reduce of one slice of the gradient arena."""
+
+    def __init__(self, tensor, group, world):
+        self.tensor, self.world = tensor, world
+        self.div = not tensor.is_cuda                       # gloo has no AVG
+        self.work = dist.all_reduce(tensor, op=dist.ReduceOp.SUM if self.div else dist.ReduceOp.AVG, group=group, async_op=True)
+
+    def wait(self):
+        self.work.wait()                                    # NCCL/RCCL: the current stream waits for the collective's stream
+        if self.div:
+            self.tensor.div_(self.world)
+
+
+def overlap_plan(model, optimizer):
+    """Where to cut the step of a MultimodalModel for the overlapped data-parallel step: (stage index k, parameter index of the
+    first parameter after the cut, arena offset there), or None when the model / optimizer do not support it.  The arena follows
+    ``model.parameters()``: [EEG branch | block1 | block2 | block3 .. block5, fc, fc1, fc2]; the cut after stage 2 leaves 88 % of
+    the bytes (everything from block3 on) in the first bucket, which is complete when backward reaches block2."""
+    sm = getattr(model, "spectrogram_model", None)
+    if not isinstance(optimizer, FlatAdamW) or sm is None or not hasattr(sm, "block3") or not hasattr(model, "_fusable") or not model._fusable():
+        return None
+    first = sm.block3.conv1.weight
+    for i, p in enumerate(optimizer.params):
+        if p is first:
+            return 2, i, optimizer.offsets[i]
+    return None
+
+
 def create_ddp_model(model, device_ids=None, output_device=None):
     """reference XAI_Multimodality.py:77-80."""
     if device_ids:
@@ -182,6 +286,32 @@ def create_ddp_model(model, device_ids=None, output_device=None):
 
 
 # ------------------------------------------------------------------------------------------------
+def train_step_overlapped(model, optimizer, eeg, spec, labels, criterion, ddp, plan=None):
+    """The data-parallel step with the gradient exchange overlapped with backward (DDP's bucketing, done with two buckets of the
+    flat arena): autograd is cut after spectrogram stage 2; ``loss.backward()`` yields the gradients of stages 3-5, the heads
+    and the EEG branch's slice; their all-reduce (88 % of the bytes) then runs on RCCL's stream while stages 2-1 run
+    their backward; the small second bucket follows; the fused AdamW waits for both.  Same arithmetic as train_step(ddp=...)."""
+    plan = plan or overlap_plan(model, optimizer)
+    if plan is None:
+        return train_step(model, optimizer, eeg, spec, labels, criterion, ddp=ddp)
+    k, pidx, off = plan
+    cut = _Cut()
+    optimizer.zero_grad()
+    out = model(eeg, spec, cut=(k, cut))
+    loss = criterion(out, labels)
+    loss.backward(ops.unit_gradient(loss.device) if loss.is_cuda and loss.dim() == 0 else None)
+    optimizer.gather_grads(pidx, None)
+    r1 = ddp.reduce_async(optimizer.flat_g.narrow(0, off, optimizer.n - off))
+    cut.finish()
+    optimizer.gather_grads(0, pidx)
+    r2 = ddp.reduce_async(optimizer.flat_g.narrow(0, 0, off))
+    for r in (r1, r2):
+        if r is not None:
+            r.wait()
+    optimizer.step(gathered=True)
+    return loss.detach(), out.detach()
+
+
 def train_step(model, optimizer, eeg, spec, labels, criterion, ddp=None):
     """zero_grad -> forward -> loss -> backward -> (all-reduce) -> step (reference NB:1597-1601).
     Returns (loss, outputs) as device tensors; nothing here synchronises with the host."""
@@ -217,90 +347,58 @@ def save_checkpoint(state, checkpoint_dir, checkpoint_filename):
 class GraphedTrainStep:
     """forward + loss + backward (+ fused AdamW when not data-parallel) of one training step replayed from a hipGraph.
 
-    A step is ~150 kernel launches; issued one by one from Python the host becomes the bottleneck (2.44 ms vs 2.0 ms per
+    A step is ~100 kernel launches; issued one by one from Python the host becomes the bottleneck (2.44 ms vs 2.0 ms per
     step on MI355X).  The first batch of a given shape runs eagerly, the second is captured, later ones are replayed:
     inputs are copied into the graph's static buffers, the dropout seeds and BatchNorm statistics live on the device and
-    advance inside the graph.  Needs FlatAdamW (stable gradient arena) and CUDA inputs; anything else, or BX_GRAPH_LOOPS=0,
-    falls back to the eager step.  Returned loss / output are the graph's static tensors (valid until the next call)."""
+    advance inside the graph, and the optimizer's hyper-parameters are read from FlatAdamW's device buffer (refreshed before
+    every replay when ``param_groups`` changed), so a learning-rate schedule is honoured without re-capturing.  Needs FlatAdamW
+    (stable gradient arena) and CUDA inputs; anything else, or BX_GRAPH_LOOPS=0, falls back to the eager step.  Returned loss /
+    output are the graph's static tensors (valid until the next call).
 
-    def __init__(self, model, optimizer, criterion, ddp=None):
-        self.model, self.opt, self.crit, self.ddp = model, optimizer, criterion, ddp
+    (Round 1 carried an experimental six-graph "branch-parallel" replay, BX_BRANCH_GRAPHS: it left the eager trajectory at
+    B=64 -- cross-queue visibility at graph launches -- gained 1.4 % and was removed in round 2)"""
+
+    def __init__(self, model, optimizer, criterion, ddp=None, adopt_inputs=False):
+        """``adopt_inputs``: the tensors of the capturing call become the graph's static inputs themselves (no clone, no
+        per-step copy when the same tensors are passed again) -- for callers that refill one resident batch in place."""
+        self.model, self.opt, self.crit, self.ddp, self.adopt = model, optimizer, criterion, ddp, adopt_inputs
         self.enabled = isinstance(optimizer, FlatAdamW) and optimizer.is_cuda and os.environ.get("BX_GRAPH_LOOPS", "1") != "0"
         self._seen, self._graphs = set(), {}
-        # branch-parallel replay (MultimodalModel only): see _capture_branches
-        self.branches = os.environ.get("BX_BRANCH_GRAPHS", "0") == "1"     # off by default: see _capture_branches
-        self._side = None
+        # data-parallel: two graphs cut after spectrogram stage 2, the first bucket's all-reduce between them (BX_DDP_OVERLAP=0:
+        # one graph, one collective after it)
+        self.plan = overlap_plan(model, optimizer) if (ddp is not None and os.environ.get("BX_DDP_OVERLAP", "1") != "0") else None
 
-    def _capture_branches(self, static_in, static_lab):
-        """The two-branch model as SIX graphs instead of one.  A replayed hipGraph runs its kernels strictly one after the
-        other on this stack, even across forked branches (tools/graph_concurrency_probe.py), but two graph launches on two
-        streams do overlap.  The EEG branch is ~25 small, latency-bound kernels forward and backward that are independent
-        of the spectrogram branch until the fusion head, so the step is cut at the head:
-            main stream:  [zero grads, spectrogram features] -> [head fwd, loss, head bwd] -> [spectrogram bwd] -> [AdamW]
-            side stream:  [EEG features]                  ->            (join)           -> [EEG bwd]        -> (join)
-        Autograd is cut at the two feature tensors (detached leaves feed the head; their .grad seeds the branch backward
-        passes).  Every graph has its own memory pool: graphs that replay concurrently must not share one."""
-        m = self.model
-        em, sm = m.eeg_model, m.spectrogram_model
-        eeg_in, spec_in = static_in
-        cur = torch.cuda.current_stream()
-        s_main, s_side = torch.cuda.Stream(), torch.cuda.Stream()
-        s_main.wait_stream(cur); s_side.wait_stream(cur)
-        g = [torch.cuda.CUDAGraph() for _ in range(6)]
-        with torch.cuda.graph(g[0], stream=s_main):
-            self.opt.zero_grad()
-            sf = sm.features(spec_in)
-        with torch.cuda.graph(g[1], stream=s_side):
-            ef = em.features(eeg_in)
-        with torch.cuda.graph(g[2], stream=s_main):
-            sf_leaf, ef_leaf = sf.detach().requires_grad_(True), ef.detach().requires_grad_(True)
-            out = ops.MultimodalHeadFn.apply(sf_leaf.permute(0, 2, 3, 1), ef_leaf, sm.fc.weight, sm.fc.bias, em.dense.weight, em.dense.bias,
-                                             m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
-            loss = self.crit(out, static_lab)
-            loss.backward(ops.unit_gradient(loss.device) if loss.is_cuda and loss.dim() == 0 else None)
-            d_sf, d_ef = sf_leaf.grad, ef_leaf.grad
-        with torch.cuda.graph(g[3], stream=s_main):
-            torch.autograd.backward([sf], [d_sf])
-        with torch.cuda.graph(g[4], stream=s_side):
-            torch.autograd.backward([ef], [d_ef])
-        with torch.cuda.graph(g[5], stream=s_main):
-            if self.ddp is None:
-                self.opt.step()
-            else:
-                self.opt.gather_grads()
-        cur.wait_stream(s_main); cur.wait_stream(s_side)
-        self._side = s_side
-        ev = [torch.cuda.Event() for _ in range(4)]
-        return ("branches", g, ev, static_in, static_lab, loss.detach(), out.detach(), (sf, ef, sf_leaf, ef_leaf, d_sf, d_ef))
-
-    def _replay_branches(self, entry):
-        _, g, ev, _, _, loss, out, _ = entry
-        cur, side = torch.cuda.current_stream(), self._side
-        if os.environ.get("BX_BRANCH_SYNC") == "1":         # debugging aid: the same six graphs with device-wide syncs between stages
-            for k in (1, 0, 2, 4, 3, 5):
-                with torch.cuda.stream(side if k in (1, 4) else cur):
-                    g[k].replay()
-                torch.cuda.synchronize()
-            return loss, out
-        ev[0].record(cur)                               # inputs copied, previous step's optimizer update done
-        side.wait_event(ev[0])
-        with torch.cuda.stream(side):
-            g[1].replay()
-            ev[1].record(side)
-        g[0].replay()
-        cur.wait_event(ev[1])
-        g[2].replay()
-        ev[2].record(cur)
-        side.wait_event(ev[2])
-        with torch.cuda.stream(side):
-            g[4].replay()
-            ev[3].record(side)
-        g[3].replay()
-        cur.wait_event(ev[3])
-        g[5].replay()
+    def _finish(self):
         if self.ddp is not None:
             self.ddp.sync_gradients(self.opt)
             self.opt.step(gathered=True)
+
+    def _capture_overlapped(self, static_in, static_lab):
+        k, pidx, off = self.plan
+        cut = _Cut()
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            self.opt.zero_grad()
+            out = self.model(*static_in, cut=(k, cut))
+            loss = self.crit(out, static_lab)
+            loss.backward(ops.unit_gradient(loss.device) if loss.is_cuda and loss.dim() == 0 else None)
+            self.opt.gather_grads(pidx, None)
+        with torch.cuda.graph(g2, pool=g1.pool()):          # always replayed right after g1: one memory pool
+            cut.finish()
+            self.opt.gather_grads(0, pidx)
+        return ("overlap", (g1, g2), static_in, static_lab, loss.detach(), out.detach(), cut)
+
+    def _replay_overlapped(self, entry):
+        _, (g1, g2), _, _, loss, out, _ = entry
+        _, _, off = self.plan
+        g1.replay()
+        r1 = self.ddp.reduce_async(self.opt.flat_g.narrow(0, off, self.opt.n - off))
+        g2.replay()
+        r2 = self.ddp.reduce_async(self.opt.flat_g.narrow(0, 0, off))
+        for r in (r1, r2):
+            if r is not None:
+                r.wait()
+        self.opt.step(gathered=True)
         return loss, out
 
     def _eager(self, inputs, labels):
@@ -309,69 +407,59 @@ class GraphedTrainStep:
         loss = self.crit(out, labels)
         loss.backward(ops.unit_gradient(loss.device) if loss.is_cuda and loss.dim() == 0 else None)
         if self.ddp is not None:
-            self.ddp.sync_gradients(self.opt)
-            self.opt.step(gathered=True)
+            self._finish()
         else:
             self.opt.step()
         return loss.detach(), out.detach()
 
+    def _eager_any(self, inputs, labels):
+        if self.plan is not None and len(inputs) == 2:
+            return train_step_overlapped(self.model, self.opt, inputs[0], inputs[1], labels, self.crit, self.ddp, self.plan)
+        return self._eager(inputs, labels)
+
     def __call__(self, inputs, labels):
         if not self.enabled or not self.model.training:
-            return self._eager(inputs, labels)
+            return self._eager_any(inputs, labels)
         key = (tuple((tuple(t.shape), t.dtype) for t in inputs), tuple(labels.shape), labels.dtype)
         entry = self._graphs.get(key)
         if entry is None:
             if key not in self._seen:                 # first batch of this shape: plain step (also sizes every workspace)
                 self._seen.add(key)
-                return self._eager(inputs, labels)
-            static_in = [t.detach().clone() for t in inputs]
-            static_lab = labels.detach().clone()
-            entry = None
-            if self.branches and type(self.model).__name__ == "MultimodalModel" and len(inputs) == 2 and self.model._fusable():
-                try:
-                    torch.cuda.synchronize()
-                    entry = self._capture_branches(static_in, static_lab)
-                except Exception as exc:              # noqa: BLE001
-                    print(f"[brainxai] branch-parallel capture failed ({type(exc).__name__}: {exc}); capturing one graph instead")
-                    self.branches, entry = False, None
-                    torch.cuda.synchronize()
-                    self.opt.zero_grad()
-            if entry is not None:
-                self._graphs[key] = entry
-                return self._replay_entry(entry, inputs, labels)
+                return self._eager_any(inputs, labels)
+            static_in = [t.detach() if self.adopt else t.detach().clone() for t in inputs]
+            static_lab = labels.detach() if self.adopt else labels.detach().clone()
             try:
                 torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    self.opt.zero_grad()
-                    out = self.model(*static_in)
-                    loss = self.crit(out, static_lab)
-                    loss.backward(ops.unit_gradient(loss.device) if loss.is_cuda and loss.dim() == 0 else None)
-                    if self.ddp is None:
-                        self.opt.step()
-                entry = (graph, static_in, static_lab, loss.detach(), out.detach())
+                if self.plan is not None and len(inputs) == 2:
+                    entry = self._capture_overlapped(static_in, static_lab)
+                else:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        self.opt.zero_grad()
+                        out = self.model(*static_in)
+                        loss = self.crit(out, static_lab)
+                        loss.backward(ops.unit_gradient(loss.device) if loss.is_cuda and loss.dim() == 0 else None)
+                        if self.ddp is None:
+                            self.opt.step()
+                    entry = ("one", graph, static_in, static_lab, loss.detach(), out.detach())
             except Exception as exc:                  # noqa: BLE001  (capture is an optimisation, never a requirement)
                 print(f"[brainxai] hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); running eagerly")
                 self.enabled = False
                 torch.cuda.synchronize()
-                return self._eager(inputs, labels)
+                return self._eager_any(inputs, labels)
             self._graphs[key] = entry
-        return self._replay_entry(entry, inputs, labels)
-
-    def _replay_entry(self, entry, inputs, labels):
-        static_in, static_lab = (entry[3], entry[4]) if entry[0] == "branches" else (entry[1], entry[2])
+        static_in, static_lab = entry[2], entry[3]
         for dst, src in zip(static_in, inputs):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         if static_lab.data_ptr() != labels.data_ptr():
             static_lab.copy_(labels, non_blocking=True)
-        if entry[0] == "branches":
-            return self._replay_branches(entry)
-        graph, _, _, loss, out = entry
+        self.opt.refresh_hyper()                      # lr / betas / weight decay changed by a scheduler since the last step?
+        if entry[0] == "overlap":
+            return self._replay_overlapped(entry)
+        _, graph, _, _, loss, out = entry
         graph.replay()
-        if self.ddp is not None:
-            self.ddp.sync_gradients(self.opt)
-            self.opt.step(gathered=True)
+        self._finish()
         return loss, out
 
 
@@ -409,28 +497,44 @@ class AsyncCheckpointer:
             return type(obj)(self._snapshot(v, f"{key}/{i}") for i, v in enumerate(obj))
         return obj
 
+    def _clone_device(self, obj):
+        """Device-side copy of every CUDA tensor, queued on the CURRENT stream: what the training stream writes next (BatchNorm
+        running statistics in the first forward, the whole parameter arena in the fused AdamW) can then no longer reach the
+        snapshot -- state_dict entries are views of FlatAdamW's arena and of the live buffers, not copies."""
+        if torch.is_tensor(obj):
+            return obj.detach().clone() if obj.is_cuda else obj
+        if isinstance(obj, dict):
+            return type(obj)((k, self._clone_device(v)) for k, v in obj.items())
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(self._clone_device(v) for v in obj)
+        return obj
+
     def save(self, state):
         self.wait()                                        # one write in flight; also frees the pinned buffers for reuse
+        stable = None
         if torch.cuda.is_available():
             if self._stream is None:
                 self._stream = torch.cuda.Stream()
+            stable = self._clone_device(state)             # ordered on the training stream, BEFORE the next step's kernels
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
-                snap = self._snapshot(state, "")
+                snap = self._snapshot(stable, "")          # device clones -> pinned host buffers, beside the next epoch
                 done = torch.cuda.Event()
                 done.record()
         else:
             snap, done = self._snapshot(state, ""), None
 
-        def work():
+        def work(stable=stable):
             try:
                 if done is not None:
                     done.synchronize()
+                del stable                                 # the clones were only read on the side stream, which has finished
                 cpu = _to_plain(snap)
                 torch.save(cpu, self.path + ".tmp")
                 os.replace(self.path + ".tmp", self.path)
             except Exception as exc:                       # noqa: BLE001  (surfaced by wait())
                 self.error = exc
+        stable = None
         self._thread = self._threading.Thread(target=work, daemon=True)
         self._thread.start()
 
@@ -454,8 +558,9 @@ def _to_plain(obj):
     return obj
 
 
-def _run_epoch(model, loader, criterion, device, optimizer=None, ddp=None, unpack=None):
-    """One pass; loss*B and correct counts accumulate ON DEVICE (the reference syncs three times per step)."""
+def _run_epoch(model, loader, criterion, device, optimizer=None, ddp=None, unpack=None, per_batch_sum=False):
+    """One pass; loss*B (combined loop, NB:1603) or the plain per-batch loss (DDP loop, training_distributed.py:59,89:
+    ``per_batch_sum``) and the correct counts accumulate ON DEVICE (the reference syncs three times per step)."""
     loss_sum = torch.zeros((), dtype=torch.float32, device=device)
     correct = torch.zeros((), dtype=torch.int64, device=device)
     total = 0
@@ -477,7 +582,7 @@ def _run_epoch(model, loader, criterion, device, optimizer=None, ddp=None, unpac
                 out = model(*inputs)
                 loss = criterion(out, labels)
         n = labels.shape[0]
-        loss_sum += loss.detach() * n
+        loss_sum += loss.detach() if per_batch_sum else loss.detach() * n
         correct += (out.detach().argmax(1) == labels.argmax(1)).sum()
         total += n
     total = max(total, 1)
@@ -513,61 +618,101 @@ def train_and_validate_combined(model, train_loader, valid_loader, epochs, optim
     return tr_l, va_l, tr_a, va_a
 
 
+def load_checkpoint_distributed(checkpoint_dir, checkpoint_filename, model, optimizer):
+    """What the reference's DDP loop expects of load_checkpoint (training_distributed.py:31 unpacks SEVEN values; the committed
+    data_utils.py:259-283 returns six -- SURVEY fact 7): the five of the combined loop + the learning-rate history + the
+    per-epoch regularisation losses, so that a resumed run continues both lists."""
+    path = os.path.join(checkpoint_dir, checkpoint_filename)
+    if os.path.isfile(path):
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        model.load_state_dict(ck["state_dict"])
+        optimizer.load_state_dict(ck["optimizer"])
+        return (ck["epoch"], ck["train_losses"], ck["valid_losses"], ck["train_accuracies"], ck["valid_accuracies"],
+                list(ck.get("lr_scheduler", [])), list(ck.get("regularization_losses", [])))
+    return 0, [], [], [], [], [], []
+
+
+def l2_penalty_(model_or_params, weight_decay, optimizer=None):
+    """The reference's manual penalty (training_distributed.py:52-57): ``reg = weight_decay * sum_p sum(p**2)`` over
+    ``model.parameters()`` joins the loss, i.e. its gradient ``2 * weight_decay * p`` joins every ``p.grad``.
+    With a FlatAdamW the work is deferred into the fused optimizer launch (``optimizer.l2_lambda``; the value lands in
+    ``optimizer.l2_value`` when ``step`` runs) and this returns None; otherwise it is done here, one bx_sumsq + bx_axpby per
+    parameter, and the value is returned as a device scalar."""
+    wd = float(weight_decay)
+    if isinstance(optimizer, FlatAdamW) and optimizer.is_cuda:
+        optimizer.l2_lambda = wd
+        return None
+    params = list(model_or_params.parameters()) if isinstance(model_or_params, nn.Module) else list(model_or_params)
+    lib = L.load()
+    dev = params[0].device
+    total = torch.zeros((), dtype=torch.float32, device=dev)
+    part = torch.empty((), dtype=torch.float32, device=dev)
+    for p in params:
+        flat = p.detach().reshape(-1)
+        if not flat.is_cuda:
+            raise RuntimeError("brainxai.l2_penalty_: parameters must live on the GPU; there is no CPU path")
+        L.check(lib.bx_sumsq(_p(flat), flat.numel(), _p(part), _stream()), "bx_sumsq")
+        L.check(lib.bx_axpby(_p(part), _p(total), 1, wd, 1.0, _stream()), "bx_axpby")                  # total += wd * sum p^2
+        if p.grad is not None:
+            g = p.grad.reshape(-1)
+            L.check(lib.bx_axpby(_p(flat), _p(g), flat.numel(), 2.0 * wd, 1.0, _stream()), "bx_axpby")   # grad += 2 wd p
+    return total
+
+
 def train_and_validate_eeg_distributed(model, train_loader, valid_loader, epochs, optimizer, criterion, scheduler, device,
                                        checkpoint_dir, logger, rank, world_size):
-    """Reference root/src/training/training_distributed.py:22-141 for a single-input model (EEGNet).
-    The reference adds ``sum(p**2) * model.weight_decay`` to the loss (:52-53); here its value comes from one
-    bx_sumsq launch and its gradient (2*wd*p) is added to the flat gradient arena before the all-reduce."""
+    """Reference root/src/training/training_distributed.py:22-141 for a single-input model (EEGNet), same bookkeeping:
+
+    * ``total_loss = criterion(out, labels) + model.weight_decay * sum(p**2)`` (:52-57) -- the penalty's value and gradient
+      come from the fused optimizer launch (FlatAdamW) or from l2_penalty_();
+    * train / regularisation / validation losses are the SUMS of the per-batch values divided by the number of SAMPLES
+      (:59-60, :70-71, :95), accuracies arg-max based;
+    * ``scheduler.step(valid_loss)`` (:99; ReduceLROnPlateau -- other schedulers are stepped without an argument) and the
+      learning rate it leaves is appended to the ``lr_scheduler`` history (:101);
+    * rank 0 writes ``eeg_checkpoint.pth.tar`` with the reference's keys, ``module.``-prefixed weights (:104-117); a resumed run
+      restores both histories (load_checkpoint_distributed).
+    Nothing in the batch loop synchronises with the host: the running sums live on the device."""
     setup(rank, world_size)
     model = model.to(device)
     wd = float(getattr(model, "weight_decay", 0.0))
     ddp = DataParallel(model, device_ids=[rank] if torch.cuda.is_available() else None)
     name = "eeg_checkpoint.pth.tar"
-    start, tr_l, va_l, tr_a, va_a = load_checkpoint(checkpoint_dir, name, ddp, optimizer)
-    reg_losses = []
+    start, tr_l, va_l, tr_a, va_a, lr_hist, reg_losses = load_checkpoint_distributed(checkpoint_dir, name, ddp, optimizer)
     flat = isinstance(optimizer, FlatAdamW)
+    plateau = isinstance(scheduler, torch.optim.lr_scheduler.ReduceLROnPlateau)
     for epoch in range(start, epochs):
         if logger:
             logger.info(f"Starting Epoch {epoch + 1}/{epochs}")
         model.train()
         if hasattr(getattr(train_loader, "sampler", None), "set_epoch"):
-            train_loader.sampler.set_epoch(epoch)
+            train_loader.sampler.set_epoch(epoch)           # :42
         loss_sum = torch.zeros((), device=device); reg_sum = torch.zeros((), device=device)
-        correct = torch.zeros((), dtype=torch.int64, device=device); total = 0; nb = 0
+        correct = torch.zeros((), dtype=torch.int64, device=device); total = 0
         for data, labels in train_loader:
             data, labels = data.to(device), labels.to(device)
             optimizer.zero_grad()
             out = ddp(data)
             loss = criterion(out, labels)
             loss.backward(ops.unit_gradient(loss.device) if loss.is_cuda and loss.dim() == 0 else None)
-            if wd > 0 and flat and optimizer.is_cuda:
-                optimizer.gather_grads()
-                reg = torch.empty((), dtype=torch.float32, device=device)
-                L.check(L.load().bx_sumsq(_p(optimizer.flat_p), optimizer.n, _p(reg), _stream()), "bx_sumsq")
-                L.check(L.load().bx_axpby(_p(optimizer.flat_p), _p(optimizer.flat_g), optimizer.n, 2.0 * wd, 1.0, _stream()), "bx_axpby")
-                reg_sum += reg * wd
-            elif wd > 0:
-                with torch.no_grad():
-                    for p in model.parameters():
-                        if p.grad is not None:
-                            p.grad.add_(p, alpha=2.0 * wd)
-                            reg_sum += (p.detach() ** 2).sum() * wd
+            reg = l2_penalty_(model, wd, optimizer) if wd > 0 else None
             ddp.sync_gradients(optimizer)
             optimizer.step(gathered=True) if flat else optimizer.step()
-            loss_sum += loss.detach(); nb += 1
+            if wd > 0:
+                reg_sum += optimizer.l2_value if reg is None else reg
+            loss_sum += loss.detach()
             correct += (out.detach().argmax(1) == labels.argmax(1)).sum(); total += labels.shape[0]
-        tr_l.append(float(loss_sum) / max(nb, 1)); tr_a.append(float(correct) / max(total, 1) * 100.0)
-        reg_losses.append(float(reg_sum) / max(nb, 1))
+        tr_l.append(float(loss_sum) / max(total, 1)); tr_a.append(float(correct) / max(total, 1) * 100.0)
+        reg_losses.append(float(reg_sum) / max(total, 1))
         model.eval()
-        l, a = _run_epoch(ddp, valid_loader, criterion, device)
+        l, a = _run_epoch(ddp, valid_loader, criterion, device, per_batch_sum=True)
         va_l.append(l); va_a.append(a)
         if scheduler is not None:
-            scheduler.step()
+            scheduler.step(va_l[-1]) if plateau else scheduler.step()
+            lr_hist.append(float(scheduler.get_last_lr()[0]) if hasattr(scheduler, "get_last_lr") else float(optimizer.param_groups[0]["lr"]))
         if logger:
-            logger.info(f"Epoch {epoch + 1}/{epochs} train {tr_l[-1]:.4f}/{tr_a[-1]:.2f}% valid {va_l[-1]:.4f}/{va_a[-1]:.2f}%")
+            logger.info(f"Epoch {epoch + 1}/{epochs} train {tr_l[-1]:.5f} reg {reg_losses[-1]:.5f} / {tr_a[-1]:.2f}% valid {va_l[-1]:.5f}/{va_a[-1]:.2f}%")
         if rank == 0:
             save_checkpoint({"epoch": epoch + 1, "state_dict": ddp.state_dict(), "optimizer": optimizer.state_dict(),
                              "train_losses": tr_l, "valid_losses": va_l, "train_accuracies": tr_a, "valid_accuracies": va_a,
-                             "lr_scheduler": scheduler.state_dict() if scheduler is not None else [],
-                             "regularization_losses": reg_losses}, checkpoint_dir, name)
+                             "lr_scheduler": lr_hist, "regularization_losses": reg_losses}, checkpoint_dir, name)
     return tr_l, va_l, tr_a, va_a

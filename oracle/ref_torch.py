@@ -290,6 +290,53 @@ def train_step(model, optimizer, eeg, spec, labels, criterion=None):
 
 
 # --------------------------------------------------------------------------------------
+# Row F -- one epoch of train_and_validate_eeg_distributed (root/src/training/training_distributed.py:34-101), one rank
+# --------------------------------------------------------------------------------------
+def l2_penalty(model: nn.Module, weight_decay: float):
+    """``reg_loss = sum(torch.sum(param ** 2) for param in model.parameters()) * weight_decay`` (DDP:52-53)."""
+    return sum(torch.sum(p ** 2) for p in model.parameters()) * weight_decay
+
+
+def distributed_epoch(model, train_batches, valid_batches, optimizer, criterion, weight_decay, scheduler=None, on_step=None):
+    """The body of the reference's DDP epoch loop on ONE replica (DDP averaging over ranks is the identity for one rank; for N
+    ranks each replica runs exactly this on its shard and gradients are averaged before ``optimizer.step()``).  Follows
+    DDP:34-101 line by line: total_loss = loss + reg (:55), running sums of ``loss.item()`` / ``reg_loss.item()`` (:59-60)
+    divided by the number of SAMPLES (:66-67, :95), arg-max accuracy, ``scheduler.step(valid_loss)`` (:99).
+    ``on_step(i, loss, reg, model)`` is called after backward and before the optimizer step (test hook).
+    Returns dict(train_loss, reg_loss, train_acc, valid_loss, valid_acc, lr)."""
+    model.train()
+    run_loss = run_reg = 0.0
+    correct = total = 0
+    for i, (data, labels) in enumerate(train_batches):
+        optimizer.zero_grad()
+        out = model(data)
+        loss = criterion(out, labels)
+        reg = l2_penalty(model, weight_decay)
+        (loss + reg).backward()
+        if on_step is not None:
+            on_step(i, loss.detach(), reg.detach(), model)
+        optimizer.step()
+        run_loss += loss.item(); run_reg += reg.item()
+        total += labels.size(0)
+        correct += int((out.argmax(1) == labels.argmax(1)).sum())
+    res = {"train_loss": run_loss / total, "reg_loss": run_reg / total, "train_acc": 100.0 * correct / total}
+    model.eval()
+    run_v = 0.0
+    correct = total = 0
+    with torch.no_grad():
+        for data, labels in valid_batches:
+            out = model(data)
+            run_v += criterion(out, labels).item()
+            total += labels.size(0)
+            correct += int((out.argmax(1) == labels.argmax(1)).sum())
+    res.update(valid_loss=run_v / total, valid_acc=100.0 * correct / total, lr=None)
+    if scheduler is not None:
+        scheduler.step(res["valid_loss"])
+        res["lr"] = scheduler.get_last_lr()[0]
+    return res
+
+
+# --------------------------------------------------------------------------------------
 # Row G -- attribution
 # --------------------------------------------------------------------------------------
 def _resolve(model: nn.Module, dotted: str) -> nn.Module:
@@ -659,3 +706,95 @@ def expected_gradients(model, x, background, nsamples=200, seed=0):
             out[i, c] = (g * diff).mean(0)
     model.train(was_training)
     return out
+
+
+# --------------------------------------------------------------------------------------
+# Discontinuity bookkeeping for gradient comparisons (test tooling, no reference counterpart)
+# --------------------------------------------------------------------------------------
+# A gradient is a discontinuous function of the activations: ReLU'(z) jumps at z = 0 and a 2x2 max-pool routes its
+# gradient to the arg-max.  Two fp32 implementations of the same convolution differ by ~1e-7 * S in a pre-activation
+# (S = sum of |terms|), so a z that is that close to zero -- or two window entries that close to each other -- can land on
+# different sides.  These helpers make such an event an OBSERVED fact instead of an assumption: the fp64 run of the
+# oracle gives every pre-activation with its summation scale, and `activation_flips` lists the positions where another
+# implementation's post-ReLU activations disagree with it, each with its |z| / S margin.
+def relu_pool_trace(model: nn.Module, args, dtype=torch.float64):
+    """Run a deep copy of ``model`` (same mode, same buffers) in ``dtype`` on ``args`` and record for every residual stage
+    (anything with conv1..conv3 + pool, i.e. Block here and in the reference) the pre-ReLU outputs ``z`` of its three
+    convolutions and their summation scales ``S = conv(|x|, |w|) + |b|``.  Returns {stage name: {"z": [z1,z2,z3],
+    "S": [S1,S2,S3], "pool": "max"|"avg"}} (NCHW tensors)."""
+    import copy
+    twin = copy.deepcopy(model).to(dtype)
+    twin.train(model.training)
+    trace, hooks = {}, []
+    for name, mod in twin.named_modules():
+        if all(hasattr(mod, f"conv{k}") for k in (1, 2, 3)) and hasattr(mod, "pool"):
+            ent = {"z": [None] * 3, "S": [None] * 3, "pool": "max" if isinstance(mod.pool, nn.MaxPool2d) else "avg"}
+            trace[name] = ent
+            for k in range(3):
+                def hook(m, inp, out, ent=ent, k=k):
+                    ent["z"][k] = out.detach()
+                    ent["S"][k] = F.conv2d(inp[0].detach().abs(), m.weight.detach().abs(), m.bias.detach().abs(), padding=1)
+                hooks.append(getattr(mod, f"conv{k + 1}").register_forward_hook(hook))
+    with torch.no_grad():
+        twin(*[a.to(dtype) if torch.is_floating_point(a) else a for a in args])
+    for h in hooks:
+        h.remove()
+    return trace
+
+
+def activation_flips(trace, acts, tie=1e-4):
+    """Compare another implementation's post-ReLU activations with an fp64 ``relu_pool_trace``.
+
+    acts: {stage name: [y1, y2, y3]} NCHW tensors (what the implementation stored after each conv+ReLU).
+    Returns (flips, errors): ``flips`` = list of dicts {stage, conv|'pool', index, margin} for every position where the
+    sign pattern (y > 0 vs z > 0) or a max-pool arg-max differs AND the oracle's margin |z|/S (or top-2 gap / S) is below
+    ``tie`` -- a demonstrated tie flip; ``errors`` = the same for disagreements with a LARGER margin, which no rounding
+    argument explains (a test must fail on those)."""
+    flips, errors = [], []
+    for name, ent in trace.items():
+        if name not in acts:
+            continue
+        for k in range(3):
+            z, S = ent["z"][k], ent["S"][k]
+            y = torch.as_tensor(acts[name][k]).to(z.dtype)
+            bad = (y > 0) != (z > 0)
+            for idx in bad.nonzero().tolist():
+                m = float(z[tuple(idx)].abs() / S[tuple(idx)].clamp_min(1e-300))
+                (flips if m < tie else errors).append({"stage": name, "conv": k + 1, "index": idx, "margin": m})
+        if ent["pool"] == "max":
+            z3, S3 = F.relu(ent["z"][2]), ent["S"][2]
+            y3 = torch.as_tensor(acts[name][2]).to(z3.dtype)
+            Hc, Wc = z3.shape[2] // 2 * 2, z3.shape[3] // 2 * 2
+
+            def windows(t):
+                t = t[:, :, :Hc, :Wc]
+                return t.reshape(t.shape[0], t.shape[1], Hc // 2, 2, Wc // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(*t.shape[:2], Hc // 2, Wc // 2, 4)
+            wz, wy, wS = windows(z3), windows(y3), windows(S3)
+            top2 = wz.topk(2, dim=-1).values
+            # first-maximum rule on both sides (PyTorch's max_pool2d backward routes to the first maximum in window order)
+            bad = (wz.argmax(-1) != wy.argmax(-1)) & (top2[..., 0] > 0)
+            for idx in bad.nonzero().tolist():
+                t = tuple(idx)
+                m = float((top2[t][0] - top2[t][1]) / wS[t].max().clamp_min(1e-300))
+                (flips if m < tie else errors).append({"stage": name, "conv": "pool", "index": idx, "margin": m})
+    return flips, errors
+
+
+def conditioning(model: nn.Module, args, loss_of, dtype=torch.float64):
+    """How well-posed a gradient comparison at fp32 is: max over parameters of the relative L2 distance between the fp32
+    and the ``dtype`` gradients of ``loss_of(model(*args))`` (both on deep copies; ``model`` itself is untouched)."""
+    import copy
+    grads = []
+    for dt in (torch.float32, dtype):
+        twin = copy.deepcopy(model).to(dt)
+        twin.train(model.training)
+        twin.zero_grad()
+        loss_of(twin(*[a.to(dt) if torch.is_floating_point(a) else a for a in args])).backward()
+        grads.append({n: p.grad.detach().double() for n, p in twin.named_parameters() if p.grad is not None})
+    gmax = max(float(g.norm()) for g in grads[1].values())
+    worst, where = 0.0, None
+    for n, g in grads[1].items():
+        d = float((grads[0][n] - g).norm() / max(float(g.norm()), 1e-3 * gmax, 1e-300))
+        if d > worst:
+            worst, where = d, n
+    return worst, where

@@ -12,7 +12,7 @@ import brainxai
 from brainxai import _lib as L
 from brainxai import ops
 from oracle import ref_torch as O
-from tests.golden_util import REPORT, check, grad_close, load, rel_err
+from tests.golden_util import REPORT, check, grad_close, load, observed_flips, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
@@ -25,9 +25,16 @@ def _sync_err(a, b):
     return rel_err(a.detach().float().cpu(), b)
 
 
-def _gclose(a, b, label, tol=TIGHT, floor=0.0):
+def _gclose(a, b, label, tol=TIGHT, floor=0.0, flips=None):
     torch.cuda.synchronize()
-    return grad_close(a.detach().float().cpu(), b, tol, label=label, floor=floor)
+    return grad_close(a.detach().float().cpu(), b, tol, label=label, floor=floor, flips=flips)
+
+
+def _flips(ref, args, keep, label):
+    """Observed ReLU / max-pool flips of the GPU forward that filled ``keep`` (ops.keep_block_activations) against the fp64
+    trace of the oracle ``ref`` on the CPU inputs ``args``; [] (the usual case) keeps every gradient comparison strict."""
+    torch.cuda.synchronize()
+    return observed_flips(O, ref, args, keep, label)
 
 
 def _gscale(model):
@@ -77,19 +84,21 @@ def test_block_fwd_bwd(tag, cfg):
     for mode in ("eval", "train"):
         ref.train(mode == "train"); mine.train(mode == "train")
         ref.zero_grad(); mine.zero_grad()
+        keep = ops.keep_block_activations(mine)
         xr = x.clone().requires_grad_(True)
         yr = ref(xr); (yr * r).sum().backward()
         xm = x.clone().to(DEV).requires_grad_(True)
         ym = mine(xm); (ym * r.to(DEV)).sum().backward()
         assert ym.shape == yr.shape
         assert _sync_err(ym, yr) < TIGHT, mode
-        _gclose(xm.grad, xr.grad, f"block {tag} {mode} dx")
+        fp = _flips(ref, (x,), keep, f"block {tag} {mode}")
+        _gclose(xm.grad, xr.grad, f"block {tag} {mode} dx", flips=fp)
         check(fix, f"{mode}.out", ym.detach().float().cpu().contiguous(), tol=TOL)
-        check(fix, f"{mode}.dx", xm.grad.cpu(), tol=TOL, robust=True)
+        check(fix, f"{mode}.dx", xm.grad.cpu(), tol=TOL, robust=True, flips=fp)
         fl = _gscale(ref)
         for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
-            _gclose(p.grad, q.grad, f"block {tag} {mode} d{n}", tol=TOL, floor=fl)
-            check(fix, f"{mode}.grad.{n}", p.grad.cpu(), tol=TOL, floor=fl, robust=True)
+            _gclose(p.grad, q.grad, f"block {tag} {mode} d{n}", tol=TOL, floor=fl, flips=fp)
+            check(fix, f"{mode}.grad.{n}", p.grad.cpu(), tol=TOL, floor=fl, robust=True, flips=fp)
     assert _sync_err(mine.bn.running_mean, ref.bn.running_mean) < TIGHT
     assert _sync_err(mine.bn.running_var, ref.bn.running_var) < TIGHT
     assert int(mine.bn.num_batches_tracked) == int(ref.bn.num_batches_tracked) == 1
@@ -105,12 +114,14 @@ def test_block_odd_shapes_strict(cin, c, h, w, kind):
     for mode in ("eval", "train"):
         ref.train(mode == "train"); mine.train(mode == "train")
         ref.zero_grad(); mine.zero_grad()
+        keep = ops.keep_block_activations(mine)
         xr = x.clone().requires_grad_(True); (ref(xr) * r).sum().backward()
         xm = x.clone().to(DEV).requires_grad_(True); (mine(xm) * r.to(DEV)).sum().backward()
-        _gclose(xm.grad, xr.grad, f"odd block {h}x{w} {mode} dx", tol=TOL)
+        fp = _flips(ref, (x,), keep, f"odd block {h}x{w} {mode}")          # [] on the current kernels: the comparison is strict
+        _gclose(xm.grad, xr.grad, f"odd block {h}x{w} {mode} dx", tol=TOL, flips=fp)
         fl = _gscale(ref)
         for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
-            _gclose(p.grad, q.grad, f"odd block {h}x{w} {mode} d{n}", tol=TOL, floor=fl)
+            _gclose(p.grad, q.grad, f"odd block {h}x{w} {mode} d{n}", tol=TOL, floor=fl, flips=fp)
 
 
 @pytest.mark.parametrize("tag,cin,h,w", [("spec3_64x96", 3, 64, 96), ("spec4_32x64", 4, 32, 64), ("spec3_100x75", 3, 100, 75)])
@@ -290,14 +301,25 @@ def test_eegnet_attention_deep_dropout_and_bench_batch():
     assert torch.equal(y1, y2)
 
 
-@pytest.mark.parametrize("tag,cfg", [("mm_bench_small", (19, 2000, 4, 32, 64, 4)), ("mm_native_small", (37, 3000, 3, 50, 37, 2))])
+MM_CASES = {"mm_bench_small": (19, 2000, 4, 32, 64, 4), "mm_native_small": (37, 3000, 3, 100, 75, 4)}
+
+
+@pytest.mark.parametrize("tag", list(MM_CASES))
 @pytest.mark.parametrize("opt", ["flat", "torch"])
-def test_multimodal_train3(tag, cfg, opt):
-    chans, samples, cin, h, w, b = cfg
+def test_multimodal_train3(tag, opt):
+    """Rows D/E: logits, both KLDiv reductions, step-0 gradients (strict 1e-3 unless an activation flip is OBSERVED) and the
+    3-step AdamW trajectory against the oracle and the fixture recorded from the reference classes.  mm_native_small is the
+    reference's native geometry (37x3000 EEG, 3-plane odd-sized spectrogram -> true bilinear skips) at a size where every
+    train-mode BatchNorm sees >= 24 values per channel (the round-1 fixture, 50x37 with B=2, left block5's BatchNorm with TWO
+    values per channel: its backward is a cancellation, and the reference's own fp32 gradients sat 4.6e-4 from their fp64
+    values there -- oracle.ref_torch.conditioning; the fixture records that number for its own inputs)."""
+    import copy
+    chans, samples, cin, h, w, b = MM_CASES[tag]
     fix = load(tag)
+    seeds = [int(v) for v in fix["input_seeds"]]
     ref, mine = _pair(lambda: O.build_multimodal(chans, samples, cin, dropout=0.0),
                       lambda: brainxai.build_multimodal(chans, samples, cin, dropout=0.0), 41)
-    eeg, spec = O.seeded((b, 1, chans, samples), 42, "randn"), O.seeded((b, cin, h, w), 43, "rand")
+    eeg, spec = O.seeded((b, 1, chans, samples), seeds[0], "randn"), O.seeded((b, cin, h, w), seeds[1], "rand")
     labels = torch.from_numpy(fix["labels"])
     e, s, lab = eeg.to(DEV), spec.to(DEV), labels.to(DEV)
     ref.eval(); mine.eval()
@@ -315,25 +337,62 @@ def test_multimodal_train3(tag, cfg, opt):
     losses = []
     try:
         for step in range(3):
+            ref0 = copy.deepcopy(ref) if step == 0 else None
+            keep = ops.keep_block_activations(mine, on=(step == 0))
             O.train_step(ref, opt_r, eeg, spec, labels)
             loss, _ = brainxai.train_step(mine, opt_m, e, s, lab, crit)
             losses.append(float(loss))
             if step == 0:
+                fp = _flips(ref0, (eeg, spec), keep, f"mm {tag} step0")
                 fl = _gscale(ref)
                 for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
-                    _gclose(p.grad, q.grad, f"mm {tag} step0 d{n}", tol=TOL, floor=fl)
-                    check(fix, "step0.ghead." + n, p.grad.flatten()[:32].cpu(), tol=TOL, floor=fl, robust=True)
+                    _gclose(p.grad, q.grad, f"mm {tag} step0 d{n}", tol=TOL, floor=fl, flips=fp)
+                    check(fix, "step0.ghead." + n, p.grad.flatten()[:32].cpu(), tol=TOL, floor=fl, robust=True, flips=fp)
+        ops.keep_block_activations(mine, on=False)
+        # (a) free-running trajectory.  Step 0 sees identical weights: strict.  After that the trajectory is chaotic at these
+        # sizes on ANY implementation: AdamW's update lr * m^ / (sqrt(v^) + 1e-8) is lr * sign(g) at step 1 whatever |g| is, so
+        # every entry whose gradient is rounding noise walks +-lr independently, and train-mode BatchNorm over a handful of
+        # values turns that into O(1) changes of later gradients -- the oracle's own fp32 and fp64 runs of these three steps
+        # end 3.5e-3 apart in weights whose gradients are large.  Hence: losses to 3e-2, states to the 3-step bound.
+        assert abs(losses[0] - float(fix["train.losses"][0])) <= TOL * abs(float(fix["train.losses"][0]))
+        np.testing.assert_allclose(np.array(losses), fix["train.losses"], rtol=3e-2)
+        for (n, t), (_, t2) in zip(mine.state_dict().items(), ref.state_dict().items()):
+            assert float((t.detach().float().cpu() - t2.float()).abs().max()) <= 4e-3 * max(1.0, float(t2.float().abs().max())), n
+            want = torch.from_numpy(fix["after3.shead." + n]).float()
+            assert float((t.detach().float().flatten()[:32].cpu() - want).abs().max()) <= 4e-3 * max(1.0, float(want.abs().max())), n
+        # (b) the optimizer arithmetic itself, strictly: three more steps, each started from the ORACLE's state (weights, buffers,
+        # AdamW moments and step count copied over), so that both sides take the same step from the same point.  Entries whose
+        # gradient is above 1e-3 of their tensor's (and 1e-5 of the model's) largest are well-posed: a 1e-3 relative gradient
+        # difference moves the normalised update by O(1e-3) -> 5e-6 absolute (oracle fp32 vs fp64: < 1e-6).
+        for step in range(3, 6):
+            mine.load_state_dict(ref.state_dict())
+            _sync_adamw(opt_m, opt_r)
+            O.train_step(ref, opt_r, eeg, spec, labels)
+            brainxai.train_step(mine, opt_m, e, s, lab, crit)
+            torch.cuda.synchronize()
+            gm = max(float(q.grad.abs().max()) for q in ref.parameters())
+            for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+                solid = q.grad.abs() > 1e-3 * max(float(q.grad.abs().max()), 1e-2 * gm)
+                dev = (p.detach().cpu() - q.detach()).abs()
+                if solid.any():
+                    assert float(dev[solid].max()) <= 5e-6, (step, n, float(dev[solid].max()))
+                assert float(dev.max()) <= 2.2e-3, (step, n, float(dev.max()))           # a noise entry moves by <= ~lr on either side
     finally:
+        ops.keep_block_activations(mine, on=False)
         ops.clear_grad_views()
-    # step 0 sees identical weights: strict.  Later losses follow AdamW trajectories that differ by +-lr in every
-    # weight whose gradient is rounding noise (m/sqrt(v) normalises noise to +-1), so they agree to ~1e-2 only.
-    assert abs(losses[0] - float(fix["train.losses"][0])) <= TOL * abs(float(fix["train.losses"][0]))
-    np.testing.assert_allclose(np.array(losses), fix["train.losses"], rtol=3e-2)
-    # AdamW's first steps move every weight by ~lr*sign(g): a weight whose gradient is rounding noise can move
-    # by +-lr either way, so states are compared with an absolute floor of a few lr
-    for (n, t), (_, t2) in zip(mine.state_dict().items(), ref.state_dict().items()):
-        _gclose(t.float(), t2.float(), f"mm {tag} state {n}", tol=TOL, floor=4.0)
-        check(fix, "after3.shead." + n, t.float().flatten()[:32].cpu(), tol=TOL, floor=4.0, robust=True)
+
+
+def _sync_adamw(opt_m, opt_r):
+    """Copy torch.optim.AdamW's moments and step count of the oracle into the optimizer under test."""
+    sd = opt_r.state_dict()
+    n = len(sd["state"])
+    if isinstance(opt_m, brainxai.FlatAdamW):
+        opt_m.load_state_dict({"flat_adamw": 1, "step": torch.tensor([float(sd["state"][0]["step"])]),
+                               "exp_avg": torch.cat([sd["state"][i]["exp_avg"].flatten() for i in range(n)]),
+                               "exp_avg_sq": torch.cat([sd["state"][i]["exp_avg_sq"].flatten() for i in range(n)]),
+                               "param_groups": opt_m.param_groups})
+    else:
+        opt_m.load_state_dict(sd)
 
 
 def _attr_models():
@@ -616,12 +675,10 @@ def test_gradcam_sweep_matches_eager():
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("branches", [False, pytest.param(True, marks=pytest.mark.xfail(strict=False, reason=(
-    "experimental BX_BRANCH_GRAPHS mode: memory visibility across queues at graph boundaries is not guaranteed on this stack "
-    "(DESIGN.md section 6); bit-identical with BX_BRANCH_SYNC=1")))])
-def test_graphed_train_step_matches_eager(branches, dt):
+def test_graphed_train_step_matches_eager(dt):
     """GraphedTrainStep (eager first batch, capture on the second, replay afterwards) walks the same trajectory as eager steps,
-    as one hipGraph and as the six-graph branch-parallel form (EEG branch on a side stream beside the spectrogram branch)"""
+    bit for bit -- including a learning-rate change after the capture (the optimizer's hyper-parameters are read from a device
+    buffer, so a scheduler keeps working under replay; round 1 baked them into the captured launch)."""
     def make():
         torch.manual_seed(9)
         m = brainxai.build_multimodal(19, 2000, 4, dropout=0.5, compute_dtype=dt).to(DEV).train()
@@ -631,21 +688,64 @@ def test_graphed_train_step_matches_eager(branches, dt):
     crit = brainxai.KLDivLoss()
     try:
         m1, o1 = make(); ops.manual_seed(1234)
+        sched1 = torch.optim.lr_scheduler.StepLR(o1, step_size=4, gamma=0.1)         # lr 1e-3 for 4 steps, then 1e-4
         eager = []
         for (e, s), y in batches:
-            loss, _ = brainxai.train_step(m1, o1, e, s, y, crit); eager.append(float(loss))
+            loss, _ = brainxai.train_step(m1, o1, e, s, y, crit); eager.append(float(loss)); sched1.step()
         p1 = torch.cat([p.detach().flatten() for p in m1.parameters()]).clone()
-        ops.clear_grad_views()
+        o1.close()
         m2, o2 = make(); ops.manual_seed(1234)
+        sched2 = torch.optim.lr_scheduler.StepLR(o2, step_size=4, gamma=0.1)
         step = brainxai.GraphedTrainStep(m2, o2, crit)
-        step.branches = branches
-        graphed = [float(step([e, s], y)[0]) for (e, s), y in batches]
+        graphed = []
+        for (e, s), y in batches:
+            graphed.append(float(step([e, s], y)[0])); sched2.step()
         torch.cuda.synchronize()
         p2 = torch.cat([p.detach().flatten() for p in m2.parameters()])
         assert step.enabled and len(step._graphs) == 1
-        assert (next(iter(step._graphs.values()))[0] == "branches") == branches
+        assert abs(o2.param_groups[0]["lr"] - 1e-4) < 1e-12
         np.testing.assert_allclose(graphed, eager, rtol=1e-5)
         assert float((p1 - p2).abs().max()) < 1e-6
+        # and the schedule mattered: without it the weights end somewhere else
+        m3, o3 = make(); ops.manual_seed(1234)
+        for (e, s), y in batches:
+            brainxai.train_step(m3, o3, e, s, y, crit)
+        p3 = torch.cat([p.detach().flatten() for p in m3.parameters()])
+        assert float((p1 - p3).abs().max()) > 1e-4
+    finally:
+        ops.clear_grad_views()
+
+
+def test_gradient_accumulation_is_refused_not_silently_wrong():
+    """FlatAdamW's weight-gradient kernels write their arena slice: a second backward() without zero_grad() would make autograd
+    add the slice to itself.  It must raise, and zero_grad(set_to_none=False) must not arm the same trap."""
+    torch.manual_seed(1)
+    net = brainxai.EEGNet(6, Chans=19, Samples=2000, dropoutRate=0.0).to(DEV).train()
+    opt = brainxai.FlatAdamW(net.parameters(), lr=1e-3)
+    x, y = torch.randn(4, 1, 19, 2000, device=DEV), torch.softmax(torch.randn(4, 6, device=DEV), 1)
+    try:
+        brainxai.KLDivLoss()(net(x), y).backward()
+        g1 = opt.flat_g.clone()
+        with pytest.raises(RuntimeError, match="accumulation"):
+            brainxai.KLDivLoss()(net(x), y).backward()
+        opt.zero_grad()
+        brainxai.KLDivLoss()(net(x), y).backward()
+        torch.cuda.synchronize()
+        assert torch.equal(opt.flat_g, g1)
+        # a frozen attribution pass after a training backward leaves the arena alone
+        full = brainxai.build_multimodal(19, 2000, 4, dropout=0.0).to(DEV).train()
+        opt2 = brainxai.FlatAdamW(full.parameters(), lr=1e-3)
+        e, s = torch.randn(2, 1, 19, 2000, device=DEV), torch.rand(2, 4, 32, 64, device=DEV)
+        brainxai.KLDivLoss()(full(e, s), y[:2]).backward()
+        g2 = opt2.flat_g.clone()
+        brainxai.grad_cam(full, e, s, target_layer="spectrogram_model.block3", class_idx="all")
+        brainxai.saliency(full, e, s)
+        torch.cuda.synchronize()
+        assert torch.equal(opt2.flat_g, g2)
+        # registrations die with their optimizer
+        key_ptrs = [p.data_ptr() for p in net.parameters()]
+        opt.close()
+        assert not any(k in ops._GRAD_VIEW for k in key_ptrs)
     finally:
         ops.clear_grad_views()
 
@@ -669,6 +769,36 @@ def test_async_checkpoint_equals_synchronous(tmp_path):
         assert torch.equal(a["state_dict"][k], b["state_dict"][k]), k
     for k in ("step", "exp_avg", "exp_avg_sq"):
         assert torch.equal(a["optimizer"][k], b["optimizer"][k]), k
+
+
+def test_async_checkpoint_is_a_snapshot_not_a_view(tmp_path):
+    """state_dict entries are views of the live arena / BatchNorm buffers.  A training step queued right after save()
+    must not leak into the file: the file must equal a synchronous snapshot taken BEFORE that step."""
+    torch.manual_seed(4)
+    net = brainxai.build_multimodal(19, 2000, 4, dropout=0.0).to(DEV).train()
+    opt = brainxai.FlatAdamW(net.parameters(), lr=1e-2)
+    eeg, spec = O.seeded((8, 1, 19, 2000), 1, "randn").to(DEV), O.seeded((8, 4, 64, 128), 2, "rand").to(DEV)
+    lab = torch.softmax(O.seeded((8, 6), 3, "randn"), 1).to(DEV)
+    crit = brainxai.KLDivLoss()
+    try:
+        for _ in range(2):
+            brainxai.train_step(net, opt, eeg, spec, lab, crit)
+        torch.cuda.synchronize()
+        want = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        want_m = opt.exp_avg.detach().cpu().clone()
+        saver = brainxai.AsyncCheckpointer(str(tmp_path), "ck.pth.tar")
+        saver.save({"state_dict": net.state_dict(), "optimizer": opt.state_dict()})
+        for _ in range(3):                                  # queued immediately behind the snapshot: rewrites the whole arena
+            brainxai.train_step(net, opt, eeg, spec, lab, crit)
+        saver.wait()
+        torch.cuda.synchronize()
+        got = torch.load(tmp_path / "ck.pth.tar", map_location="cpu", weights_only=False)
+        assert not torch.equal(net.state_dict()["fc1.weight"].cpu(), want["fc1.weight"]), "the extra steps must have moved the weights"
+        for k in want:
+            assert torch.equal(got["state_dict"][k], want[k]), k
+        assert torch.equal(got["optimizer"]["exp_avg"], want_m)
+    finally:
+        ops.clear_grad_views()
 
 
 def test_full_size_properties():
@@ -732,6 +862,147 @@ def test_rccl_single_rank_group_matches_plain_training():
     assert torch.equal(finals[0], finals[1])
 
 
+def test_overlapped_ddp_step_single_rank_matches_plain_training():
+    """The overlapped data-parallel step (autograd cut after spectrogram stage 2, two asynchronous RCCL all-reduces of arena
+    slices, eager and as the two-graph replay) on a 1-rank group: bit-identical to plain training, dropout on."""
+    import os
+    import socket
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    batches = [((O.seeded((4, 1, 19, 2000), 190 + i, "randn").to(DEV), O.seeded((4, 4, 32, 64), 195 + i, "rand").to(DEV)),
+                torch.softmax(O.seeded((4, 6), 199 + i, "randn"), 1).to(DEV)) for i in range(5)]
+    crit = brainxai.KLDivLoss()
+
+    def make():
+        torch.manual_seed(3)
+        net = brainxai.build_multimodal(19, 2000, 4, dropout=0.5, compute_dtype=torch.bfloat16).to(DEV).train()
+        return net, brainxai.FlatAdamW(net.parameters(), lr=1e-3)
+    finals = {}
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+    try:
+        for mode in ("plain", "overlap_eager", "overlap_graph", "single_collective_graph"):
+            net, opt = make(); ops.manual_seed(4321)
+            ddp = brainxai.DataParallel(net) if mode != "plain" else None
+            if mode == "overlap_graph" or mode == "single_collective_graph":
+                if mode == "single_collective_graph":
+                    os.environ["BX_DDP_OVERLAP"] = "0"
+                step = brainxai.GraphedTrainStep(net, opt, crit, ddp=ddp)
+                os.environ.pop("BX_DDP_OVERLAP", None)
+                assert (step.plan is not None) == (mode == "overlap_graph")
+                losses = [float(step([e, s_], y)[0]) for (e, s_), y in batches]
+                assert len(step._graphs) == 1 and next(iter(step._graphs.values()))[0] == ("overlap" if mode == "overlap_graph" else "one")
+            elif mode == "overlap_eager":
+                assert brainxai.overlap_plan(net, opt) is not None
+                losses = [float(brainxai.train_step_overlapped(net, opt, e, s_, y, crit, ddp)[0]) for (e, s_), y in batches]
+            else:
+                losses = [float(brainxai.train_step(net, opt, e, s_, y, crit)[0]) for (e, s_), y in batches]
+            torch.cuda.synchronize()
+            finals[mode] = (losses, opt.flat_p.clone())
+            opt.close()
+    finally:
+        dist.destroy_process_group()
+        ops.clear_grad_views()
+    for mode in finals:
+        assert finals[mode][0] == finals["plain"][0], mode
+        assert torch.equal(finals[mode][1], finals["plain"][1]), mode
+
+
+def _microbatch(r, b=4):
+    return (O.seeded((b, 1, 19, 2000), 420 + r, "randn"), O.seeded((b, 4, 32, 64), 430 + r, "rand"),
+            torch.softmax(O.seeded((b, 6), 440 + r, "randn"), 1))
+
+
+def _check_ddp_mean(flat_mean, net, fix):
+    got = O.summarize(flat_mean)
+    np.testing.assert_allclose(got[[1, 3]], fix["mean.gsum"][[1, 3]], rtol=2e-3)
+    fl = 1e-2 * float(fix["mean.gmax"][0])
+    off = 0
+    for n, p in net.named_parameters():
+        k = min(32, p.numel())
+        check(fix, "mean.ghead." + n, flat_mean[off:off + k], tol=TOL, floor=fl)
+        off += p.numel()
+
+
+def test_ddp_microbatch_gradient_mean_matches_reference():
+    """SURVEY 8(c) fixture 9 on one GPU: the gradients of 8 micro-batches (each its own forward/backward from the same weights,
+    BatchNorm statistics local to the micro-batch = the reference's DDP semantics) and their mean against the values recorded
+    from the reference classes.  The N-rank test below all-reduces the same gradients over RCCL."""
+    fix = load("ddp8_bench_small")
+    world = int(fix["world"][0])
+    ref = O.fill_params(O.build_multimodal(19, 2000, 4, dropout=0.0), seed=41)
+    net = brainxai.build_multimodal(19, 2000, 4, dropout=0.0)
+    net.load_state_dict(ref.state_dict())
+    net.to(DEV).train()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    mean = None
+    for r in range(world):
+        net.load_state_dict(sd)                         # every replica starts from the same weights AND buffers
+        net.zero_grad(set_to_none=True)
+        eeg, spec, lab = _microbatch(r)
+        brainxai.KLDivLoss()(net(eeg.to(DEV), spec.to(DEV)), lab.to(DEV)).backward()
+        torch.cuda.synchronize()
+        g = torch.cat([p.grad.flatten() for p in net.parameters()]).cpu()
+        check(fix, f"rank{r}.ghead", g[:64], tol=TOL, floor=1e-2 * float(fix["mean.gmax"][0]))
+        mean = g.double() if mean is None else mean + g.double()
+    _check_ddp_mean((mean / world).float(), net, fix)
+
+
+def _ddp_rank(rank, world, port, outdir):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    brainxai.setup(rank, world, backend="nccl")
+    try:
+        ref = O.fill_params(O.build_multimodal(19, 2000, 4, dropout=0.0), seed=41 + rank)     # ranks start from DIFFERENT weights:
+        net = brainxai.build_multimodal(19, 2000, 4, dropout=0.0)                              # the wrapper must broadcast rank 0's
+        net.load_state_dict(ref.state_dict())
+        net.to(dev).train()
+        ddp = brainxai.DataParallel(net)
+        opt = brainxai.FlatAdamW(net.parameters(), lr=1e-3)
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        acc = torch.zeros_like(opt.flat_g)
+        mine = list(range(rank, 8, world))              # 8 micro-batches dealt to the ranks
+        for r in mine:
+            net.load_state_dict(sd)
+            opt.zero_grad()
+            eeg, spec, lab = _microbatch(r)
+            brainxai.KLDivLoss()(net(eeg.to(dev), spec.to(dev)), lab.to(dev)).backward()
+            opt.gather_grads()
+            acc += opt.flat_g / len(mine)
+        opt.flat_g.copy_(acc)
+        plan = brainxai.overlap_plan(net, opt)
+        r1 = ddp.reduce_async(opt.flat_g.narrow(0, plan[2], opt.n - plan[2]))                 # the overlapped step's two buckets
+        r2 = ddp.reduce_async(opt.flat_g.narrow(0, 0, plan[2]))
+        r1.wait(); r2.wait()
+        torch.cuda.synchronize()
+        torch.save(opt.flat_g.cpu(), os.path.join(outdir, f"g{rank}.pt"))
+    finally:
+        brainxai.cleanup()
+        ops.clear_grad_views()
+
+
+def test_ddp_allreduce_over_rccl_matches_reference_mean(tmp_path):
+    """configs[2] correctness: N ranks (N = 8, 4 or 2 GPUs, whatever the box has; skipped on a 1-GPU box) compute the 8 recorded
+    micro-batch gradients between them and average them with the wrapper's RCCL all-reduce over xGMI: every rank must end with
+    the mean recorded from the reference classes (fixture 9)."""
+    import socket
+    import torch.multiprocessing as mp
+    n = torch.cuda.device_count()
+    world = 8 if n >= 8 else 4 if n >= 4 else 2 if n >= 2 else 0
+    if world == 0:
+        pytest.skip("needs at least 2 GPUs")
+    fix = load("ddp8_bench_small")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_ddp_rank, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ref = O.build_multimodal(19, 2000, 4, dropout=0.0)
+    grads = [torch.load(tmp_path / f"g{r}.pt") for r in range(world)]
+    for g in grads[1:]:
+        assert torch.equal(g, grads[0]), "replicas must hold identical averaged gradients"
+    _check_ddp_mean(grads[0], ref, fix)
+
+
 def _toy_loader(n_batches, b, seed):
     out = []
     for i in range(n_batches):
@@ -792,28 +1063,90 @@ def test_train_and_validate_combined_loop(tmp_path):
         ops.clear_grad_views()
 
 
+class _ListLogger:
+    def __init__(self):
+        self.lines = []
+
+    def info(self, msg):
+        self.lines.append(msg)
+
+
 @pytest.mark.parametrize("arch", ["EEGNet", "EEGNetAttentionDeep"])
-def test_train_and_validate_eeg_distributed_single_rank(tmp_path, arch):
-    """row F: reference training_distributed.py loop on a 1-rank RCCL group: DDP wrapper, manual L2 term, module.-prefixed
-    checkpoint with the extra keys the reference's load_checkpoint expects"""
+@pytest.mark.parametrize("flat", [True, False])
+def test_train_and_validate_eeg_distributed_against_oracle(tmp_path, arch, flat):
+    """Row F: the reference's DDP epoch loop (training_distributed.py:22-141) on a 1-rank RCCL group against the oracle's
+    restatement (oracle.ref_torch.distributed_epoch): the L2 penalty's value, its gradient (through the first optimizer step),
+    the sample-normalised running losses, accuracies, the plateau scheduler's learning-rate history, the checkpoint's keys and
+    a resumed third epoch.  Dropout 0: both sides see the same network."""
+    import os
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.manual_seed(5)
-    net = getattr(brainxai, arch)(6, Chans=19, Samples=2000, dropoutRate=0.25)
-    net.weight_decay = 1e-4
+    wd = 2e-3
+    ref = O.fill_params(getattr(O, arch)(6, Chans=19, Samples=2000, dropoutRate=0.0), seed=77)
+    net = getattr(brainxai, arch)(6, Chans=19, Samples=2000, dropoutRate=0.0)
+    net.load_state_dict(ref.state_dict())
+    net.weight_decay = wd
     data = [(O.seeded((4, 1, 19, 2000), 70 + i, "randn"), torch.softmax(O.seeded((4, 6), 80 + i, "randn"), 1)) for i in range(3)]
+    valid = data[:2]
     net.to(DEV)
-    opt = brainxai.FlatAdamW(net.parameters(), lr=1e-3)
+    opt = brainxai.FlatAdamW(net.parameters(), lr=1e-3) if flat else torch.optim.AdamW(net.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.5, patience=0)
+    opt_r = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+    sched_r = torch.optim.lr_scheduler.ReduceLROnPlateau(opt_r, mode="min", factor=0.5, patience=0)
+    crit_r = lambda o, y: O.kl_div(o, y, "batchmean")       # noqa: E731
+    first = {}
+    want = []
+    for ep in range(2):
+        def grab(i, loss, reg, model, ep=ep):
+            if ep == 0 and i == 0:
+                first.update(loss=float(loss), reg=float(reg), grads={n: p.grad.clone() for n, p in model.named_parameters()},
+                             before={n: p.detach().clone() for n, p in model.named_parameters()})
+        want.append(O.distributed_epoch(ref, data, valid, opt_r, crit_r, wd, sched_r, on_step=grab))
+        if ep == 0:
+            first["after_epoch"] = None
     try:
-        tl, vl, ta, va = brainxai.train_and_validate_eeg_distributed(net, data, data[:1], 2, opt, brainxai.KLDivLoss("batchmean"), None, DEV,
-                                                                       str(tmp_path), None, 0, 1)
-        assert len(tl) == 2 and np.isfinite(tl).all() and np.isfinite(vl).all() and tl[1] < tl[0] * 1.5
+        # (i) the penalty in isolation, on the initial weights: value and gradient
+        probe = getattr(brainxai, arch)(6, Chans=19, Samples=2000, dropoutRate=0.0)
+        probe.load_state_dict({k: v for k, v in O.fill_params(getattr(O, arch)(6, Chans=19, Samples=2000, dropoutRate=0.0), seed=77).state_dict().items()})
+        probe.to(DEV).train()
+        out = probe(data[0][0].to(DEV)); loss = brainxai.KLDivLoss("batchmean")(out, data[0][1].to(DEV)); loss.backward()
+        reg = brainxai.l2_penalty_(probe, wd)
+        torch.cuda.synchronize()
+        assert abs(float(loss) - first["loss"]) <= TOL * abs(first["loss"])
+        assert abs(float(reg) - first["reg"]) <= 1e-5 * abs(first["reg"]), (float(reg), first["reg"])
+        fl = 1e-2 * max(float(g.abs().max()) for g in first["grads"].values())
+        for n, p in probe.named_parameters():
+            _gclose(p.grad, first["grads"][n], f"row F {arch} d(loss+reg)/d{n}", tol=TOL, floor=fl)
+        del probe
+        # (ii) the loop
+        log = _ListLogger()
+        tl, vl, ta, va = brainxai.train_and_validate_eeg_distributed(net, data, valid, 2, opt, brainxai.KLDivLoss("batchmean"), sched, DEV,
+                                                                       str(tmp_path), log, 0, 1)
         ck = torch.load(tmp_path / "eeg_checkpoint.pth.tar", map_location="cpu", weights_only=False)
-        assert all(k.startswith("module.") for k in ck["state_dict"])
-        assert {"lr_scheduler", "regularization_losses"} <= set(ck) and len(ck["regularization_losses"]) == 2
-        assert ck["regularization_losses"][0] > 0
+        assert set(ck) == {"epoch", "state_dict", "optimizer", "train_losses", "valid_losses", "train_accuracies", "valid_accuracies",
+                           "lr_scheduler", "regularization_losses"}
+        assert all(k.startswith("module.") for k in ck["state_dict"]) and ck["epoch"] == 2
+        # epoch 1 starts from identical weights: three AdamW steps of well-posed gradients -> tight; epoch 2 has drifted by the
+        # noise-gradient entries (zero-gradient BatchNorm1 affine of EEGNet walks +-lr): looser
+        assert abs(tl[0] - want[0]["train_loss"]) <= 2e-3 * abs(want[0]["train_loss"]), (tl, want[0])
+        assert abs(ck["regularization_losses"][0] - want[0]["reg_loss"]) <= 1e-4 * want[0]["reg_loss"], (ck["regularization_losses"], want[0])
+        assert abs(vl[0] - want[0]["valid_loss"]) <= 2e-2 * abs(want[0]["valid_loss"])
+        assert abs(tl[1] - want[1]["train_loss"]) <= 3e-2 * abs(want[1]["train_loss"])
+        assert abs(ck["regularization_losses"][1] - want[1]["reg_loss"]) <= 1e-3 * want[1]["reg_loss"]
+        assert ta[0] == pytest.approx(want[0]["train_acc"]) and va[0] == pytest.approx(want[0]["valid_acc"])
+        # the learning-rate history: one entry per epoch, the values ReduceLROnPlateau leaves (the oracle's follow the same
+        # rule on its own validation losses; equal unless the two loss curves disagree about "improved")
+        assert len(ck["lr_scheduler"]) == 2 and ck["lr_scheduler"][0] == pytest.approx(1e-3)
+        if (vl[1] < vl[0]) == (want[1]["valid_loss"] < want[0]["valid_loss"]):
+            assert ck["lr_scheduler"][1] == pytest.approx(want[1]["lr"])
+        assert any("Starting Epoch 2/2" in ln for ln in log.lines)
+        # resume: a third epoch continues both histories from the checkpoint
+        tl3, *_ = brainxai.train_and_validate_eeg_distributed(net, data, valid, 3, opt, brainxai.KLDivLoss("batchmean"), sched, DEV,
+                                                              str(tmp_path), None, 0, 1)
+        ck3 = torch.load(tmp_path / "eeg_checkpoint.pth.tar", map_location="cpu", weights_only=False)
+        assert len(tl3) == 3 and tl3[:2] == tl and len(ck3["regularization_losses"]) == 3 and len(ck3["lr_scheduler"]) == 3
+        assert ck3["regularization_losses"][:2] == ck["regularization_losses"]
     finally:
         brainxai.cleanup()
         ops.clear_grad_views()

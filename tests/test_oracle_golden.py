@@ -124,13 +124,15 @@ def test_attention_module():
 
 
 @pytest.mark.parametrize("tag,cfg", [("mm_bench_small", (19, 2000, 4, 32, 64, 4)),
-                                     ("mm_native_small", (37, 3000, 3, 50, 37, 2))])
+                                     ("mm_native_small", (37, 3000, 3, 100, 75, 4))])
 def test_multimodal_train3(tag, cfg):
     chans, samples, cin, h, w, b = cfg
     fix = load(tag)
     net = O.fill_params(O.build_multimodal(chans, samples, cin, dropout=0.0), seed=41)
-    eeg = O.seeded((b, 1, chans, samples), 42, "randn")
-    spec = O.seeded((b, cin, h, w), 43, "rand")
+    seeds = [int(v) for v in fix["input_seeds"]]
+    eeg = O.seeded((b, 1, chans, samples), seeds[0], "randn")
+    spec = O.seeded((b, cin, h, w), seeds[1], "rand")
+    assert float(fix["conditioning"][0]) < 1e-4          # the recorded fp32 run is a well-posed target (make_golden checks flips too)
     labels = torch.from_numpy(fix["labels"])
     net.eval()
     y = net(eeg, spec)
@@ -151,6 +153,29 @@ def test_multimodal_train3(tag, cfg):
     check(fix, "train.losses", np.array(losses))
     for n, t in net.state_dict().items():
         check(fix, "after3.shead." + n, t.float().flatten()[:32], tol=2e-5)
+
+
+def test_ddp_microbatch_gradients_and_mean():
+    """SURVEY 8(c) fixture 9: gradients of the reference classes on 8 micro-batches and their mean (what all-reduce(AVG) of the
+    flat gradient arena must give): the oracle reproduces each rank's gradient and the mean"""
+    fix = load("ddp8_bench_small")
+    world, b = int(fix["world"][0]), int(fix["batch"][0])
+    mean = None
+    for r in range(world):
+        net = O.fill_params(O.build_multimodal(19, 2000, 4, dropout=0.0), seed=41).train()
+        eeg, spec = O.seeded((b, 1, 19, 2000), 420 + r, "randn"), O.seeded((b, 4, 32, 64), 430 + r, "rand")
+        labels = torch.softmax(O.seeded((b, 6), 440 + r, "randn"), 1)
+        O.kl_div(net(eeg, spec), labels).backward()
+        g = torch.cat([p.grad.flatten() for p in net.parameters()])
+        check(fix, f"rank{r}.ghead", g[:64], tol=2e-5)
+        np.testing.assert_allclose(O.summarize(g)[[1, 3]], fix[f"rank{r}.gsum"][[1, 3]], rtol=1e-5)
+        mean = g.double() if mean is None else mean + g.double()
+    mean = (mean / world).float()
+    np.testing.assert_allclose(O.summarize(mean)[[1, 3]], fix["mean.gsum"][[1, 3]], rtol=1e-5)
+    off = 0
+    for n, p in net.named_parameters():
+        check(fix, "mean.ghead." + n, mean[off:off + min(32, p.numel())], tol=2e-5, floor=1e-2 * float(fix["mean.gmax"][0]))
+        off += p.numel()
 
 
 def test_gradcam_saliency_ig():
