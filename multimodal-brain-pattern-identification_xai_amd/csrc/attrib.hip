@@ -162,7 +162,11 @@ __global__ __launch_bounds__(256) void k_gradcam_head(const T* __restrict__ A, c
   for (int ci = 0; ci < nm; ++ci) {
     const int c = first + ci;
     // ---- backward of the fused head for the score y_c = lp[c]:  d logits = onehot(c) - softmax
-    if (tid < N) dz[tid] = (tid == c ? 1.f : 0.f) - expf(lp[tid]);
+    if (tid < N) {                                       // (1 - p_c) as the sum of the other probabilities: no cancellation when p_c -> 1
+      float others = 0.f;
+      for (int jn = 0; jn < N; ++jn) if (jn != c) others += expf(lp[jn]);
+      dz[tid] = tid == c ? others : -expf(lp[tid]);
+    }
     __syncthreads();
     for (int j = tid; j < Hd; j += 256) {
       float acc = 0.f;
@@ -177,16 +181,12 @@ __global__ __launch_bounds__(256) void k_gradcam_head(const T* __restrict__ A, c
       if (lane == 0) ds[i] = acc;
     }
     __syncthreads();
-    if (tid == 0) {                                      // through LogSoftmax: dz_s = ds - softmax * sum(ds)
-      float tot = 0.f;
-      for (int i = 0; i < N; ++i) tot += ds[i];
-      for (int i = 0; i < N; ++i) ds[i] -= expf(cat[N + i]) * tot;
-    }
+    if (tid == 0) bx_lsm_bwd(ds, cat + N, N, dz);       // through the spectrogram head's LogSoftmax (dz is free again)
     __syncthreads();
     float* wdst = wout ? wout + ((size_t)b * nm + ci) * C : nullptr;
     for (int k = tid; k < C; k += 256) {                 // through fc and the mean over positions: w = W_fc^T dz_s / HW
       float acc = 0.f;
-      for (int i = 0; i < N; ++i) acc = fmaf(fcw[(size_t)i * C + k], ds[i], acc);
+      for (int i = 0; i < N; ++i) acc = fmaf(fcw[(size_t)i * C + k], dz[i], acc);
       acc *= inv_hw;
       w[k] = acc;
       if (wdst) wdst[k] = acc;
@@ -347,6 +347,189 @@ __global__ void k_eeg_stack_iir(const float* __restrict__ raw, const int* __rest
     }
   }
 }
+// ------------------------------------------------------------------------------------------------
+// The same filter as a CHUNKED SCAN (round 2).  One thread per row above is 1 216 threads walking 10 000 samples each
+// (19 waves on a 256-CU chip, 1.9 ms per 64-sample batch = 0.3 % of the HBM rate).  The recurrence is linear,
+//     z' = A z + Bx,   y = z[0] + b0 x,        A = shift - a e0^T   (direct form II transposed, as scipy.signal.lfilter runs it)
+// so a row is cut into chunks of S samples, one THREAD per (channel, chunk):
+//   phase A  every chunk runs the recurrence from a ZERO state over its S samples (inputs staged once per workgroup into LDS with
+//            coalesced 16-byte loads, already clipped / NaN-zeroed / scaled in fp32), keeps its decimated zero-state outputs in
+//            registers and leaves its end state in LDS;
+//   phase B  the true state entering chunk j is z_in[j+1] = A^S z_in[j] + (end state of chunk j): a short chain of ORDER x ORDER
+//            products over the chunks in front of it inside the workgroup;
+//   phase C  y[n] = y_zero_state[n] + e0^T A^n z_in  for the kept samples (rows of e0^T A^(m*step) precomputed on the host).
+// A workgroup covers G chunks of one sample; what came before its window enters through Kc extra WARM-UP chunks in front of it,
+// run from a zero state: the filter's memory decays like |pole|^n (0.795 for the reference's 4th-order 20 Hz Butterworth), and
+// the host picks Kc so that ||A^(Kc*S)|| < 1e-13 -- below fp64 resolution of the outputs -- or falls back to the sequential kernel
+// (filters with slow poles, e.g. the montage chain's 0.5 Hz band edge at radius 0.998, never take this path).  The first
+// workgroup of a row reads zeros in its warm-up chunks: the exact zero initial state of lfilter.  All arithmetic stays fp64.
+#define SCAN_MAX_KEEP 16
+struct IirScan {
+  double b[IIR_MAX_ORDER + 1], a[IIR_MAX_ORDER + 1];
+  double AS[IIR_MAX_ORDER][IIR_MAX_ORDER];          // A^S
+  double P[SCAN_MAX_KEEP][IIR_MAX_ORDER];           // e0^T A^(m*step), m < S/step
+};
+template <int ORDER, int STEP, int KEEP>
+__global__ __launch_bounds__(512) void k_eeg_stack_scan(const float* __restrict__ raw, const int* __restrict__ chan, float* __restrict__ out, int L,
+                                                         int Lout, int Craw, int C, IirScan k, int G, int Kc, float clip, float scale) {
+  constexpr int S = STEP * KEEP;
+  extern __shared__ float tile[];                    // [4 + G*S*Craw] staged inputs (later: [C][R*KEEP] outputs) | zs[G][C][ORDER] doubles
+  const int R = G - Kc, w = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int rows = G * S;
+  const long long t_first = ((long long)w * R - Kc) * S;                  // time of tile row 0 (negative in the first workgroup)
+  const long long gstart = ((long long)b * L + t_first) * Craw;           // float index of tile row 0 in `raw`
+  const int shift = (int)(((gstart % 4) + 4) % 4);                         // tile_f[q] <-> raw[gstart - shift + q]: 16-byte aligned loads
+  const long long gbase = gstart - shift;
+  double* zs = reinterpret_cast<double*>(tile + (((size_t)rows * Craw + 4 + 3) / 4 * 4 + 4));
+  // valid element range of the tile (times 0 <= t < L); everything else is zero input
+  const long long r_lo = t_first < 0 ? -t_first : 0;
+  const long long r_hi = (long long)L - t_first < rows ? (long long)L - t_first : rows;
+  const int q_lo = shift + (int)r_lo * Craw, q_hi = shift + (int)(r_hi > 0 ? r_hi : 0) * Craw;
+  const int nq4 = (shift + rows * Craw + 3) / 4;
+  const int i_lo = (q_lo + 3) / 4, i_hi = q_hi / 4;                        // 16-byte groups that lie entirely inside the valid range
+  const float4* g4 = reinterpret_cast<const float4*>(raw + gbase);
+  auto prep = [&](float e) {                                               // reference dataset.py:88-90 in fp32, as numpy does it
+    float xv = fminf(fmaxf(e, -clip), clip);                               // np.clip keeps NaN; fminf/fmaxf drop it -> handled next
+    if (e != e) xv = 0.f;                                                  // np.nan_to_num(nan=0)
+    return xv / scale;
+  };
+  for (int i0 = tid; i0 < nq4; i0 += 512 * 4) {                            // 4 x 16-byte loads per thread in flight per trip
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 512;
+      const int ic = (i >= i_lo && i < i_hi) ? i : i_lo;                   // clamped, always valid: an unconditional load, selected afterwards
+      v[u] = i_lo < i_hi ? g4[ic] : make_float4(0.f, 0.f, 0.f, 0.f);       // (the outer condition is workgroup-uniform)
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 512;
+      if (i < nq4) {
+        const bool ok = i >= i_lo && i < i_hi;
+        reinterpret_cast<float4*>(tile)[i] = ok ? make_float4(prep(v[u].x), prep(v[u].y), prep(v[u].z), prep(v[u].w)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 8) {                                                           // the (at most 3 + 3) valid elements in front of / behind the full groups
+    const int q = (tid < 4 ? 4 * (i_lo - 1) : 4 * i_hi) + (tid & 3);
+    if (q >= q_lo && q < q_hi && !(q >= 4 * i_lo && q < 4 * i_hi)) tile[q] = prep(raw[gbase + q]);
+  }
+  __syncthreads();
+  const int j = tid / C, c = tid - j * C;                                 // lanes of a wave: neighbouring channels (LDS banks), then chunks
+  const bool active = j < G;
+  double z[ORDER], y0[KEEP];
+#pragma unroll
+  for (int i = 0; i < ORDER; ++i) z[i] = 0.0;
+  if (active) {
+    const float* src = tile + shift + (size_t)j * S * Craw + (chan ? chan[c] : c);
+#pragma unroll
+    for (int m = 0; m < KEEP; ++m) {
+#pragma unroll
+      for (int q = 0; q < STEP; ++q) {
+        const double x = (double)src[(m * STEP + q) * Craw];
+        const double y = z[0] + k.b[0] * x;
+#pragma unroll
+        for (int i = 0; i < ORDER - 1; ++i) z[i] = z[i + 1] + k.b[i + 1] * x - k.a[i + 1] * y;
+        z[ORDER - 1] = k.b[ORDER] * x - k.a[ORDER] * y;
+        if (q == 0) y0[m] = y;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ORDER; ++i) zs[((size_t)j * C + c) * ORDER + i] = z[i];
+  }
+  __syncthreads();                                                        // end states visible; the input tile is dead from here on
+  float* otile = tile;                                                    // [C][R*KEEP]
+  if (active) {
+    double zi[ORDER];
+#pragma unroll
+    for (int i = 0; i < ORDER; ++i) zi[i] = 0.0;
+    for (int p = 0; p < j; ++p) {                                         // z_in[p+1] = A^S z_in[p] + end_state[p]
+      double t[ORDER];
+#pragma unroll
+      for (int r = 0; r < ORDER; ++r) {
+        double acc = zs[((size_t)p * C + c) * ORDER + r];
+#pragma unroll
+        for (int q = 0; q < ORDER; ++q) acc += k.AS[r][q] * zi[q];
+        t[r] = acc;
+      }
+#pragma unroll
+      for (int r = 0; r < ORDER; ++r) zi[r] = t[r];
+    }
+    if (j >= Kc) {
+#pragma unroll
+      for (int m = 0; m < KEEP; ++m) {
+        double y = y0[m];
+#pragma unroll
+        for (int q = 0; q < ORDER; ++q) y += k.P[m][q] * zi[q];
+        otile[(size_t)c * R * KEEP + (j - Kc) * KEEP + m] = (float)y;
+      }
+    }
+  }
+  __syncthreads();
+  const int o_first = w * R * KEEP, per = R * KEEP;                       // this workgroup's outputs: [o_first, o_first + per) of every row
+  for (int i = tid; i < C * per; i += 512) {
+    const int cc = i / per, o = i - cc * per;
+    if (o_first + o < Lout) out[((size_t)b * C + cc) * Lout + o_first + o] = otile[i];
+  }
+}
+
+// host: A^n helpers in plain doubles (ORDER <= 8)
+static void scan_matmul(int n, const double* X, const double* Y, double* Z) {
+  double T[IIR_MAX_ORDER * IIR_MAX_ORDER];
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c < n; ++c) {
+      double acc = 0.0;
+      for (int q = 0; q < n; ++q) acc += X[r * n + q] * Y[q * n + c];
+      T[r * n + c] = acc;
+    }
+  for (int i = 0; i < n * n; ++i) Z[i] = T[i];
+}
+template <int ORDER, int STEP, int KEEP>
+static int launch_stack_scan(const float* raw, const int* chan, float* out, int B, int L, int Craw, int C, const double* bn, const double* an,
+                             float clip, float scale, hipStream_t stream) {
+  constexpr int S = STEP * KEEP;
+  if (C > 512 || ((uintptr_t)raw & 15) != 0) return 0;
+  const int G = 512 / C;
+  double A[ORDER * ORDER], Pw[ORDER * ORDER], Astep[ORDER * ORDER];
+  for (int r = 0; r < ORDER; ++r)
+    for (int c = 0; c < ORDER; ++c) A[r * ORDER + c] = (c == 0 ? -an[r + 1] : 0.0) + (c == r + 1 ? 1.0 : 0.0);
+  IirScan k;
+  for (int i = 0; i <= IIR_MAX_ORDER; ++i) { k.b[i] = i <= ORDER ? bn[i] : 0.0; k.a[i] = i <= ORDER ? an[i] : 0.0; }
+  for (int i = 0; i < ORDER * ORDER; ++i) { Pw[i] = (i / ORDER == i % ORDER) ? 1.0 : 0.0; Astep[i] = Pw[i]; }
+  for (int q = 0; q < STEP; ++q) scan_matmul(ORDER, Astep, A, Astep);                     // A^STEP
+  for (int m = 0; m < KEEP; ++m) {                                                        // Pw = A^(m*STEP); row 0 = e0^T A^(m*STEP)
+    for (int q = 0; q < ORDER; ++q) k.P[m][q] = Pw[q];
+    scan_matmul(ORDER, Pw, Astep, Pw);
+  }
+  for (int r = 0; r < ORDER; ++r)
+    for (int c = 0; c < ORDER; ++c) k.AS[r][c] = Pw[r * ORDER + c];                       // A^S
+  // warm-up length: smallest Kc with ||A^(Kc*S)||_max < 1e-13
+  double M[ORDER * ORDER];
+  for (int i = 0; i < ORDER * ORDER; ++i) M[i] = Pw[i];
+  int Kc = 1;
+  for (;; ++Kc) {
+    double mx = 0.0;
+    for (int i = 0; i < ORDER * ORDER; ++i) mx = fmax(mx, fabs(M[i]));
+    if (mx < 1e-13) break;
+    if (!(mx < 1e6) || Kc >= G - 1) return 0;                                            // slow or unstable poles: sequential kernel
+    scan_matmul(ORDER, M, Pw, M);
+  }
+  const int R = G - Kc;
+  const size_t tile_f = ((size_t)G * S * Craw + 4 + 3) / 4 * 4 + 4;
+  const size_t lds = tile_f * sizeof(float) + (size_t)G * C * ORDER * sizeof(double);
+  if (lds > 160 * 1024 || (size_t)C * R * KEEP > tile_f) return 0;
+  static size_t attr_set = 0;
+  if (lds > 64 * 1024 && lds > attr_set) {
+    if (hipFuncSetAttribute((const void*)k_eeg_stack_scan<ORDER, STEP, KEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
+    attr_set = lds;
+  }
+  const int nwg = bx_ceil_div(L, R * S);
+  hipLaunchKernelGGL((k_eeg_stack_scan<ORDER, STEP, KEEP>), dim3(nwg, B), dim3(512), lds, stream, raw, chan, out, L, (L + STEP - 1) / STEP, Craw, C, k,
+                     G, Kc, clip, scale);
+  return 1;
+}
+
 extern "C" int bx_eeg_stack_iir(const float* raw, const int* channel_index, float* out, int B, int L, int Craw, int C,
                                 const double* b_host, const double* a_host, int order, int step, float clip, float scale,
                                 bxStream stream) {
@@ -357,6 +540,13 @@ extern "C" int bx_eeg_stack_iir(const float* raw, const int* channel_index, floa
   const double a0 = a_host[0];
   BX_REQUIRE(a0 != 0.0, "bx_eeg_stack_iir: a[0] == 0");
   for (int i = 0; i <= IIR_MAX_ORDER; ++i) { k.b[i] = i <= order ? b_host[i] / a0 : 0.0; k.a[i] = i <= order ? a_host[i] / a0 : 0.0; }
+  BX_REQUIRE(B <= 65535, "bx_eeg_stack_iir: batch %d exceeds the grid's y extent", B);
+  // the reference's configuration (4th order, keep every 5th sample) takes the chunked scan; anything else, or a filter whose
+  // memory is too long for a warm-up, the one-thread-per-row recurrence
+  if (order == 4 && step == 5 && launch_stack_scan<4, 5, 8>(raw, channel_index, out, B, L, Craw, C, k.b, k.a, clip, scale, (hipStream_t)stream)) {
+    BX_CHECK_LAUNCH("bx_eeg_stack_iir (scan)");
+    return BX_OK;
+  }
   const int nrows = B * C;
   hipLaunchKernelGGL(k_eeg_stack_iir, dim3(bx_ceil_div(nrows, 64)), dim3(64), 0, (hipStream_t)stream, raw, channel_index, out,
                      nrows, L, Craw, C, k, order, step, clip, 1.f / scale);

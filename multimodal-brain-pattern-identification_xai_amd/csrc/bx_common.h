@@ -116,6 +116,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// LogSoftmax backward for one row, dz_n = dy_n - softmax_n * sum_j dy_j, evaluated WITHOUT its cancellation:
+//     dz_n = dy_n * (sum_{j != n} p_j)  -  p_n * (sum_{j != n} dy_j),      p = exp(logp).
+// The textbook form computes (1 - p_n) by subtraction; with a one-hot seed on a confident sample (saliency / Grad-CAM of the
+// arg-max class: p_n -> 1) that turns an absolute 1e-6 error of the log-prob into a relative 1e-6 / (1 - p_n) error of every
+// gradient behind it (measured: 1.1e-3 on the saliency maps at fp32, against 4e-5 for the cancellation-free form).
+// Plain pointers (global or LDS), runtime N, O(N^2) for the N <= 32 classes the heads support (N = 6 in the reference).
+__device__ __forceinline__ void bx_lsm_bwd(const float* dy, const float* logp, int N, float* dz) {
+  for (int n = 0; n < N; ++n) {
+    float ps = 0.f, ds = 0.f;
+    for (int j = 0; j < N; ++j)
+      if (j != n) { ps += expf(logp[j]); ds += dy[j]; }
+    dz[n] = dy[n] * ps - expf(logp[n]) * ds;
+  }
+}
+
 // Cooperative LDS fill: dst[i] = load(i) for i < n.  U loads per thread are issued before the first LDS store, so a fill
 // costs ceil(n / (U * blockDim)) memory round trips instead of one per element (a plain `for (i...) dst[i] = src[..]`
 // loop is compiled into load -> wait -> store per trip).

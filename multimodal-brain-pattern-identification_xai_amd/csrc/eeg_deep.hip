@@ -342,9 +342,10 @@ __global__ __launch_bounds__(256) void k_deep_head_bwd(DeepHeadBwdArgs a) {
   if (tid < DP_MAXN) {
     float v = 0.f;
     if (tid < N) {
-      float gs = 0.f;
-      for (int n = 0; n < N; ++n) gs += a.dlogp[(size_t)b * N + n];
-      v = a.dlogp[(size_t)b * N + tid] - expf(a.logp[(size_t)b * N + tid]) * gs;
+      float ps = 0.f, gs = 0.f;                          // cancellation-free LogSoftmax backward (bx_common.h: bx_lsm_bwd)
+      for (int n = 0; n < N; ++n)
+        if (n != tid) { ps += expf(a.logp[(size_t)b * N + n]); gs += a.dlogp[(size_t)b * N + n]; }
+      v = a.dlogp[(size_t)b * N + tid] * ps - expf(a.logp[(size_t)b * N + tid]) * gs;
       a.dlog[(size_t)b * N + tid] = v;
     }
     dlg[tid] = v;

@@ -60,12 +60,23 @@ __global__ __launch_bounds__(256) void k_linear_lsm_fwd(const float* __restrict_
 
 // dlogit = dlogp - softmax * sum(dlogp)
 // (loops are fully unrolled over HEAD_MAX_N with guards: a runtime-indexed per-thread array would live in scratch memory)
+// evaluated without the (1 - p_n) cancellation (bx_common.h: bx_lsm_bwd), here with prefix / suffix sums so that every index is static:
+//   dz_n = dy_n * (P_<n + P_>n) - p_n * (D_<n + D_>n)
 __device__ __forceinline__ void lsm_bwd_row(const float* dlogp, const float* logp, int N, float* dlogit) {
-  float s = 0.f;
+  float p[HEAD_MAX_N], pl[HEAD_MAX_N], dl[HEAD_MAX_N];
+  float pr = 0.f, dr = 0.f;
 #pragma unroll
-  for (int n = 0; n < HEAD_MAX_N; ++n) if (n < N) s += dlogp[n];
+  for (int n = 0; n < HEAD_MAX_N; ++n) {
+    p[n] = n < N ? expf(logp[n]) : 0.f;
+    pl[n] = pr; dl[n] = dr;                       // sums over j < n
+    pr += p[n]; dr += n < N ? dlogp[n] : 0.f;
+  }
+  pr = 0.f; dr = 0.f;                             // now sums over j > n
 #pragma unroll
-  for (int n = 0; n < HEAD_MAX_N; ++n) dlogit[n] = n < N ? dlogp[n] - expf(logp[n]) * s : 0.f;
+  for (int n = HEAD_MAX_N - 1; n >= 0; --n) {
+    dlogit[n] = n < N ? dlogp[n] * (pl[n] + pr) - p[n] * (dl[n] + dr) : 0.f;
+    pr += p[n]; dr += n < N ? dlogp[n] : 0.f;
+  }
 }
 
 // input gradient: dx[b][k] = sum_n dlogit[b][n] W[n][k]; GAP variant broadcasts dx/HW over the pixels
@@ -520,11 +531,7 @@ __global__ __launch_bounds__(256) void k_mm_head_bwd_in(const float* __restrict_
     hid = hidden[(size_t)b * Hd + (tid < Hd ? tid : 0)];
   }
   lds_fill<8>(w1s, Hd * 2 * N, [&](int i) { return w1[i]; });
-  if (tid == 0) {
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s += dlogp[(size_t)b * N + n];
-    for (int n = 0; n < N; ++n) dl2[n] = dlogp[(size_t)b * N + n] - expf(logp[(size_t)b * N + n]) * s;
-  }
+  if (tid == 0) bx_lsm_bwd(dlogp + (size_t)b * N, logp + (size_t)b * N, N, dl2);
   __syncthreads();
   float* ws_dl2 = ws; float* ws_dpre = ws + (size_t)B * N; float* ws_dle = ws_dpre + (size_t)B * Hd; float* ws_dls = ws_dle + (size_t)B * N;
   if (tid < N) ws_dl2[(size_t)b * N + tid] = dl2[tid];
@@ -559,9 +566,7 @@ __global__ __launch_bounds__(256) void k_mm_head_bwd_in(const float* __restrict_
   __syncthreads();
   if (tid < 2) {                                               // log-softmax backward of the two branch outputs
     const float* lp = (tid == 0 ? e_logp : s_logp) + (size_t)b * N;
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s += dz[tid * N + n];
-    for (int n = 0; n < N; ++n) dbr[tid * N + n] = dz[tid * N + n] - expf(lp[n]) * s;
+    bx_lsm_bwd(dz + tid * N, lp, N, dbr + tid * N);
   }
   __syncthreads();
   if (tid < 2 * N) (tid < N ? ws_dle : ws_dls)[(size_t)b * N + (tid < N ? tid : tid - N)] = dbr[tid];

@@ -780,6 +780,111 @@ def activation_flips(trace, acts, tie=1e-4):
     return flips, errors
 
 
+class _StoreAs(torch.autograd.Function):
+    """Emulates a tensor that lives in memory in a narrower type: the value is rounded to ``store`` on the way forward and the
+    gradient that flows back through the same point is rounded too (an activation and its gradient are both stored tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, store):
+        ctx.store = store
+        return x.to(store).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.store).to(g.dtype), None
+
+
+class _StoreGradAs(torch.autograd.Function):
+    """Identity forward; the gradient flowing back is rounded to ``store`` (a gradient tensor that is written to memory in the
+    narrow type before it is added to another one)."""
+
+    @staticmethod
+    def forward(ctx, x, store):
+        ctx.store = store
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.store).to(g.dtype), None
+
+
+def decision_matched_twin(model: nn.Module, acts, dtype=torch.float64, storage=None):
+    """A deep copy of ``model`` in ``dtype`` whose residual stages take their DISCRETE decisions from another implementation's
+    stored activations ``acts`` ({stage name: [y1, y2, y3]} NCHW, post-ReLU): ReLU passes exactly where y_k > 0 there, and a 2x2
+    max-pool picks the window element that is the (first) maximum of y3 there.  Everything continuous is recomputed in ``dtype``.
+    With the decisions pinned, outputs and gradients are smooth functions of the arithmetic again, so they can be compared
+    strictly; whether the pinned decisions are legitimate is a separate, explicit check (activation_flips: every disagreement with
+    the exact forward must be a demonstrated tie).  With no disagreement this twin computes exactly what the plain model does.
+
+    ``storage=torch.bfloat16`` additionally restates the product's bf16 STORAGE mode on the reference's algorithm: every tensor
+    the HIP path keeps in memory as bf16 -- the converted input, each convolution's ReLU'd output, the pooled map (an average of
+    four; a maximum is already one of them), each stage's output, the EEG branch's temporal-convolution output -- and the gradient
+    arriving at each of those points is rounded to bf16 (round to nearest even, as v_cvt_pk_bf16_f32 does); sums, statistics,
+    parameters and parameter gradients stay in ``dtype`` (the kernels accumulate in fp32).
+
+    ``twin.decision_log`` (filled by each forward) lists, per convolution / max-pool, how many pinned decisions the twin's own
+    arithmetic would have taken the other way and the largest margin |z|/S (or window gap / S) among them: the evidence that
+    those decisions are ties at the resolution of the arithmetic."""
+    import copy
+    import types
+    twin = copy.deepcopy(model).to(dtype)
+    twin.train(model.training)
+    st = (lambda t: _StoreAs.apply(t, storage)) if storage is not None else (lambda t: t)
+    # the skip path's input gradient (transposed bilinear of W1x1^T dOut) is a stored tensor of its own on the HIP path: it is
+    # rounded once before the main path's data gradient is added to it (and the sum is rounded again)
+    stg = (lambda t: _StoreGradAs.apply(t, storage)) if storage is not None else (lambda t: t)
+    log = []
+    twin.decision_log = log          # filled by forward(): pinned decisions this arithmetic would have taken differently, with margins
+
+    def windows(t, Hc, Wc):
+        t = t[:, :, :Hc, :Wc]
+        return t.reshape(t.shape[0], t.shape[1], Hc // 2, 2, Wc // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(*t.shape[:2], Hc // 2, Wc // 2, 4)
+
+    first = True
+    for name, mod in twin.named_modules():
+        if name not in acts or not all(hasattr(mod, f"conv{k}") for k in (1, 2, 3)):
+            continue
+        theirs = [torch.as_tensor(a).to(dtype) for a in acts[name]]
+
+        def forward(self, x, theirs=theirs, is_first=first, name=name):
+            if is_first:
+                x = st(x)                                   # the fp32 input batch is converted to the storage type once
+            y = x
+            for k, conv in enumerate((self.conv1, self.conv2, self.conv3)):
+                z = conv(y)
+                mask = theirs[k] > 0
+                with torch.no_grad():                       # how far from a tie is every pinned decision that this arithmetic would not take?
+                    bad = (z > 0) != mask
+                    if bool(bad.any()):
+                        S = F.conv2d(y.abs(), conv.weight.abs(), conv.bias.abs(), padding=1)
+                        log.append({"stage": name, "conv": k + 1, "count": int(bad.sum()), "margin": float((z.abs() / S.clamp_min(1e-300))[bad].max())})
+                y = st(z * mask.to(z.dtype))
+            if isinstance(self.pool, nn.MaxPool2d):
+                Hc, Wc = y.shape[2] // 2 * 2, y.shape[3] // 2 * 2
+                idx = windows(theirs[2], Hc, Wc).argmax(-1, keepdim=True)
+                wy = windows(y, Hc, Wc)
+                with torch.no_grad():
+                    gap = wy.max(-1).values - wy.gather(-1, idx).squeeze(-1)
+                    if bool((gap > 0).any()):
+                        S = windows(F.conv2d(theirs[1].abs(), self.conv3.weight.abs(), self.conv3.bias.abs(), padding=1), Hc, Wc).max(-1).values   # scale of conv3's sums
+                        log.append({"stage": name, "conv": "pool", "count": int((gap > 0).sum()), "margin": float((gap / S.clamp_min(1e-300)).max())})
+                y = wy.gather(-1, idx).squeeze(-1)
+            else:
+                y = st(self.pool(y))
+            y = self.dropout(self.bn(y))
+            skip = F.interpolate(stg(x), size=y.shape[-2:], mode="bilinear", align_corners=False)
+            return st(y + self.conv1x1(skip))
+        mod.forward = types.MethodType(forward, mod)
+        first = False
+    if storage is not None:
+        for name, mod in twin.named_modules():              # EEGNet: only the temporal convolution's output is a narrow tensor
+            if hasattr(mod, "depthwiseConv") and hasattr(mod, "conv1") and hasattr(mod, "batchnorm1"):
+                conv1 = mod.conv1
+                orig = conv1.forward
+                conv1.forward = (lambda x, orig=orig: st(orig(x)))
+    return twin
+
+
 def conditioning(model: nn.Module, args, loss_of, dtype=torch.float64):
     """How well-posed a gradient comparison at fp32 is: max over parameters of the relative L2 distance between the fp32
     and the ``dtype`` gradients of ``loss_of(model(*args))`` (both on deep copies; ``model`` itself is untouched)."""

@@ -3,18 +3,23 @@ comparison metrics.
 
 Metrics
   rel_err(a, b)            max|a-b| / max|b|                        -- forward values (continuous in the inputs)
-  grad_close(a, b, tol..)  the same for gradients, STRICT by default.  ``floor`` floors the denominator so that a
+  grad_close(a, b, tol..)  the same for gradients, STRICT: no outliers are tolerated.  ``floor`` floors the denominator so that a
                            gradient that is mathematically zero (e.g. d/d gamma of a BatchNorm directly followed by a
                            linear map and another BatchNorm) is compared on the scale of its neighbours, not of its
                            own rounding noise.
-                           A gradient is a discontinuous function of the activations (ReLU'(0), max-pool arg-max), so
-                           one pre-activation that is +1e-7 on one implementation and -1e-7 on the other changes a
-                           patch of an input gradient by O(1).  Such an event is never ASSUMED here: the caller passes
-                           ``flips`` = the list of OBSERVED disagreements between the implementation's stored
-                           activations and the oracle's fp64 trace, each with its |z|/S margin (observed_flips()
-                           below, oracle.ref_torch.activation_flips).  Only with a non-empty list is the flip-tolerant
-                           branch taken: outliers must stay below ``max_outlier_frac`` of the elements and 1 % in
-                           relative L2 norm, and the flips are printed with the deviation.
+
+Discontinuities.  A gradient is a discontinuous function of the activations (ReLU'(0), max-pool arg-max): one pre-activation
+that is +1e-9 on one implementation and -1e-9 on the other changes a patch of an input gradient by O(1), and -- through a late
+stage with few positions -- every upstream weight gradient by O(1e-2).  At the benchmark size (100 M activations) a few dozen
+such ties exist in every forward.  Round 1 "tolerated" outliers on the ASSUMPTION that they were tie flips.  Now nothing is
+assumed:
+  * matched_oracle() compares the implementation's stored post-ReLU activations with the oracle's fp64 trace.  Every
+    disagreement must be a demonstrated tie (|z|/S < 1e-4, in practice 1e-7 .. 1e-10); anything larger fails the test there.
+  * the gradient TARGET is then the fp64 oracle run with those same decisions pinned (oracle.ref_torch.decision_matched_twin).
+    With the decisions equal on both sides the comparison is strict again (checked on the CPU: the reference's own fp32
+    gradients are 1.6e-2 from the plain fp64 ones when 3 ReLUs flip, and 1.7e-5 from the decision-matched ones).
+  * fixtures (recorded fp32 outputs of the reference) are generated on inputs where neither the reference nor the HIP path
+    flips (oracle/make_golden.py, tools/flip_scan.py), so they are compared strictly as well.
 """
 import os
 
@@ -39,7 +44,8 @@ def rel_err(a, b, floor=0.0):
     return float((a - b).abs().max() / max(float(b.abs().max()), floor, 1e-30))
 
 
-def grad_close(got, want, tol, label="", floor=0.0, flips=None, max_outlier_frac=0.03):
+def grad_close(got, want, tol, label="", floor=0.0, flips=None):
+    """Strict.  ``flips`` (observed activation flips of the forward under test, if the caller looked) only enriches the message."""
     a, b = _flat(got), _flat(want)
     assert a.shape == b.shape, f"{label}: {a.shape} vs {b.shape}"
     scale = max(float(b.abs().max()), floor, 1e-30)
@@ -47,17 +53,12 @@ def grad_close(got, want, tol, label="", floor=0.0, flips=None, max_outlier_frac
     err = float(d.max() / scale)
     frac = float((d > tol * scale).double().mean())
     REPORT.append((label, err, frac))
-    if err <= tol:
-        return err
-    where = int(d.argmax())
-    assert flips, (f"{label}: rel err {err:.3e} > {tol} at flat index {where} ({frac:.2%} of elements beyond the tolerance) "
-                   "and no activation flip was observed")
-    l2 = float(d.norm() / max(float(b.norm()), floor * a.numel() ** 0.5, 1e-30))
-    assert frac <= max_outlier_frac and l2 <= 1e-2 and err <= 0.2, (
-        f"{label}: rel err {err:.3e} > {tol}, outliers {frac:.2%} (limit {max_outlier_frac:.0%}), rel L2 {l2:.2e}; "
-        f"observed flips: {describe_flips(flips)}")
-    print(f"[parity] {label}: {frac:.3%} of elements beyond {tol:g} (max {err:.2e} at {where}, rel L2 {l2:.2e}) "
-          f"with OBSERVED activation flips: {describe_flips(flips)}")
+    if err > tol:
+        hint = ""
+        if flips:
+            hint = (f"; the forward under test flipped {len(flips)} activation decision(s) against the exact forward ({describe_flips(flips)}): "
+                    "compare with matched_oracle(), or re-pick this fixture's input seeds (tools/flip_scan.py)")
+        raise AssertionError(f"{label}: rel err {err:.3e} > {tol} at flat index {int(d.argmax())} ({frac:.2%} of elements beyond the tolerance){hint}")
     return err
 
 
@@ -66,20 +67,44 @@ def describe_flips(flips, limit=4):
     return "; ".join(items) + (f"; ... {len(flips)} in all" if len(flips) > limit else "")
 
 
-def observed_flips(oracle_mod, ref, args, keep, label=""):
-    """Demonstrated activation flips of a GPU forward.  ``ref``: the oracle model in the state the forward saw (call this
-    before stepping it); ``args``: the CPU inputs; ``keep``: what brainxai.ops.keep_block_activations(model) returned before
-    that forward.  A disagreement whose oracle margin is NOT tiny is an error, not a flip, and fails here."""
-    trace = oracle_mod.relu_pool_trace(ref, args)
+def _nchw_acts(keep, trace):
     acts = {}
     for name, d in keep.items():
         if "acts" in d and name in trace:
             acts[name] = [t.detach().float().permute(0, 3, 1, 2)[:, :trace[name]["z"][k].shape[1]].cpu() for k, t in enumerate(d["acts"])]
+    return acts
+
+
+def observed_flips(oracle_mod, ref, args, keep, label=""):
+    """Demonstrated activation flips of a GPU forward.  ``ref``: the oracle model in the state the forward saw (call this
+    before stepping it); ``args``: the CPU inputs; ``keep``: what brainxai.ops.keep_block_activations(model) returned before
+    that forward.  A disagreement whose oracle margin is NOT tiny is an error, not a flip, and fails here."""
+    return matched_oracle(oracle_mod, ref, args, keep, label, twin=False)[1]
+
+
+def matched_oracle(oracle_mod, ref, args, keep, label="", twin=True, storage=None):
+    """(fp64 oracle with the GPU forward's ReLU / max-pool decisions pinned, list of observed flips).  See the module docstring.
+    ``storage=torch.bfloat16``: the twin restates the product's bf16 storage mode (oracle.ref_torch.decision_matched_twin); the
+    legitimacy of the pinned decisions is then read from the twin's own decision log (check_decisions) after its forward."""
+    trace = oracle_mod.relu_pool_trace(ref, args)
+    acts = _nchw_acts(keep, trace)
+    if storage is not None:
+        return oracle_mod.decision_matched_twin(ref, acts, storage=storage), None
     flips, errors = oracle_mod.activation_flips(trace, acts)
     assert not errors, f"{label}: activations disagree with the fp64 oracle beyond a tie: {describe_flips(errors)}"
     if flips:
-        print(f"[parity] {label}: observed {len(flips)} activation flip(s): {describe_flips(flips)}")
-    return flips
+        print(f"[parity] {label}: {len(flips)} activation decision(s) differ from the exact forward, all demonstrated ties: {describe_flips(flips)}")
+    return (oracle_mod.decision_matched_twin(ref, acts) if twin else None), flips
+
+
+def check_decisions(twin, tie, label=""):
+    """After a forward of a decision-matched twin: every pinned decision its own arithmetic would have taken the other way must be
+    within ``tie`` of a tie (|z|/S for a ReLU, window gap / S for a max-pool).  Returns (count, largest margin)."""
+    n = sum(e["count"] for e in twin.decision_log)
+    worst = max((e["margin"] for e in twin.decision_log), default=0.0)
+    bad = [e for e in twin.decision_log if e["margin"] >= tie]
+    assert not bad, f"{label}: pinned decisions that are NOT ties at resolution {tie:g}: {bad[:4]}"
+    return n, worst
 
 
 def summarize(t):
@@ -105,7 +130,7 @@ def check(fix, key, value, tol=1e-5, what="", floor=0.0, robust=False, digest=Tr
     head = torch.as_tensor(fix[key + "#head"])
     got_head = value.flatten()[: head.numel()]
     if robust:
-        err = grad_close(got_head, head, tol, label=what + key + "#head", floor=floor, flips=flips, max_outlier_frac=0.10)
+        err = grad_close(got_head, head, tol, label=what + key + "#head", floor=floor, flips=flips)
     else:
         err = rel_err(got_head, head, floor)
         assert err <= tol, f"{what}{key}#head: rel err {err:.3e} > {tol}"
@@ -115,7 +140,7 @@ def check(fix, key, value, tol=1e-5, what="", floor=0.0, robust=False, digest=Tr
     # abs-sum and square-sum are well conditioned; the signed sums are checked against the abs-sum scale
     scale = np.array([want[1], want[1], want[1], want[3]]) + 1e-30
     derr = float(np.max(np.abs(got - want) / scale))
-    dtol = max(tol, 2e-2) if (robust and flips) else tol      # an observed flip moves the digest of a gradient by O(1e-3)
+    dtol = tol
     assert derr <= dtol, f"{what}{key}#sum: digest err {derr:.3e} > {dtol}"
     REPORT.append((what + key + "#sum", derr, 0.0))
     return max(err, derr)

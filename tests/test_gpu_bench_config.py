@@ -20,7 +20,7 @@ import torch.nn.functional as F
 import brainxai
 from brainxai import ops
 from oracle import ref_torch as O
-from tests.golden_util import grad_close, observed_flips, rel_err
+from tests.golden_util import check_decisions, grad_close, matched_oracle, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
@@ -56,11 +56,11 @@ def _gscale(model):
 
 def test_bench_config_fp32_train_step_and_gradcam():
     """configs[1] shapes, fp32 storage, train mode.  Logits and loss within 1e-3 of the fp32 oracle (north_star).  Parameter
-    gradients: at this size the reference's OWN fp32 gradients sit up to 1.4e-3 from their exact values (each entry of a
-    block1 weight gradient is an fp32 sum of 2 million products; oracle fp32 vs the same oracle in fp64, printed below), so
-    the target for the gradients is the fp64 oracle: every tensor within 1e-3 of it -- unless a ReLU / max-pool decision
-    flipped, which is then OBSERVED (tests/golden_util.observed_flips) and reported, never assumed.  Then eval mode: block5
-    Grad-CAM maps of all 6 classes (configs[3]'s map) within 1e-3 of the raw-map scale."""
+    gradients: at this size every forward contains a few dozen ReLU pre-activations within 1e-8 of zero, and the reference's OWN
+    fp32 gradients sit 1.4e-3 from their exact (fp64) values (printed below).  The gradient target is therefore the fp64 oracle
+    with the HIP forward's decisions pinned (tests/golden_util.matched_oracle: every decision that differs from the exact forward
+    must be a demonstrated tie) -- and against that target the comparison is strict, every tensor within 1e-3.  Then eval mode:
+    block5 Grad-CAM maps of all 6 classes (configs[3]'s map) within 1e-3 of the raw-map scale."""
     ref, mine = _models(5, torch.float32)
     eeg, spec, labels = _bench_inputs()
     ref.train(); mine.train()
@@ -78,16 +78,17 @@ def test_bench_config_fp32_train_step_and_gradcam():
         e_out = rel_err(out.detach().cpu(), out_r.detach())
         assert e_out < TOL
         assert abs(float(loss.detach()) - float(loss_r.detach())) <= TOL * abs(float(loss_r.detach()))
-        flips = observed_flips(O, ref, (eeg, spec), keep, "bench config fp32")
+        twin, flips = matched_oracle(O, ref, (eeg, spec), keep, "bench config fp32")
         ops.keep_block_activations(mine, on=False)
         del keep
-        fl = 1e-2 * max(float(p.grad.abs().max()) for p in ref64.parameters())
+        O.kl_div(twin(eeg.double(), spec.double()), labels.double()).backward()
+        fl = 1e-2 * max(float(p.grad.abs().max()) for p in twin.parameters())
         worst, worst_ref = 0.0, 0.0
-        for (n, p), (_, q32), (_, q) in zip(mine.named_parameters(), ref.named_parameters(), ref64.named_parameters()):
-            worst = max(worst, grad_close(p.grad.cpu(), q.grad, TOL, label=f"bench fp32 d{n} (vs fp64 oracle)", floor=fl, flips=flips))
-            worst_ref = max(worst_ref, rel_err(q32.grad, q.grad, floor=fl))
-        print(f"[parity] bench config fp32: logits {e_out:.2e}; parameter gradients vs the fp64 oracle: HIP path {worst:.2e}, "
-              f"the fp32 oracle itself {worst_ref:.2e}; {len(flips)} observed activation flips")
+        for (n, p), (_, q32), (_, q64), (_, q) in zip(mine.named_parameters(), ref.named_parameters(), ref64.named_parameters(), twin.named_parameters()):
+            worst = max(worst, grad_close(p.grad.cpu(), q.grad, TOL, label=f"bench fp32 d{n} (vs decision-matched fp64 oracle)", floor=fl))
+            worst_ref = max(worst_ref, rel_err(q32.grad, q64.grad, floor=fl))
+        print(f"[parity] bench config fp32: logits {e_out:.2e}; parameter gradients: HIP path vs the decision-matched fp64 oracle {worst:.2e} "
+              f"({len(flips)} demonstrated tie flips pinned); for scale, the fp32 oracle vs its own fp64 run: {worst_ref:.2e}")
         for (n, t), (_, t2) in zip(mine.named_buffers(), ref.named_buffers()):
             assert rel_err(t.float().cpu(), t2.float()) < TOL, n         # BatchNorm running statistics after the step
     finally:
@@ -103,19 +104,29 @@ def test_bench_config_fp32_train_step_and_gradcam():
 
 
 def test_bench_config_bf16_train_step():
-    """configs[1] exactly as bench.py runs it (bf16 storage, MFMA kernels, B=64, train mode), against the fp32 oracle on
-    bf16-exact inputs and convolution weights.
+    """configs[1] exactly as bench.py runs it (bf16 storage, MFMA kernels, B=64, train mode; inputs and convolution weights
+    bf16-exact on both sides so that operand conversion is not part of the comparison).
 
-    Derived bounds.  Every stored activation / activation gradient is rounded to bf16 once: relative error u uniform in
-    +-2^-9, rms 2^-9/sqrt(3) = 1.1e-3, independent across elements.  An output of the network depends on L = 15 such roundings
-    in sequence (plus the EEG branch's 1): its relative error is ~sqrt(L) * 1.1e-3 = 4.4e-3 rms when the perturbations add
-    in quadrature -> logits within 2e-2 of their scale (4.5 sigma), loss (a mean over 64 x 6 terms) within 1e-2.  A weight
-    gradient is a sum over N >= 64*4*8 = 2048 positions of products x * dz, each factor carrying such an error: the
-    independent parts average down by sqrt(N), what remains is the common-mode error of dz coming down the backward chain,
-    again ~sqrt(2L) * 1.1e-3 = 6e-3 relative per element, partly correlated across the tensor.  For a direction cosine the
-    common-mode part cancels: cos >= 1 - (6e-3)^2 / 2 ~ 0.99998; the observed floor is set by ReLU / max-pool decisions that
-    bf16 rounding moves (a fraction ~1e-3 of positions), which perturb each entry by ~3e-2 of its value incoherently ->
-    cos ~ 1 - 5e-4.  Bound used: cos >= 0.99 for every tensor with >= 1024 entries, relative L2 error <= 0.1."""
+    What bf16 storage does to THIS workload is not a kernel property, and it is measured here instead of being waved at.  The
+    3x3-convolution gradients of a randomly initialised network on noise inputs are small residuals: each stage ends in a
+    train-mode BatchNorm, which projects the per-channel mean and the component along x-hat out of the gradient that flows back
+    into the convolutions, and what is left is a sum of 10^4..10^6 incoherent terms.  Rounding every stored activation to 8
+    significant bits moves ~1 % of the ReLU decisions of the next layer, and through 15 layers that changes those residual sums
+    by 20-50 % of their norm (direction cosine 0.88-0.98) -- on ANY implementation: the oracle's own algorithm with its stored
+    tensors rounded to bf16 (oracle.ref_torch.decision_matched_twin(storage=bfloat16), CPU, fp64 arithmetic) sits exactly there
+    against the fp32 oracle, while the 1x1 skip convolutions, BatchNorm affines and heads, whose gradients are coherent sums,
+    agree to 2e-3..6e-2.  Both numbers are printed below.  A cosine >= 0.99 against the fp32 oracle is therefore not a property
+    any bf16-storage implementation can have here; the strict statement that CAN be made, and is asserted, is:
+
+      * against the bf16-STORAGE restatement of the oracle with the HIP forward's decisions pinned, every gradient tensor of
+        >= 1024 entries has cosine >= 0.998 and a relative L2 error below ONE TENTH of that restatement's own distance from the
+        fp32 oracle, and every pinned decision the restatement would have taken differently is a tie at bf16 resolution
+        (margin < 2^-8).  Where the tenth comes from: the two sides accumulate the same bf16 operands in different orders (fp32
+        MFMA tiles vs fp64), so a sum lands on the other side of a bf16 rounding boundary with probability
+        p ~ (3e-7 S/|y|) / 2^-8 ~ 1.5e-4 per stored element, a full ulp (3.5x the rms rounding error) each: relative noise power
+        p * 3.5^2 = 1.8e-3 of what rounding EVERY element injects, i.e. 4 % of its amplitude -- measured 3.7e-2 / 0.51 = 7 %;
+      * against the fp32 oracle: logits within 2e-2 of their scale and the loss within 1e-2 (both are coherent quantities: 15
+        roundings of rms 2^-9/sqrt(3) in sequence give 4.4e-3)."""
     ref, mine = _models(5, torch.bfloat16, bf16_exact=True)
     eeg, spec, labels = _bench_inputs(bf16_exact=True)
     ref.train(); mine.train()
@@ -123,25 +134,43 @@ def test_bench_config_bf16_train_step():
     loss_r = O.kl_div(out_r, labels)
     loss_r.backward()
     try:
+        keep = ops.keep_block_activations(mine)
         out = mine(eeg.to(DEV), spec.to(DEV))
         loss = brainxai.KLDivLoss()(out, labels.to(DEV))
         loss.backward()
         torch.cuda.synchronize()
         e_out = rel_err(out.detach().cpu(), out_r.detach())
-        e_loss = abs(float(loss) - float(loss_r)) / abs(float(loss_r))
+        e_loss = abs(float(loss.detach()) - float(loss_r.detach())) / abs(float(loss_r.detach()))
         assert e_out < 2e-2, e_out
         assert e_loss < 1e-2, e_loss
-        worst_cos, worst_l2 = 1.0, 0.0
-        for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        twin, _ = matched_oracle(O, ref, (eeg, spec), keep, "bench config bf16", storage=torch.bfloat16)
+        ops.keep_block_activations(mine, on=False)
+        del keep
+        out_t = twin(eeg.double(), spec.double())
+        n_dec, margin = check_decisions(twin, 2.0 ** -8, "bench config bf16")
+        O.kl_div(out_t, labels.double()).backward()
+        e_out_t = rel_err(out.detach().cpu(), out_t.detach())
+        worst_cos, worst_l2, base_cos, base_l2, worst_n = 1.0, 0.0, 1.0, 0.0, ""
+        table = []
+        for (n, p), (_, q32), (_, q) in zip(mine.named_parameters(), ref.named_parameters(), twin.named_parameters()):
             if q.numel() < 1024:
                 continue
-            a, b = p.grad.flatten().cpu().double(), q.grad.flatten().double()
-            cos = float(F.cosine_similarity(a, b, dim=0))
-            l2 = float((a - b).norm() / b.norm())
+            a, b, c = p.grad.flatten().cpu().double(), q.grad.flatten().double(), q32.grad.flatten().double()
+            cos, l2 = float(F.cosine_similarity(a, b, dim=0)), float((a - b).norm() / b.norm())
+            table.append((l2, cos, n))
+            if l2 > worst_l2:
+                worst_n = n
             worst_cos, worst_l2 = min(worst_cos, cos), max(worst_l2, l2)
-            assert cos >= 0.99 and l2 <= 0.1, (n, cos, l2)
-        print(f"[parity] bench config bf16: logits {e_out:.2e}, loss {e_loss:.2e}, worst gradient cosine {worst_cos:.5f}, worst rel L2 {worst_l2:.2e}")
+            base_cos, base_l2 = min(base_cos, float(F.cosine_similarity(b, c, dim=0))), max(base_l2, float((b - c).norm() / c.norm()))
+        print(f"[parity] bench config bf16: vs fp32 oracle: logits {e_out:.2e}, loss {e_loss:.2e}.  vs the bf16-storage restatement of the oracle "
+              f"(decisions pinned; {n_dec} of them ties, largest margin {margin:.1e}): logits {e_out_t:.2e}, worst gradient cosine {worst_cos:.5f}, "
+              f"worst rel L2 {worst_l2:.2e} ({worst_n}).  For scale, that restatement vs the fp32 oracle: worst cosine {base_cos:.3f}, worst rel L2 {base_l2:.2f}")
+        for l2, cos, n in sorted(table, reverse=True)[:12]:
+            print(f"[parity]    {n:48s} rel L2 {l2:.2e}  cosine {cos:.5f}")
+        assert e_out_t < 5e-3, e_out_t
+        assert worst_cos >= 0.998 and worst_l2 <= 0.1 * base_l2, (worst_n, worst_cos, worst_l2, base_l2)
     finally:
+        ops.keep_block_activations(mine, on=False)
         ops.clear_grad_views()
 
 
@@ -189,11 +218,17 @@ def test_config0_spectrogram_model_alone():
     ref0 = copy.deepcopy(ref)
     out_r = ref(spec); loss_r = O.kl_div(out_r, labels, "batchmean"); loss_r.backward()
     try:
+        keep = ops.keep_block_activations(mine)
         out = mine(spec.to(DEV)); loss = brainxai.KLDivLoss("batchmean")(out, labels.to(DEV)); loss.backward()
         torch.cuda.synchronize()
-        assert rel_err(out.detach().cpu(), out_r.detach()) < TOL and abs(float(loss) - float(loss_r)) <= TOL * abs(float(loss_r))
-        fl = _gscale(ref)
-        for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert rel_err(out.detach().cpu(), out_r.detach()) < TOL and abs(float(loss.detach()) - float(loss_r.detach())) <= TOL * abs(float(loss_r.detach()))
+        # gradients against the fp64 oracle with the HIP forward's decisions pinned (the reference's own fp32 gradients are
+        # 3e-3 from their fp64 values on this batch: 15 of its ReLU decisions flip -- oracle.ref_torch.conditioning)
+        twin, flips = matched_oracle(O, ref0, (spec,), keep, "config0")
+        ops.keep_block_activations(mine, on=False)
+        O.kl_div(twin(spec.double()), labels.double(), "batchmean").backward()
+        fl = _gscale(twin)
+        for (n, p), (_, q) in zip(mine.named_parameters(), twin.named_parameters()):
             grad_close(p.grad.cpu(), q.grad, TOL, label=f"config0 d{n}", floor=fl)
         # the debug epoch from the same initial weights
         ref = ref0
@@ -214,4 +249,5 @@ def test_config0_spectrogram_model_alone():
         torch.cuda.synchronize()
         assert int(mine.block3.bn.num_batches_tracked) == int(ref.block3.bn.num_batches_tracked) == 2
     finally:
+        ops.keep_block_activations(mine, on=False)
         ops.clear_grad_views()
