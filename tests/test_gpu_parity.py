@@ -378,10 +378,14 @@ def test_multimodal_train3(tag, opt):
         assert abs(losses[0] - float(fix["train.losses"][0])) <= TOL * abs(float(fix["train.losses"][0]))
         np.testing.assert_allclose(np.array(losses), fix["train.losses"], rtol=3e-2)
         for (n, t), (_, t2) in zip(mine.state_dict().items(), ref.state_dict().items()):
-            # 3 steps x (<= 1.05 lr per step per side) x 2 sides = 6.3e-3: the hard bound for weights that walk in opposite directions
-            assert float((t.detach().float().cpu() - t2.float()).abs().max()) <= 6.5e-3 * max(1.0, float(t2.float().abs().max())), n
+            # parameters: 3 steps x (<= 1.05 lr per step per side) x 2 sides = 6.3e-3, the hard bound for weights that walk in
+            # opposite directions.  BatchNorm running statistics follow the activations of those drifting weights (block5 averages
+            # over 8 values per channel here): held to 3e-2 of their scale, like the losses.
+            pnames = {k for k, _ in ref.named_parameters()}
+            bound = (lambda ref_t: 6.5e-3 * max(1.0, float(ref_t.abs().max()))) if n in pnames else (lambda ref_t: 3e-2 * max(1.0, float(ref_t.abs().max())))
+            assert float((t.detach().float().cpu() - t2.float()).abs().max()) <= bound(t2.float()), n
             want = torch.from_numpy(fix["after3.shead." + n]).float()
-            assert float((t.detach().float().flatten()[:32].cpu() - want).abs().max()) <= 6.5e-3 * max(1.0, float(want.abs().max())), n
+            assert float((t.detach().float().flatten()[:32].cpu() - want).abs().max()) <= bound(want), n
         # (b) the optimizer arithmetic itself, strictly: three more steps, each started from the ORACLE's state (weights, buffers,
         # AdamW moments and step count copied over), so that both sides take the same step from the same point.  Entries whose
         # gradient is above 1e-3 of their tensor's (and 1e-5 of the model's) largest are well-posed: a 1e-3 relative gradient
