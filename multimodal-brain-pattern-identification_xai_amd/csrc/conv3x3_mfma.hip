@@ -915,6 +915,215 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const bf16_t* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_wgrad_own (round 2): the 32 x 32 (cin, cout) slice with its four waves OWNING output tiles instead of splitting K.
+//   Round 1's kernel above gives every wave a full copy of the 36 accumulator tiles (144 registers, 2 workgroups per CU) and
+//   splits each staged pixel tile's K-steps over the waves; the copies are then summed through LDS (three exchange rounds).
+//   With 4 pixel tiles per workgroup the launch was neither MFMA- nor bandwidth-bound: every shape took 22-35 us (hbm bound
+//   2-21 us, MFMA bound 2-4 us, tools/conv_bench.py) -- a workgroup's life was one exposed global-load latency per tile plus that
+//   epilogue, with two tiles in flight per CU.
+//   Here wave (m, n) owns the (16 cin) x (16 cout) quadrant for all 9 taps (9 accumulator tiles, 36 registers) and every wave
+//   walks every K-step of the staged tile: no cross-wave sum at all (the partial is stored straight from the accumulators), and
+//   at ~100 registers four workgroups fit a CU, i.e. twice the tiles in flight.  The price is LDS operand traffic (10 fragment
+//   reads per 9 MFMAs instead of 22 per 36), which is why the tiles are SWIZZLED here: a transposing read takes its 32-lane
+//   group's rows from pixels {x..x+3, x+8..x+11}, whose 64-byte records alias in the 64 banks; swapping the two 32-byte halves of
+//   the records of pixels with bit 3 of x set makes every read conflict-free (brute-forced over both lane groups, all taps, both
+//   tile widths).  Round 1 measured 86 % of the LDS-active cycles as bank-conflict cycles in the kernel above and had no
+//   registers left for swizzled addresses.
+//   Workgroup -> work mapping: 1-D grid; consecutive ids are dealt to the 8 XCDs round-robin, so id & 7 picks the pixel range and
+//   id >> 3 walks the (cin, cout) slices of that range: all slices that re-read one range's X / dZ tiles sit on ONE XCD at the
+//   same time and share them through its L2 (before: every slice pair fetched them from HBM again; a performance assumption
+//   only, any placement is correct).
+#ifdef BX_WGRAD_STAMPS
+// Diagnostic build only (hipcc -DBX_WGRAD_STAMPS, tools/wgrad_stamps.py): shader-clock stamps of one workgroup in 16 go to a
+// buffer of their own that nothing else reads.  Slot layout per workgroup: [start, first tile staged, end of tile 0..3, stored].
+__device__ unsigned long long bx_wgrad_stamps[64 * 8];
+extern "C" int bx_debug_wgrad_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(bx_wgrad_stamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -1;
+}
+#define BX_STAMP(i) do { if (stamp_wg >= 0 && threadIdx.x == 0) bx_wgrad_stamps[stamp_wg * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BX_STAMP(i) do { } while (0)
+#endif
+template <int TW, int OCC, int DEPTH>
+__global__ __launch_bounds__(256, OCC) void k_wgrad_own(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dz, float* __restrict__ partial,
+    int H, int W, int Ci_p, int Co, int tiles_x, int tiles_y, int ntiles, int tiles_per_split, int nsplit, int ytiles, int ztiles,
+    WgradRedJob prev, int nred) {
+  constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CIT = 32, COT = 32, XB = 64, ZB = 64;
+  constexpr int KSTEPS = TH * TW / 32, ROWS_PER_STEP = 32 / TW;   // TW = 32: one tile row per K-step; TW = 16: two
+  constexpr int XS_BYTES = HH * HWID * XB;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  if ((int)blockIdx.x < nred) {                                  // chained mode: sum the PREVIOUS layer's partials
+    if ((int)blockIdx.x < prev.nblocks) wgrad_reduce3_body(prev, (int)blockIdx.x, reinterpret_cast<float4*>(lds));
+    return;
+  }
+  const int L = (int)blockIdx.x - nred, YZ = ytiles * ztiles;     // nred is a multiple of 8: L & 7 == blockIdx.x & 7
+  const int slot = L >> 3, yz = slot % YZ, split = (slot / YZ) * 8 + (L & 7);
+  if (split >= nsplit) return;
+  const int by = yz / ztiles, bz = yz - by * ztiles;
+#ifdef BX_WGRAD_STAMPS
+  const int stamp_wg = (L % 16 == 5 && L / 16 < 64) ? L / 16 : -1;
+#endif
+  BX_STAMP(0);
+  char* xs = lds;
+  char* zs = lds + XS_BYTES;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+  const int q = li >> 2, pc = li & 3;
+  const int m = wave >> 1, n = wave & 1;
+  const int ci0 = by * CIT, co0 = bz * COT;
+  const bool want_bias = by == 0 && m == 0;
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  const int t_begin = split * tiles_per_split;
+  const int t_end = t_begin + tiles_per_split < ntiles ? t_begin + tiles_per_split : ntiles;
+  constexpr int NXU = HH * HWID * (CIT / 8), NZU = TH * TW * (COT / 8);
+  constexpr int NX = (NXU + 255) / 256, NZ = (NZU + 255) / 256;
+  uint4 rxa[NX], rza[NZ], rxb[NX], rzb[NZ];        // two tiles in flight (OCC = 3 leaves the registers): fetch distance 2
+  const int nimg = ntiles / (tiles_x * tiles_y);
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (uint32_t)((size_t)nimg * H * W * Ci_p * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t zres = __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, (uint32_t)((size_t)nimg * H * W * Co * 2), 0x00020000);
+  int xpp[NX], zpp[NZ];                                          // (row << 16) | (column & 0xffff) of the unit inside the tile
+  uint32_t xrel[NX], zrel[NZ];
+#pragma unroll
+  for (int k = 0; k < NX; ++k) {
+    const int u = threadIdx.x + k * 256;
+    const int p = u / (CIT / 8), c = u % (CIT / 8);
+    const bool live = u < NXU && ci0 + c * 8 < Ci_p;
+    const int px = p % HWID;
+    xpp[k] = ((live ? p / HWID - 1 : -20000) << 16) | ((px - 1) & 0xffff);
+    xrel[k] = (uint32_t)((((p / HWID - 1) * W + (px - 1)) * Ci_p + ci0 + c * 8) * 2);
+  }
+#pragma unroll
+  for (int k = 0; k < NZ; ++k) {
+    const int u = threadIdx.x + k * 256;
+    const int p = u / (COT / 8), c = u % (COT / 8);
+    const int px = p % TW;
+    zpp[k] = ((u < NZU ? p / TW : 20000) << 16) | px;
+    zrel[k] = (uint32_t)((((p / TW) * W + px) * Co + co0 + c * 8) * 2);
+  }
+  auto fetch = [&](int tile, uint4 (&rx)[NX], uint4 (&rz)[NZ]) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    const uint32_t pix0 = (uint32_t)((b * H + y0) * W + x0);
+    const uint32_t xb = pix0 * (uint32_t)(Ci_p * 2), zb = pix0 * (uint32_t)(Co * 2);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const bool ok = (unsigned)(y0 + (xpp[k] >> 16)) < (unsigned)H && (unsigned)(x0 + (int)(short)(xpp[k] & 0xffff)) < (unsigned)W;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? xb + xrel[k] : 0x80000000u, 0, 0);
+      rx[k] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) {
+      const bool ok = (unsigned)(y0 + (zpp[k] >> 16)) < (unsigned)H && (unsigned)(x0 + (zpp[k] & 0xffff)) < (unsigned)W;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(zres, ok ? zb + zrel[k] : 0x80000000u, 0, 0);
+      rz[k] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  };
+  // per-lane read addresses: pixel kp = 8g + 4h + q of a K-step (h = the two 4-row halves of a transposing read pair)
+  int xbase[2][3], zbase[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int kp = 8 * g + 4 * h + q;
+    const int r = TW == 32 ? 0 : (kp >> 4), c = TW == 32 ? kp : (kp & 15);
+    zbase[h] = (r * TW + c) * ZB + (((n ^ (c >> 3)) & 1) << 5) + pc * 8;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) xbase[h][dx] = (r * HWID + c + dx) * XB + (((m ^ ((c + dx) >> 3)) & 1) << 5) + pc * 8;
+  }
+  auto stage = [&](const uint4 (&rx)[NX], const uint4 (&rz)[NZ]) {
+    // LDS destinations are recomputed per tile (a handful of integer ops; keeping them would cost 10 registers):
+    // record p, 16-byte unit c; the two 32-byte halves of a record are swapped where bit 3 of its x position is set (swizzle)
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int u = threadIdx.x + k * 256, p = u >> 2, c = u & 3, px = p % HWID;
+      if (u < NXU) *reinterpret_cast<uint4*>(xs + p * XB + ((((c >> 1) ^ (px >> 3)) & 1) << 5) + (c & 1) * 16) = rx[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) {
+      const int u = threadIdx.x + k * 256, p = u >> 2, c = u & 3, px = p % TW;
+      if (u < NZU) *reinterpret_cast<uint4*>(zs + p * ZB + ((((c >> 1) ^ (px >> 3)) & 1) << 5) + (c & 1) * 16) = rz[k];
+    }
+  };
+  // The K-steps of a staged tile with the operand fragments of step k+1 requested BEFORE the nine MFMAs of step k.  Written
+  // as plain "read, then use" the compiler waits for each fragment right before its MFMA: the in-kernel stamps (tools/
+  // wgrad_stamps.py) showed 560 cycles per K-step for 144 cycles of MFMA -- nine exposed LDS latencies.
+  auto load_frags = [&](int ks, bf16x8 (&a)[9], bf16x8& b) {
+    const int r0 = ks * ROWS_PER_STEP;
+    b = tr_read8(zs, zbase[0] + r0 * TW * ZB, zbase[1] + r0 * TW * ZB);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      a[tap] = tr_read8(xs, xbase[0][dx] + (r0 + dy) * HWID * XB, xbase[1][dx] + (r0 + dy) * HWID * XB);
+    }
+  };
+  auto mma = [&](const bf16x8 (&a)[9], const bf16x8& b) {
+    if (want_bias) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsum += __uint_as_float(((uint32_t)(unsigned short)b[j]) << 16);
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tap], b, acc[tap], 0, 0, 0);
+  };
+  auto compute = [&]() {
+    bf16x8 a0[9], a1[9], b0, b1;
+    load_frags(0, a0, b0);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks += 2) {
+      if (ks + 1 < KSTEPS) load_frags(ks + 1, a1, b1);
+      mma(a0, b0);
+      if (ks + 2 < KSTEPS) load_frags(ks + 2, a0, b0);
+      if (ks + 1 < KSTEPS) mma(a1, b1);
+    }
+  };
+  if (DEPTH == 2) {                                              // two tiles in flight (needs the 256-register budget of OCC = 2)
+    if (t_begin < t_end) fetch(t_begin, rxa, rza);
+    if (t_begin + 1 < t_end) fetch(t_begin + 1, rxb, rzb);
+    for (int tile = t_begin; tile < t_end; tile += 2) {
+      __syncthreads();
+      stage(rxa, rza);
+      __syncthreads();
+      if (tile + 2 < t_end) fetch(tile + 2, rxa, rza);
+      compute();
+      if (tile + 1 < t_end) {
+        __syncthreads();
+        stage(rxb, rzb);
+        __syncthreads();
+        if (tile + 3 < t_end) fetch(tile + 3, rxb, rzb);
+        compute();
+      }
+    }
+  } else {
+    if (t_begin < t_end) fetch(t_begin, rxa, rza);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      __syncthreads();
+      stage(rxa, rza);
+      __syncthreads();
+      if (tile == t_begin) BX_STAMP(1);
+      if (tile + 1 < t_end) fetch(tile + 1, rxa, rza);
+      compute();
+      if (tile - t_begin < 4) BX_STAMP(2 + tile - t_begin);
+    }
+  }
+  // ---- the partial: fragment order [tile = tap*4 + m*2 + n][lane][reg], exactly what k_wgrad_mfma writes (same reduce kernel)
+  constexpr int NT = 36;
+  const size_t nfrag = (size_t)ytiles * ztiles * NT * 256;
+  const size_t per_split = nfrag + Co;
+  float* out = partial + (size_t)split * per_split;
+  float4* out4 = reinterpret_cast<float4*>(out) + ((size_t)by * ztiles + bz) * NT * 64;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) out4[(tap * 4 + m * 2 + n) * 64 + lane] = make_float4(acc[tap][0], acc[tap][1], acc[tap][2], acc[tap][3]);
+  if (want_bias) {                                               // wave (0, n) saw every pixel of the range: its 16 couts' sums are complete
+    float v = bsum;
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lane < 16) out[nfrag + co0 + n * 16 + lane] = v;
+  }
+  BX_STAMP(6);
+}
+
 struct WgradPlan { int ma, nb, tw, tiles_x, tiles_y, ntiles, ytiles, ztiles, nsplit, tps; size_t lds; };
 static WgradPlan wgrad_plan(int B, int H, int W, int Ci_p, int Co) {
   WgradPlan p;
@@ -993,12 +1202,28 @@ int bx_wgrad_mfma_launch(const void* x, const void* dz, float* dw, float* db, in
     prev = wgrad_job_from(pending, true);
     zextra = (prev.nblocks + p.nsplit * p.ytiles - 1) / (p.nsplit * p.ytiles);
   }
+  static const bool own = !(getenv("BX_WGRAD_OWN") && atoi(getenv("BX_WGRAD_OWN")) == 0);
+  if (own && p.ma == 2 && p.nb == 2) {
+    // tile-owner kernel (k_wgrad_own): 1-D grid = [reduce-role workgroups, padded to a multiple of 8][8 XCD lanes x slots]
+    const int nred = pending && pending->valid ? (prev.nblocks + 7) / 8 * 8 : 0;
+    const int ranges8 = (p.nsplit + 7) / 8;                           // pixel ranges per XCD lane
+    const int nwg = nred + ranges8 * 8 * p.ytiles * p.ztiles;
+    const size_t lds = (size_t)10 * (p.tw + 2) * 64 + (size_t)8 * p.tw * 64;
+    // two workgroups per CU (256-register budget: 36 accumulators + two fragment sets of 40 + 40 staging registers); BX_WGRAD_DEPTH=2
+    // keeps two tiles in flight instead of one
+    static const int depth = getenv("BX_WGRAD_DEPTH") ? atoi(getenv("BX_WGRAD_DEPTH")) : 1;
+#define BX_OWN(TW_, D_) hipLaunchKernelGGL((k_wgrad_own<TW_, 2, D_>), dim3(nwg), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)dz, part, H, W, \
+                                           Ci_p, Co, p.tiles_x, p.tiles_y, p.ntiles, p.tps, p.nsplit, p.ytiles, p.ztiles, prev, nred)
+    if (p.tw == 16) { if (depth == 2) BX_OWN(16, 2); else BX_OWN(16, 1); }
+    else            { if (depth == 2) BX_OWN(32, 2); else BX_OWN(32, 1); }
+#undef BX_OWN
+  } else
 #define BX_WG(MA_, NB_) do { if (p.tw == 16) launch_wgrad<MA_, NB_, 16>(p, x, dz, part, H, W, Ci_p, Co, prev, zextra, s); \
                              else launch_wgrad<MA_, NB_, 32>(p, x, dz, part, H, W, Ci_p, Co, prev, zextra, s); } while (0)
-  if (p.ma == 1 && p.nb == 1) BX_WG(1, 1);
+  { if (p.ma == 1 && p.nb == 1) BX_WG(1, 1);
   else if (p.ma == 1 && p.nb == 2) BX_WG(1, 2);
   else if (p.ma == 2 && p.nb == 1) BX_WG(2, 1);
-  else BX_WG(2, 2);
+  else BX_WG(2, 2); }
 #undef BX_WG
   BX_CHECK_LAUNCH("bx_conv3x3_wgrad(mfma)");
   bxWgradPending cur;
