@@ -164,6 +164,7 @@ def main():
 
     import brainxai
     from brainxai import ops
+    brainxai_stack_regions = brainxai.stack_spectrogram_regions
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     extra = {}
 
@@ -176,7 +177,12 @@ def main():
 
     # ---- synthetic inputs, seed 42 + rank, generated on the host like a DataLoader would
     g = torch.Generator().manual_seed(42 + rank)
-    spec = torch.rand(B, CIN, H, W, generator=g).to(dev)
+    # spectrogram side: parquet-like power values [B, 320 time rows, 4 regions x 100 bins] (positive, heavy-tailed, 0.2 % NaNs)
+    # -> the GPU region stacker (window, NaN fill, min-max, anti-aliased resize) -> [B,4,128,256], resident
+    sraw = torch.exp(torch.randn(B, 320, 400, generator=g) * 1.5 + torch.linspace(2, -2, 400)[None, None, :])
+    sraw[torch.rand(B, 320, 400, generator=g) < 2e-3] = float("nan")
+    sraw = sraw.to(dev)
+    spec = brainxai_stack_regions(sraw)
     raw = (torch.randn(B, RAW_LEN, CHANS, generator=g) * 100.0)
     flat = raw.view(-1)
     k = flat.numel() // 1000
@@ -186,6 +192,7 @@ def main():
     labels = torch.softmax(torch.randn(B, 6, generator=g), 1).to(dev)
     eeg = brainxai.stack_eeg(raw)                      # [B,1,19,2000], resident
     stacker_sps = montage_sps = specprep_sps = None
+    region_sps = 10 * B / timed(lambda: brainxai_stack_regions(sraw), 10, sync)
     if not args.no_extras:
         stacker_sps = 10 * B / timed(lambda: brainxai.stack_eeg(raw), 10, sync)
         # the notebook's native montage chain, raw frames [B,10000,20] -> [B,1,37,3000]
@@ -235,12 +242,14 @@ def main():
     # ---- the same step with the stacker in the loop (SURVEY 8(d) "end-to-end" figure): raw EEG [64,10000,19] -> stack -> step
     def e2e():
         inputs[0].copy_(brainxai.stack_eeg(raw))
+        inputs[1].copy_(brainxai_stack_regions(sraw))
         step()
     e2e()
     e2e_n = min(args.steps, 50)
     e2e_elapsed = all_max(timed(e2e, e2e_n, sync))
     extra["end_to_end_samples_per_sec"] = round(world * B * e2e_n / e2e_elapsed, 1)
-    extra["end_to_end_note"] = "raw EEG [64,10000,19] -> GPU stacker -> training step, one stream, nothing overlapped"
+    extra["end_to_end_note"] = ("raw EEG [64,10000,19] -> GPU stacker, raw spectrogram values [64,320,400] -> GPU region stacker, then the "
+                                "training step; one stream, nothing overlapped")
 
     # ---- per-kernel HIP-event timing of the conv family: the same step launched eagerly right after the timed
     # region (events cannot bracket kernels inside a replayed graph), same buffers, same data
@@ -368,7 +377,7 @@ def main():
         torch.set_num_threads(max(1, min(avail, 16)))
         ref = O.build_multimodal(CHANS, T, CIN, dropout=0.5).train()
         ropt = torch.optim.AdamW(ref.parameters(), lr=1e-3)
-        ce, cs, cl = eeg.cpu(), spec.cpu(), labels.cpu()
+        ce, cs, cl = eeg.cpu(), spec.float().cpu(), labels.cpu()
         O.train_step(ref, ropt, ce, cs, cl)
         t0 = time.perf_counter()
         for _ in range(args.cpu_steps):
@@ -387,6 +396,11 @@ def main():
         t0 = time.perf_counter()
         O.stack_eeg_batch(raw[:16].cpu().numpy())
         cpu["stacker_samples_per_sec"] = round(16 / (time.perf_counter() - t0), 2)                 # one host core, numpy/scipy (dataset.py:73-104)
+        sr_host = sraw[:8].cpu().numpy()
+        t0 = time.perf_counter()
+        for f in sr_host:
+            O.spectrogram_regions_transform(f)
+        cpu["spectrogram_region_stacker_samples_per_sec"] = round(8 / (time.perf_counter() - t0), 2)
         if not args.no_extras:
             fr = O.synthetic_frames(batch=4, seed=3)
             t0 = time.perf_counter()
@@ -426,6 +440,7 @@ def main():
                                                                            if stepper.plan is not None else "one all-reduce(AVG) of the flat arena")},
                 "hip_graph": graphed, "final_loss": round(loss_val, 6), "gradcam": gradcam,
                 "stacker_samples_per_sec": None if stacker_sps is None else round(stacker_sps, 1),
+                "spectrogram_region_stacker_samples_per_sec": round(region_sps, 1),
                 "montage_stacker_samples_per_sec": None if montage_sps is None else round(montage_sps, 1),
                 "spectrogram_prep_samples_per_sec": None if specprep_sps is None else round(specprep_sps, 1),
                 "roofline": roofline, "cpu_baseline": cpu}

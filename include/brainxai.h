@@ -329,6 +329,18 @@ int bx_spec_preprocess(const float* raw, const int* offsets, float* out, int B, 
                        const double* notch_b, const double* notch_a, const double* notch_zi, const double* gauss_w,
                        float eps, int* status, void* workspace, size_t workspace_bytes, bxStream stream);
 
+/* ---- benchmark-variant spectrogram stacker (spectrogram half): four region planes per sample ----------- */
+/* raw fp32 [B,Trows,C] parquet values (C = regions x bins, NaNs allowed); offsets device int32[B] or NULL (window of `win` time
+ * rows from offset // 2, zero padded; XAI_Multimodality.py:1178-1183); out fp32 [B,regions,Ho,Wo].  Chain: transpose ->
+ * normalize_signal (root/src/utils/data_utils.py:133-136: NaN -> nanmean of the sample, min-max with eps) -> per region
+ * resample_spectrogram (data_utils.py:145-147: skimage.transform.resize(mode='reflect', anti_aliasing=True): gaussian_filter
+ * with the host-supplied 1-D weights gauss_y[2*radius_y+1] / gauss_x[2*radius_x+1] ('mirror' boundary; radius 0 = no filter),
+ * then order-1 zoom with grid_mode coordinates, mirrored indices).  fp64 arithmetic. */
+size_t bx_spec_regions_workspace(int B);
+int bx_spec_regions(const float* raw, const int* offsets, float* out, int B, int Trows, int C, int regions, int win, int Ho, int Wo,
+                    const double* gauss_y, int radius_y, const double* gauss_x, int radius_x, float eps, void* workspace,
+                    size_t workspace_bytes, bxStream stream);
+
 /* ---- optimiser over the flat parameter arena (torch.optim.AdamW, NB:1988) ------------------------ */
 /* p, g, m, v fp32 [n]; step_count device float[1]: incremented by this call, then used as t. */
 int bx_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,

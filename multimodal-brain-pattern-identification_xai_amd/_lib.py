@@ -121,6 +121,8 @@ SIGNATURES = {
     "bx_spec_preprocess_workspace": (sz, [i32, i32, i32]),
     "bx_spec_preprocess": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_double),
                                  f32, vp, vp, sz, vp]),
+    "bx_spec_regions_workspace": (sz, [i32]),
+    "bx_spec_regions": (i32, [vp, vp, vp] + [i32] * 7 + [P(C.c_double), i32, P(C.c_double), i32, f32, vp, sz, vp]),
     "bx_adamw_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, f32, vp, vp]),
     "bx_adamw_partials": (sz, [sz]),
     "bx_adamw_step_dev": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),

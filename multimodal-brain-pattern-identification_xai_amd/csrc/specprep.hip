@@ -148,3 +148,124 @@ extern "C" int bx_spec_preprocess(const float* raw, const int* offsets, float* o
   BX_CHECK_LAUNCH("bx_spec_preprocess");
   return BX_OK;
 }
+
+// ================================================================================================
+// Benchmark-variant spectrogram stacker (spectrogram half): parquet values [B, Trows, C] (C = regions x
+// bins: the four 100-bin regions of a Kaggle HMS spectrogram) -> [B, regions, Ho, Wo] fp32 region planes.
+//   window of `win` time rows from offset // 2, zero padded (process_spectrogram, XAI_Multimodality.py:1178-1183) -> transpose
+//   to [C, win] -> normalize_signal (root/src/utils/data_utils.py:133-136: NaN -> nanmean of the sample, min-max with eps) ->
+//   per region resample_spectrogram (data_utils.py:145-147: skimage.transform.resize, mode='reflect', anti_aliasing=True).
+// skimage 0.24's resize for 2-D input is gaussian_filter(sigma = max(0, (s-1)/2), 'mirror') + ndi.zoom(order 1, 'mirror',
+// grid_mode=True) + clip to the input range (a no-op for convex weights): out(oy, ox) = bilinear sample of the filtered plane at
+// ((oy + 0.5) h/Ho - 0.5, (ox + 0.5) w/Wo - 0.5), indices mirrored about the edge samples.  Normalisation is affine and the
+// resize weights sum to one, so the min-max is applied to the resized value.  All arithmetic in fp64 (scipy's type).
+#define SR_MAX_RADIUS 8
+struct SpecRegCoef { double gy[2 * SR_MAX_RADIUS + 1], gx[2 * SR_MAX_RADIUS + 1]; int ry, rx; };
+
+__device__ __forceinline__ int sr_mirror(int i, int n) {     // numpy 'reflect' / scipy 'mirror': (d c b | a b c d | c b a)
+  if (n == 1) return 0;
+  const int period = 2 * (n - 1);
+  i = i < 0 ? -i : i;
+  i %= period;
+  return i > n - 1 ? period - i : i;
+}
+// stats[b] = {nanmean, min, max} of the windowed sample (zero padding included, NaNs replaced by the nanmean)
+__global__ __launch_bounds__(256) void k_specreg_stats(const float* __restrict__ raw, const int* __restrict__ offsets, double* __restrict__ stats,
+                                                       int Trows, int C, int win) {
+  __shared__ double ssum[256], smin[256], smax[256];
+  __shared__ long long scnt[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int o = offsets ? offsets[b] / 2 : 0;
+  const float* src = raw + (size_t)b * Trows * C;
+  double sum = 0.0, mn = INFINITY, mx = -INFINITY;
+  long long cnt = 0, nnan = 0;
+  const long long n = (long long)win * C;
+  for (long long i0 = tid; i0 < n; i0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long i = i0 + (long long)u * 256;
+      const int j = (int)(i / C), c = (int)(i - (long long)j * C);
+      const bool live = i < n && o + j >= 0 && o + j < Trows;
+      v[u] = live ? src[(size_t)(o + j) * C + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (i0 + (long long)u * 256 >= n) continue;
+      const double d = (double)v[u];
+      if (d == d) { sum += d; ++cnt; mn = fmin(mn, d); mx = fmax(mx, d); } else ++nnan;
+    }
+  }
+  ssum[tid] = sum; scnt[tid] = cnt; smin[tid] = mn; smax[tid] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { ssum[tid] += ssum[tid + s]; scnt[tid] += scnt[tid + s]; smin[tid] = fmin(smin[tid], smin[tid + s]); smax[tid] = fmax(smax[tid], smax[tid + s]); }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double mean = scnt[0] ? ssum[0] / (double)scnt[0] : 0.0;
+    double lo = smin[0], hi = smax[0];
+    if (scnt[0] < n) { lo = fmin(lo, mean); hi = fmax(hi, mean); }      // the fill value takes part in the min-max
+    if (!scnt[0]) { lo = hi = 0.0; }
+    stats[b * 3 + 0] = mean; stats[b * 3 + 1] = lo; stats[b * 3 + 2] = hi;
+  }
+}
+__global__ __launch_bounds__(256) void k_specreg_resize(const float* __restrict__ raw, const int* __restrict__ offsets, const double* __restrict__ stats,
+                                                        float* __restrict__ out, int Trows, int C, int win, int bins, int Ho, int Wo,
+                                                        SpecRegCoef k, double eps) {
+  // 16 (frequency) x 16 (time) output tile per workgroup: neighbouring threads read neighbouring frequency bins (contiguous in `raw`)
+  const int b = blockIdx.z, r = blockIdx.y;
+  const int tiles_x = (Wo + 15) / 16;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int oy = ty * 16 + (threadIdx.x & 15), ox = tx * 16 + (threadIdx.x >> 4);
+  if (oy >= Ho || ox >= Wo) return;
+  const int o = offsets ? offsets[b] / 2 : 0;
+  const float* src = raw + (size_t)b * Trows * C + (size_t)r * bins;
+  const double mean = stats[b * 3], lo = stats[b * 3 + 1], hi = stats[b * 3 + 2];
+  auto at = [&](int f, int j) -> double {                      // filled, un-normalised sample: frequency bin f of region r, time j of the window
+    const int t = o + j;
+    if (t < 0 || t >= Trows) return 0.0;
+    const double d = (double)src[(size_t)t * C + f];
+    return d == d ? d : mean;
+  };
+  auto filtered = [&](int f, int j) -> double {                // anti-aliasing gaussian (separable, mirrored), identity when both radii are 0
+    if (k.ry == 0 && k.rx == 0) return at(f, j);
+    double acc = 0.0;
+    for (int dy = -k.ry; dy <= k.ry; ++dy) {
+      const int ff = sr_mirror(f + dy, bins);
+      double row = 0.0;
+      for (int dx = -k.rx; dx <= k.rx; ++dx) row += k.gx[dx + k.rx] * at(ff, sr_mirror(j + dx, win));
+      acc += k.gy[dy + k.ry] * row;
+    }
+    return acc;
+  };
+  const double cy = ((double)oy + 0.5) * (double)bins / (double)Ho - 0.5, cx = ((double)ox + 0.5) * (double)win / (double)Wo - 0.5;
+  const int y0 = (int)floor(cy), x0 = (int)floor(cx);
+  const double wy = cy - (double)y0, wx = cx - (double)x0;
+  const int ya = sr_mirror(y0, bins), yb = sr_mirror(y0 + 1, bins), xa = sr_mirror(x0, win), xb = sr_mirror(x0 + 1, win);
+  const double v = (1.0 - wy) * ((1.0 - wx) * filtered(ya, xa) + wx * filtered(ya, xb)) + wy * ((1.0 - wx) * filtered(yb, xa) + wx * filtered(yb, xb));
+  out[(((size_t)b * gridDim.y + r) * Ho + oy) * Wo + ox] = (float)((v - lo) / (hi - lo + eps));
+}
+
+extern "C" size_t bx_spec_regions_workspace(int B) { return (size_t)B * 3 * sizeof(double) + 256; }
+extern "C" int bx_spec_regions(const float* raw, const int* offsets, float* out, int B, int Trows, int C, int regions, int win, int Ho, int Wo,
+                               const double* gauss_y, int radius_y, const double* gauss_x, int radius_x, float eps, void* workspace,
+                               size_t workspace_bytes, bxStream stream) {
+  BX_REQUIRE(raw && out && workspace && B > 0 && B <= 65535 && Trows > 0 && C > 0 && regions > 0 && regions <= 65535 && C % regions == 0 && win > 0 && Ho > 0 && Wo > 0,
+             "bx_spec_regions: bad arguments");
+  BX_REQUIRE(radius_y >= 0 && radius_y <= SR_MAX_RADIUS && radius_x >= 0 && radius_x <= SR_MAX_RADIUS && (radius_y == 0 || gauss_y) && (radius_x == 0 || gauss_x),
+             "bx_spec_regions: anti-aliasing radius must be 0..%d", SR_MAX_RADIUS);
+  BX_REQUIRE(workspace_bytes >= bx_spec_regions_workspace(B), "bx_spec_regions: workspace too small");
+  SpecRegCoef k;
+  k.ry = radius_y; k.rx = radius_x;
+  for (int i = 0; i < 2 * SR_MAX_RADIUS + 1; ++i) { k.gy[i] = radius_y && i <= 2 * radius_y ? gauss_y[i] : (i == 0 ? 1.0 : 0.0); k.gx[i] = radius_x && i <= 2 * radius_x ? gauss_x[i] : (i == 0 ? 1.0 : 0.0); }
+  double* stats = reinterpret_cast<double*>(bx_align_up((uintptr_t)workspace, 8));
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_specreg_stats, dim3(B), dim3(256), 0, s, raw, offsets, stats, Trows, C, win);
+  const int bins = C / regions;
+  const int tiles = ((Ho + 15) / 16) * ((Wo + 15) / 16);
+  hipLaunchKernelGGL(k_specreg_resize, dim3(tiles, regions, B), dim3(256), 0, s, raw, offsets, (const double*)stats, out, Trows, C, win, bins, Ho, Wo, k,
+                     (double)eps);
+  BX_CHECK_LAUNCH("bx_spec_regions");
+  return BX_OK;
+}

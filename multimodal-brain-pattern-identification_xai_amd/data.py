@@ -212,3 +212,70 @@ def preprocess_spectrograms(raw: torch.Tensor, offsets=None) -> torch.Tensor:
     if _SPECPREP is None:
         _SPECPREP = SpectrogramPreprocessor()
     return _SPECPREP(raw, offsets)
+
+
+class SpectrogramRegionStacker:
+    """The benchmark's spectrogram input (BASELINE.json: [B, 4, 128, 256]) from raw parquet values, on the GPU: the four 100-bin
+    regions of a Kaggle HMS spectrogram (LL, RL, RP, LP = 400 columns) become four channel planes.  The reference has no 4-plane
+    pipeline (its CNN takes one 400 x 300 image tiled to 3 channels); this composes the reference's own helpers on that layout:
+    a window of ``window`` time rows from ``offset // 2`` (zero padded; XAI_Multimodality.py:1178-1183), ``normalize_signal``
+    (root/src/utils/data_utils.py:133-136) over the sample and ``resample_spectrogram`` (data_utils.py:145-147: scikit-image's
+    anti-aliased bilinear resize, restated from scikit-image 0.24: gaussian pre-filter with sigma = (s - 1) / 2 where an axis
+    shrinks, then an order-1 zoom) of every region to ``out_hw``.
+
+    raw: CUDA float tensor [B, Trows, regions * bins] (NaNs allowed); offsets: optional int tensor / list [B].
+    Returns float32 [B, regions, out_h, out_w]."""
+
+    def __init__(self, out_hw=(128, 256), window=300, regions=4, eps=1e-6):
+        self.out_hw, self.window, self.regions, self.eps = (int(out_hw[0]), int(out_hw[1])), int(window), int(regions), float(eps)
+        self._g = {}
+
+    @staticmethod
+    def _gauss(n_in, n_out, truncate=4.0):
+        sigma = max(0.0, (n_in / n_out - 1.0) / 2.0)
+        radius = int(truncate * sigma + 0.5)
+        if radius == 0:
+            return np.ones(1, dtype=np.float64), 0
+        x = np.arange(-radius, radius + 1)
+        phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+        return np.ascontiguousarray(phi / phi.sum(), dtype=np.float64), radius
+
+    def __call__(self, raw: torch.Tensor, offsets=None) -> torch.Tensor:
+        if not raw.is_cuda:
+            raise RuntimeError("brainxai.SpectrogramRegionStacker: raw spectrograms must be a CUDA tensor; there is no CPU path")
+        if raw.dim() != 3 or raw.shape[2] % self.regions:
+            raise RuntimeError(f"expected raw spectrogram frames [B, Trows, {self.regions} * bins], got {tuple(raw.shape)}")
+        raw = raw.contiguous().float()
+        B, Trows, Cc = raw.shape
+        Ho, Wo = self.out_hw
+        if B == 0:
+            return torch.empty(0, self.regions, Ho, Wo, device=raw.device)
+        off = None
+        if offsets is not None:
+            off = torch.as_tensor(offsets, dtype=torch.int32).to(raw.device).contiguous()
+            if off.numel() != B or int(off.min()) < 0:
+                raise RuntimeError("offsets must be B non-negative integers")
+        key = (Cc // self.regions, self.window)
+        if key not in self._g:
+            self._g[key] = (self._gauss(key[0], Ho), self._gauss(key[1], Wo))
+        (gy, ry), (gx, rx) = self._g[key]
+        if ry > 8 or rx > 8:
+            raise RuntimeError("SpectrogramRegionStacker: down-scaling factor too large for the kernel's anti-aliasing radius (8)")
+        lib = L.load()
+        out = torch.empty(B, self.regions, Ho, Wo, dtype=torch.float32, device=raw.device)
+        ws = workspace(lib.bx_spec_regions_workspace(B), raw.device)
+        dbl = C.POINTER(C.c_double)
+        L.check(lib.bx_spec_regions(_p(raw), _p(off), _p(out), B, Trows, Cc, self.regions, self.window, Ho, Wo, gy.ctypes.data_as(dbl), ry,
+                                    gx.ctypes.data_as(dbl), rx, self.eps, _p(ws), ws.numel(), _stream()), "bx_spec_regions")
+        return out
+
+
+_REGIONS = None
+
+
+def stack_spectrogram_regions(raw: torch.Tensor, offsets=None) -> torch.Tensor:
+    """Benchmark defaults: [B, Trows, 400] parquet values -> [B, 4, 128, 256]."""
+    global _REGIONS
+    if _REGIONS is None:
+        _REGIONS = SpectrogramRegionStacker()
+    return _REGIONS(raw, offsets)

@@ -542,6 +542,31 @@ def test_spectrogram_preprocessing():
     assert pre(torch.from_numpy(frames[:0]).to(DEV)).shape == (0, 3, 400, 300)
 
 
+def test_spectrogram_region_stacker():
+    """Row H, spectrogram half (benchmark variant): parquet values [B, Trows, 400] -> four region planes [B, 4, 128, 256] (window,
+    NaN -> nanmean, per-sample min-max, scikit-image-style anti-aliased resize per region) against the oracle's restatement
+    (normalize_signal + scipy.ndimage gaussian_filter / zoom); also a down-scaling geometry where the anti-aliasing filter is active,
+    short frames (zero padding) and the empty batch"""
+    frames = O.synthetic_spectrogram_frames(batch=3, trows=320, seed=5)
+    assert np.isnan(frames).any()
+    offs = [0, 20, 60]
+    got = brainxai.stack_spectrogram_regions(torch.from_numpy(frames).to(DEV), offs)
+    want = np.stack([O.spectrogram_regions_transform(f, o) for f, o in zip(frames, offs)])
+    assert got.shape == (3, 4, 128, 256) and _sync_err(got, want) < 2e-5
+    assert float(got.min()) >= 0.0 and float(got.max()) <= 1.0
+    none = brainxai.stack_spectrogram_regions(torch.from_numpy(frames[:1]).to(DEV))
+    assert _sync_err(none, O.spectrogram_regions_transform(frames[0], None)[None]) < 2e-5
+    small = brainxai.SpectrogramRegionStacker(out_hw=(32, 100))           # 100 -> 32 bins, 300 -> 100 columns: sigma 1.06 / 1.0, radius 4
+    want_s = np.stack([O.spectrogram_regions_transform(f, 0, out_hw=(32, 100)) for f in frames[:2]])
+    assert _sync_err(small(torch.from_numpy(frames[:2]).to(DEV), [0, 0]), want_s) < 2e-5
+    short = O.synthetic_spectrogram_frames(batch=2, trows=120, seed=9)       # 120 time rows: the window is zero padded to 300
+    want_z = np.stack([O.spectrogram_regions_transform(f, 40) for f in short])
+    assert _sync_err(brainxai.stack_spectrogram_regions(torch.from_numpy(short).to(DEV), [40, 40]), want_z) < 2e-5
+    assert brainxai.stack_spectrogram_regions(torch.from_numpy(frames[:0]).to(DEV)).shape == (0, 4, 128, 256)
+    with pytest.raises(RuntimeError, match="regions"):
+        brainxai.stack_spectrogram_regions(torch.zeros(1, 10, 399, device=DEV))
+
+
 def test_native_pipeline_end_to_end():
     """The literal reference multimodal configuration (NB:1132-1146 + NB:1932-1935): raw EEG frames and parquet spectrogram values
     -> GPU pre-processing (8(f) ranks 2 and 3) -> MultimodalModel(EEGNet(6, 37, 3000), Spectrogram_Model(6)) forward, loss,

@@ -32,3 +32,39 @@ def test_ig_completeness():
         base = net(torch.zeros_like(eeg), torch.zeros_like(spec))
     total = float(ie.sum() + is_.sum())
     assert abs(total - float(out[0, c] - base[0, c])) < 0.05 * abs(float(out[0, c] - base[0, c])) + 1e-3
+
+
+def test_region_stacker_resize_restatement():
+    """Row H, spectrogram half: the oracle's skimage.transform.resize restatement (two scipy.ndimage calls, as scikit-image 0.24
+    does for 2-D input) against the closed form the HIP kernel implements -- separable gaussian with mirrored indices, then a
+    bilinear sample at ((o + 0.5) n_in / n_out - 0.5) with mirrored indices -- up- and down-scaling."""
+    import numpy as np
+    from oracle import ref_torch as O
+
+    def mir(i, n):
+        i = -i if i < 0 else i
+        return 2 * (n - 1) - i if i > n - 1 else i
+
+    def manual(x, H, W):
+        h, w = x.shape
+        for axis, wts in ((0, O.resize_gaussian_weights(h, H)), (1, O.resize_gaussian_weights(w, W))):
+            r = len(wts) // 2
+            if r:
+                xp = np.pad(x, [(r, r) if a == axis else (0, 0) for a in range(2)], mode="reflect")
+                x = sum(wts[k] * (xp[k:k + h] if axis == 0 else xp[:, k:k + w]) for k in range(len(wts)))
+        out = np.zeros((H, W))
+        for oy in range(H):
+            cy = (oy + 0.5) * h / H - 0.5; y0 = int(np.floor(cy)); ty = cy - y0
+            for ox in range(W):
+                cx = (ox + 0.5) * w / W - 0.5; x0 = int(np.floor(cx)); tx = cx - x0
+                out[oy, ox] = ((1 - ty) * ((1 - tx) * x[mir(y0, h), mir(x0, w)] + tx * x[mir(y0, h), mir(x0 + 1, w)])
+                               + ty * ((1 - tx) * x[mir(y0 + 1, h), mir(x0, w)] + tx * x[mir(y0 + 1, h), mir(x0 + 1, w)]))
+        return out
+    g = np.random.default_rng(0)
+    for (h, w, H, W) in ((100, 300, 128, 256), (100, 300, 32, 100), (37, 53, 64, 20)):
+        x = g.random((h, w))
+        assert np.abs(O.skimage_resize(x, (H, W)) - manual(x, H, W)).max() < 1e-12, (h, w, H, W)
+    fr = O.synthetic_spectrogram_frames(batch=1, trows=320, seed=5)[0]
+    out = O.spectrogram_regions_transform(fr, offset=20)
+    assert out.shape == (4, 128, 256) and out.dtype == np.float32 and 0.0 <= out.min() and out.max() <= 1.0
+    assert np.isnan(fr).any() and not np.isnan(out).any()
