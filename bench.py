@@ -82,7 +82,7 @@ def pmc_conv_traffic(dtype):
     for path in reversed(files):
         tot, launches = 0.0, 0.0
         for line in open(path):
-            if not line.startswith(("k_conv_mfma", "k_conv3x3", "k_wgrad_mfma", "k_wgrad_reduce")):
+            if not line.startswith(("k_conv_mfma", "k_conv3x3", "k_wgrad_mfma", "k_wgrad_own", "k_wgrad_reduce")):
                 continue
             try:
                 wr, fe, n = float(line.split()[-1]), float(line.split()[-2]), float(line.split()[-3])

@@ -189,7 +189,7 @@ typedef struct {
   int P1, P2;           /* average-pool widths 4 and 8                               */
   int training;
   float eps, momentum, dropout_p;
-  uint32_t salt;
+  uint32_t salt;        /* bit 31 set: one mask entry per (sample, channel) = nn.Dropout2d (models.py:255) */
   int dtype;            /* storage of the big intermediates (conv1 output)           */
 } bxEegDesc;
 /* Parameter block: pointers to the fp32 tensors of the module, reference names in comments. */
@@ -227,7 +227,7 @@ typedef struct {
   int Hd, N;            /* dense1 width (128; power of two in [32,256]), classes (<=16) */
   int training;
   float eps, momentum, dropout_p;
-  uint32_t salt;
+  uint32_t salt;        /* bit 31 set: one mask entry per (sample, channel) = nn.Dropout2d (models.py:255) */
 } bxEegDeepDesc;
 typedef struct {
   const float* conv2_w;      /* conv2.weight [F3,F2,1,K3] */
@@ -355,6 +355,10 @@ int bx_adamw_step_dev(float* p, const float* g, float* m, float* v, size_t n, co
                       float* sumsq_partials, float* l2_value, bxStream stream);
 /* sum of squares of a flat fp32 arena -> out[1] (DDP loop's manual L2 term, DDP:52-53). */
 int bx_sumsq(const float* x, size_t n, float* out, bxStream stream);
+/* LIME's batched inference (XAI_Multimodality.py:1567-1574): uint8 images [N,H,W,C] -> scale * value in the internal
+ * channels-last layout [N,H,W,Cp] (dtype; channels C..Cp-1 zero) = torchvision ToTensor with scale 1/255; row-wise softmax. */
+int bx_u8_to_nhwc(const unsigned char* src, void* dst, int N, int H, int W, int C, int Cp, float scale, int dtype, bxStream stream);
+int bx_softmax_rows(const float* x, float* y, int rows, int N, bxStream stream);
 /* attribution seeds: seed fp32 [rows,N], row r = onehot(class of sample r % B); class_mode >= 0: that class, -1: arg-max of
  * logp fp32 [B,N] (first maximum).  Replaces the reference's output[0, argmax] indexing (XAI_Multimodality.py:3110-3111). */
 int bx_class_seed(const float* logp, float* seed, int rows, int B, int N, int class_mode, bxStream stream);

@@ -7,7 +7,7 @@ from . import _lib, ops                                                       # 
 from .models import (Attention, Block, EEGNet, EEGNetAttentionDeep, KLDivLoss, MultimodalModel, Spectrogram_Model,   # noqa: F401
                      build_multimodal, set_compute_dtype)
 from .explain import (GradCamSweep, expected_gradients, generate_saliency_maps, grad_cam, integrated_gradients, saliency,   # noqa: F401
-                      shard_bounds, sharded_sweep)
+                      predict_fn, shard_bounds, sharded_sweep)
 from .data import (EEGStacker, stack_eeg, EEGMontageStacker, stack_eeg_montage,          # noqa: F401
                    SpectrogramPreprocessor, preprocess_spectrograms, SpectrogramRegionStacker, stack_spectrogram_regions)                                        # noqa: F401
 from .train import (FlatAdamW, DataParallel, GraphedTrainStep, AsyncCheckpointer, train_and_validate_combined, train_and_validate_eeg_distributed,   # noqa: F401

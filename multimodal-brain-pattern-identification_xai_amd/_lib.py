@@ -127,6 +127,8 @@ SIGNATURES = {
     "bx_adamw_partials": (sz, [sz]),
     "bx_adamw_step_dev": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
     "bx_sumsq": (i32, [vp, sz, vp, vp]),
+    "bx_u8_to_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),
+    "bx_softmax_rows": (i32, [vp, vp, i32, i32, vp]),
     "bx_class_seed": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "bx_seed_next": (i32, [vp, vp, vp]),
     "bx_seed_next2": (i32, [vp, vp, vp, vp, vp]),

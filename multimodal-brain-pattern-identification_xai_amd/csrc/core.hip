@@ -331,6 +331,45 @@ extern "C" int bx_sumsq(const float* x, size_t n, float* out, bxStream stream) {
   return BX_OK;
 }
 
+// LIME's batched inference (reference XAI_Multimodality.py:1567-1574, predict_fn): uint8 images [N,H,W,C] (what LIME hands over
+// after astype(np.uint8)) -> torchvision ToTensor (x / 255, channels first) -> the model's internal channels-last layout in one
+// pass; and softmax over the returned scores.
+template <typename T>
+__global__ void k_u8_to_nhwc(const unsigned char* __restrict__ src, T* __restrict__ dst, long long npix, int C, int Cp, float scale) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  for (int c0 = 0; c0 < Cp; c0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (c0 + j) < C ? (float)src[p * C + c0 + j] * scale : 0.f;
+    st8(dst, (size_t)p * Cp + c0, v);
+  }
+}
+extern "C" int bx_u8_to_nhwc(const unsigned char* src, void* dst, int N, int H, int W, int C, int Cp, float scale, int dtype, bxStream stream) {
+  BX_DTYPE_OK(dtype);
+  BX_REQUIRE(src && dst && N > 0 && H > 0 && W > 0 && C > 0 && Cp % 8 == 0 && C <= Cp, "bx_u8_to_nhwc: bad arguments");
+  const long long npix = (long long)N * H * W;
+  BX_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((k_u8_to_nhwc<T>), dim3(bx_ceil_div(npix, 256)), dim3(256), 0, (hipStream_t)stream, src, (T*)dst, npix,
+                                                 C, Cp, scale));
+  BX_CHECK_LAUNCH("bx_u8_to_nhwc");
+  return BX_OK;
+}
+__global__ void k_softmax_rows(const float* __restrict__ x, float* __restrict__ y, int rows, int N) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* xr = x + (size_t)r * N;
+  float m = -INFINITY, se = 0.f;
+  for (int n = 0; n < N; ++n) m = fmaxf(m, xr[n]);
+  for (int n = 0; n < N; ++n) se += expf(xr[n] - m);
+  for (int n = 0; n < N; ++n) y[(size_t)r * N + n] = expf(xr[n] - m) / se;
+}
+extern "C" int bx_softmax_rows(const float* x, float* y, int rows, int N, bxStream stream) {
+  BX_REQUIRE(x && y && rows > 0 && N > 0, "bx_softmax_rows: bad arguments");
+  hipLaunchKernelGGL(k_softmax_rows, dim3(bx_ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream, x, y, rows, N);
+  BX_CHECK_LAUNCH("bx_softmax_rows");
+  return BX_OK;
+}
+
 // gradient seeds for attribution: seed[r][:] = onehot(class of sample r % B), the class being class_mode (>= 0) or the arg-max of
 // logp[r % B] (first maximum, like torch.argmax) -- replaces zeros + argmax + scatter_ (+ repeat) framework launches
 __global__ void k_class_seed(const float* __restrict__ logp, float* __restrict__ seed, int R, int B, int N, int class_mode) {

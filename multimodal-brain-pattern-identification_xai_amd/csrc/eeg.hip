@@ -248,7 +248,7 @@ __global__ void k_eeg_bn_elu_pool(const float* __restrict__ in, const float* __r
     float s = 0.f;
     for (int j = 0; j < P; ++j) s += elu1(src[j] * a + c);
     s /= (float)P;
-    if (dropout_p > 0.f) s *= bx_dropout_scale(sd, salt, (uint64_t)i, dropout_p, inv_keep);
+    if (dropout_p > 0.f) s *= bx_dropout_scale(sd, salt, (salt >> 31) ? (uint64_t)bf : (uint64_t)i, dropout_p, inv_keep);   // salt bit 31: one mask entry per (sample, channel) = nn.Dropout2d
     out[i] = s;
   }
 }
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void k_eeg_act_bwd(const float* __restrict__ d
     if (to < Tout) {
       const size_t io = ((size_t)b * F + f) * Tout + to;
       float go = dpool[io] / (float)P;
-      if (dropout_p > 0.f) go *= bx_dropout_scale(sd, salt, (uint64_t)io, dropout_p, inv_keep);
+      if (dropout_p > 0.f) go *= bx_dropout_scale(sd, salt, (salt >> 31) ? (uint64_t)((size_t)b * F + f) : (uint64_t)io, dropout_p, inv_keep);
       const float v = pre[i];
       const float u = v * a + c;
       g_ = u > 0.f ? go : go * expf(u);

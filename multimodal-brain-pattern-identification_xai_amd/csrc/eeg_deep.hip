@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_deep_head(DeepHeadArgs a) {
 #pragma unroll
     for (int u = 0; u < DP_P; ++u) { const float y = v[u] * s_ + h_; s += y > 0.f ? y : expm1f(y); }
     s *= 1.f / DP_P;
-    if (a.dropout_p > 0.f) s *= bx_dropout_scale(sd, a.salt, (uint64_t)((size_t)b * K + idx), a.dropout_p, inv_keep);
+    if (a.dropout_p > 0.f) s *= bx_dropout_scale(sd, a.salt, (a.salt >> 31) ? (uint64_t)((size_t)b * DP_F3 + c) : (uint64_t)((size_t)b * K + idx), a.dropout_p, inv_keep);   // bit 31: nn.Dropout2d
     x3s[l][c] = s;
     a.x3[((size_t)b * L + l) * DP_F3 + c] = s;
   }
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void k_deep_head_bwd(DeepHeadBwdArgs a) {
         float g_ = 0.f;
         if (l < L) {
           g_ = dOs[l][c] * (1.f / DP_P);
-          if (a.dropout_p > 0.f) g_ *= bx_dropout_scale(sd, a.salt, (uint64_t)((size_t)b * K + c * L + l), a.dropout_p, inv_keep);
+          if (a.dropout_p > 0.f) g_ *= bx_dropout_scale(sd, a.salt, (a.salt >> 31) ? (uint64_t)((size_t)b * DP_F3 + c) : (uint64_t)((size_t)b * K + c * L + l), a.dropout_p, inv_keep);
           const float y = zv[u] * s_ + h_;
           if (y <= 0.f) g_ *= expf(y);
         }

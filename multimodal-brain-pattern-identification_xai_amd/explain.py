@@ -417,3 +417,42 @@ def expected_gradients(model, x, background, nsamples=200, seed=0, max_batch=256
                     for j in range(len(ks)):
                         _axpby(g[j], out[i, c], 1.0 / nsamples, 1.0)
     return out
+
+
+def predict_fn(images, model, device=None, max_batch=256):
+    """LIME's batched-inference callback (reference XAI_Multimodality.py:1567-1574, :2710-2717; called by
+    ``lime_image.LimeImageExplainer.explain_instance`` with the perturbed copies of one spectrogram image).
+
+    images: sequence / array of H x W x C images (LIME passes float arrays holding 0..255 values; the reference casts them with
+    ``astype(np.uint8)`` and applies torchvision's ToTensor = x / 255, channels first).  model: a single-input spectrogram model
+    (``Spectrogram_Model`` or ``multimodal.forward_spectrogram``).  Returns ``softmax(model(batch))`` as a numpy array [N, classes]
+    exactly like the reference (the model already ends in LogSoftmax, so these are its class probabilities).
+    The uint8 -> channels-last conversion, the forward pass and the softmax all run on the GPU, ``max_batch`` images per pass."""
+    imgs = np.ascontiguousarray(np.stack([np.asarray(im) for im in images]).astype(np.uint8))
+    if imgs.ndim != 4:
+        raise ValueError(f"predict_fn expects images [N, H, W, C], got {imgs.shape}")
+    device = torch.device(device) if device is not None else next(model.parameters()).device
+    if device.type != "cuda":
+        raise RuntimeError("brainxai.predict_fn: the model must live on the GPU; there is no CPU path")
+    fwd = model.forward_spectrogram if hasattr(model, "forward_spectrogram") else model
+    net = model.spectrogram_model if hasattr(model, "spectrogram_model") else model
+    dt = getattr(net, "compute_dtype", torch.float32)
+    was_training = model.training
+    model.eval()
+    lib = L.load()
+    N, H, W, Cc = imgs.shape
+    out = []
+    try:
+        with torch.no_grad():
+            for i0 in range(0, N, max_batch):
+                chunk = torch.from_numpy(imgs[i0:i0 + max_batch]).to(device)
+                n = chunk.shape[0]
+                x = torch.empty(n, H, W, ops.pad8(Cc), dtype=dt, device=device)
+                L.check(lib.bx_u8_to_nhwc(_p(chunk), _p(x), n, H, W, Cc, ops.pad8(Cc), 1.0 / 255.0, ops.bx_dtype(dt), _stream()), "bx_u8_to_nhwc")
+                logp = fwd(x.permute(0, 3, 1, 2)).float().contiguous()       # a logical-NCHW view of the internal layout: no further copy
+                probs = torch.empty_like(logp)
+                L.check(lib.bx_softmax_rows(_p(logp), _p(probs), n, logp.shape[1], _stream()), "bx_softmax_rows")
+                out.append(probs.cpu())
+    finally:
+        model.train(was_training)
+    return torch.cat(out).numpy()

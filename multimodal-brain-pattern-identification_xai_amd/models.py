@@ -144,8 +144,8 @@ class EEGNet(nn.Module):
     def __init__(self, nb_classes, Chans=37, Samples=3000, dropoutRate=0.5, kernLength=64, F1=8, D=2, F2=16,
                  norm_rate=0.25, dropoutType="Dropout"):
         super().__init__()
-        if dropoutType != "Dropout":
-            raise NotImplementedError("brainxai EEGNet: only dropoutType='Dropout' (the reference's default) is implemented")
+        if dropoutType not in ("Dropout", "Dropout2d"):
+            raise ValueError("dropoutType must be 'Dropout' or 'Dropout2d' (reference models.py:255)")
         self.nb_classes, self.Chans, self.Samples = nb_classes, Chans, Samples
         self.conv1 = nn.Conv2d(1, F1, (1, kernLength), padding="same", bias=False)
         self.batchnorm1 = nn.BatchNorm2d(F1)
@@ -153,7 +153,7 @@ class EEGNet(nn.Module):
         self.batchnorm2 = nn.BatchNorm2d(F1 * D)
         self.activation = nn.ELU()
         self.avg_pool1 = nn.AvgPool2d((1, 4))
-        self.dropout = nn.Dropout(dropoutRate)
+        self.dropout = nn.Dropout(dropoutRate) if dropoutType == "Dropout" else nn.Dropout2d(dropoutRate)
         self.separableConv = nn.Conv2d(F1 * D, F2, (1, 16), padding="same", bias=False)
         self.batchnorm3 = nn.BatchNorm2d(F2)
         self.avg_pool2 = nn.AvgPool2d((1, 8))
@@ -162,7 +162,7 @@ class EEGNet(nn.Module):
         self.log_softmax = nn.LogSoftmax(dim=1)
         self._geom = SimpleNamespace(F1=F1, D=D, F2=F2, K1=kernLength, K2=16, P1=4, P2=8)
         self.compute_dtype = torch.float32
-        self.salt = 100
+        self.salt = 100 | (0x80000000 if dropoutType == "Dropout2d" else 0)     # bit 31: channel-wise mask (nn.Dropout2d)
 
     def features(self, x, seed=None):
         if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != self.Chans:
@@ -209,8 +209,9 @@ class EEGNetAttentionDeep(nn.Module):
     def __init__(self, nb_classes, Chans=37, Samples=3000, dropoutRate=0.5, kernLength=64, F1=8, D=2, F2=16, F3=32,
                  norm_rate=0.25, dropoutType="Dropout"):
         super().__init__()
-        if dropoutType != "Dropout":
-            raise NotImplementedError("brainxai EEGNetAttentionDeep: only dropoutType='Dropout' (the reference's default) is implemented")
+        if dropoutType not in ("Dropout", "Dropout2d"):
+            raise ValueError("dropoutType must be 'Dropout' or 'Dropout2d' (reference models.py:152-164)")
+        _Drop = nn.Dropout if dropoutType == "Dropout" else nn.Dropout2d
         self.nb_classes, self.Chans, self.Samples = nb_classes, Chans, Samples
         self.conv1 = nn.Conv2d(1, F1, (1, kernLength), padding="same", bias=False)
         self.batchnorm1 = nn.BatchNorm2d(F1)
@@ -218,15 +219,15 @@ class EEGNetAttentionDeep(nn.Module):
         self.batchnorm2 = nn.BatchNorm2d(F1 * D)
         self.activation = nn.ELU()
         self.avg_pool1 = nn.AvgPool2d((1, 4))
-        self.dropout1 = nn.Dropout(dropoutRate)
+        self.dropout1 = _Drop(dropoutRate)
         self.separableConv = nn.Conv2d(F1 * D, F2, (1, 16), padding="same", bias=False)
         self.batchnorm3 = nn.BatchNorm2d(F2)
         self.avg_pool2 = nn.AvgPool2d((1, 8))
-        self.dropout2 = nn.Dropout(dropoutRate)
+        self.dropout2 = _Drop(dropoutRate)
         self.conv2 = nn.Conv2d(F2, F3, (1, 16), padding="same", bias=False)
         self.batchnorm4 = nn.BatchNorm2d(F3)
         self.avg_pool3 = nn.AvgPool2d((1, 8))
-        self.dropout3 = nn.Dropout(dropoutRate)
+        self.dropout3 = _Drop(dropoutRate)
         self.attention_layer = Attention(F3, F3)
         self.output_samples = ((Samples // 4) // 8) // 8
         self.flattened_size = F3 * self.output_samples
@@ -236,7 +237,7 @@ class EEGNetAttentionDeep(nn.Module):
         self.log_softmax = nn.LogSoftmax(dim=1)
         self._geom = SimpleNamespace(F1=F1, D=D, F2=F2, F3=F3, K1=kernLength, K2=16, K3=16, P1=4, P2=8, P3=8)
         self.compute_dtype = torch.float32
-        self.salt = 200
+        self.salt = 200 | (0x80000000 if dropoutType == "Dropout2d" else 0)     # bit 31: channel-wise masks (nn.Dropout2d)
         self.last_attention = None
 
     def features(self, x):

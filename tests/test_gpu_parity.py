@@ -563,7 +563,7 @@ def test_spectrogram_region_stacker():
     want_z = np.stack([O.spectrogram_regions_transform(f, 40) for f in short])
     assert _sync_err(brainxai.stack_spectrogram_regions(torch.from_numpy(short).to(DEV), [40, 40]), want_z) < 2e-5
     assert brainxai.stack_spectrogram_regions(torch.from_numpy(frames[:0]).to(DEV)).shape == (0, 4, 128, 256)
-    with pytest.raises(RuntimeError, match="regions"):
+    with pytest.raises(RuntimeError, match="bins"):
         brainxai.stack_spectrogram_regions(torch.zeros(1, 10, 399, device=DEV))
 
 
@@ -715,6 +715,50 @@ def test_eegnet_bf16_mfma_temporal_conv(chans, samples):
             continue                                # exactly zero in train mode: pure rounding noise
         cos = F.cosine_similarity(g_m[n].flatten().double(), g_v[n].flatten().double(), dim=0)
         assert float(cos) > 0.995, ("mfma vs valu", n, float(cos))
+
+
+@pytest.mark.parametrize("arch", ["EEGNet", "EEGNetAttentionDeep"])
+def test_eeg_dropout2d_is_channelwise(arch):
+    """dropoutType='Dropout2d' (reference models.py:152-164, :255): whole feature maps are dropped per (sample, channel), the
+    backward uses the same mask, the rate is right and a fixed seed state reproduces the pass"""
+    torch.manual_seed(2)
+    net = getattr(brainxai, arch)(6, Chans=19, Samples=2000, dropoutRate=0.5, dropoutType="Dropout2d").to(DEV).train()
+    assert isinstance(net.dropout if arch == "EEGNet" else net.dropout2, torch.nn.Dropout2d)
+    x = torch.randn(32, 1, 19, 2000, device=DEV)
+    ops.manual_seed(5, DEV)
+    f = net.features(x).detach().view(32, 16, 62)               # after pool2 + dropout: [B, F2, T/32]
+    dead = (f == 0).all(-1)
+    assert bool(((f == 0).any(-1) == dead).all()), "a map is dropped entirely or not at all"
+    assert 0.35 < float(dead.float().mean()) < 0.65
+    ops.manual_seed(5, DEV)
+    assert torch.equal(net.features(x).detach().view(32, 16, 62), f)
+    xg = x.clone().requires_grad_(True)
+    ops.manual_seed(5, DEV)
+    net.features(xg).sum().backward()
+    assert torch.isfinite(xg.grad).all()
+    net_e = getattr(brainxai, arch)(6, Chans=19, Samples=2000, dropoutRate=0.5, dropoutType="Dropout").to(DEV).train()
+    fe = net_e.features(x).detach().view(32, 16, 62)
+    assert not bool(((fe == 0).any(-1) == (fe == 0).all(-1)).all()), "element-wise dropout zeroes single entries"
+    with pytest.raises(ValueError):
+        getattr(brainxai, arch)(6, dropoutType="AlphaDropout")
+
+
+def test_lime_predict_fn():
+    """LIME's batched-inference callback (NB:1567-1574): uint8 cast, ToTensor scaling, eval-mode forward of the spectrogram model,
+    softmax -- against the same steps on the oracle, for the bare Spectrogram_Model and for the multimodal wrapper"""
+    ref, mine = _pair(lambda: O.Spectrogram_Model(6), lambda: brainxai.Spectrogram_Model(6), 21)
+    g = np.random.default_rng(3)
+    imgs = (g.random((5, 64, 96, 3)) * 255.9).astype(np.float64)               # LIME hands floats holding 0..255
+    x = torch.from_numpy(imgs.astype(np.uint8)).permute(0, 3, 1, 2).float() / 255.0
+    ref.eval()
+    with torch.no_grad():
+        want = torch.softmax(ref(x), 1).numpy()
+    mine.train()                                                               # predict_fn switches to eval itself and restores the mode
+    got = brainxai.predict_fn(list(imgs), mine, DEV, max_batch=2)
+    assert mine.training and got.shape == (5, 6)
+    assert np.abs(got - want).max() < 1e-5 and np.allclose(got.sum(1), 1.0, atol=1e-5)
+    mm = brainxai.MultimodalModel(brainxai.EEGNet(6, Chans=19, Samples=2000), mine).to(DEV)
+    assert np.abs(brainxai.predict_fn(imgs, mm) - want).max() < 1e-5
 
 
 def test_gradcam_sweep_matches_eager():
