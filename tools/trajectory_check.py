@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Bench-size (B=64, bf16) trajectory check: eager steps vs one-graph replay vs branch-parallel replay must give the same
-losses and parameters (every kernel is deterministic; a difference means a race or a stale buffer)."""
+"""Bench-size (B=64, bf16) trajectory check: eager steps vs hipGraph replay must give the same losses and parameters
+(every kernel is deterministic; a difference means a race or a stale buffer)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,21 +14,20 @@ batches = [((torch.randn(B, 1, 19, 2000, generator=g).to(dev), torch.rand(B, 4, 
             torch.softmax(torch.randn(B, 6, generator=g), 1).to(dev)) for _ in range(STEPS)]
 crit = brainxai.KLDivLoss()
 res = {}
-for mode in ("eager", "graph", "branches"):
+for mode in ("eager", "graph"):
     torch.manual_seed(9)
     m = brainxai.build_multimodal(19, 2000, 4, dropout=float(os.environ.get("TC_DROPOUT", "0.5")), compute_dtype=torch.bfloat16).to(dev).train()
     opt = brainxai.FlatAdamW(m.parameters(), lr=1e-3)
     ops.manual_seed(1234)
     step = brainxai.GraphedTrainStep(m, opt, crit)
     step.enabled = mode != "eager"
-    step.branches = mode == "branches"
     losses = [float(step(list(x), y)[0]) for x, y in batches]
     torch.cuda.synchronize()
     res[mode] = (losses, torch.cat([p.detach().flatten() for p in m.parameters()]).clone())
     ops.clear_grad_views()
     print(mode, " ".join(f"{v:.6f}" for v in losses))
 ok = True
-for mode in ("graph", "branches"):
+for mode in ("graph",):
     dl = max(abs(a - b) for a, b in zip(res[mode][0], res["eager"][0]))
     dp = float((res[mode][1] - res["eager"][1]).abs().max())
     print(f"{mode}: max |loss - eager| = {dl:.3e}, max |param - eager| = {dp:.3e}")
