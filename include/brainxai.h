@@ -115,7 +115,14 @@ typedef struct {
   float dropout_p;      /* 0 disables; mask = hash(seed[0], salt, element)              */
   uint32_t salt;
   int dtype;
+  uint32_t* sync;       /* NULL, or BX_TAIL_SYNC_WORDS device words owned by THIS block instance, zero before the first call
+                         * (the library leaves them zero): the batch-statistics finalizes then ride in the kernels that
+                         * produce the partial sums (last workgroup to arrive) instead of taking launches of their own.
+                         * One block instance must not run on two streams at once with the same words. */
 } bxTailDesc;
+#define BX_TAIL_SYNC_WORDS 8192
+#define BX_TAIL_SYNC_FWD 0          /* word offsets inside sync: forward statistics | backward statistics */
+#define BX_TAIL_SYNC_BWD 4096
 size_t bx_block_tail_workspace(const bxTailDesc* d);
 /* y3: conv3 output [B,H,W,C]; x: block input [B,H,W,Cin_p]; w1x1 fp32 [C][Cin] OIHW(1x1), Cin logical;
  * bn_* fp32 [C]; num_batches_tracked int64[1]; seed uint64[1] (device, may be NULL if dropout_p==0).

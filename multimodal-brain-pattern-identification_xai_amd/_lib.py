@@ -15,13 +15,14 @@ BX_F32, BX_BF16 = 0, 1
 BX_POOL_MAX, BX_POOL_AVG = 0, 1
 BX_ALGO_AUTO, BX_ALGO_DIRECT, BX_ALGO_MFMA = 0, 1, 2
 BX_EPI_RELU = 1
+BX_TAIL_SYNC_WORDS = 8192
 
 vp, i32, i64, u32, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_float, C.c_size_t
 
 
 class TailDesc(C.Structure):
     _fields_ = [("B", i32), ("H", i32), ("W", i32), ("Cin_p", i32), ("C", i32), ("pool", i32), ("training", i32),
-                ("eps", f32), ("momentum", f32), ("dropout_p", f32), ("salt", u32), ("dtype", i32)]
+                ("eps", f32), ("momentum", f32), ("dropout_p", f32), ("salt", u32), ("dtype", i32), ("sync", vp)]
 
 
 class EegDesc(C.Structure):

@@ -200,24 +200,126 @@ __device__ __forceinline__ void sum_partials_256(const float* __restrict__ parti
     }
   }
 }
+// ---- in-launch reduction tree: the LAST workgroup to arrive finishes the sum -------------------------------------------
+// A statistics pass used to end in its own finalize launch (k_bn_finalize, k_tail_bwd_mid: ~6 us each, a dozen per training
+// step, for a few KB of arithmetic).  Here every workgroup of the producing kernel publishes its row of per-channel partial
+// sums, draws a ticket, and the workgroup that draws the last ticket of its GROUP of G rows sums that group in double; the
+// last group to finish sums the groups and returns true: its threads < Cw hold the channel totals and run the finalize.
+// Sums are taken in row order whatever the arrival order, so results do not depend on scheduling.
+//
+// Cross-XCD visibility (gfx950: eight private L2s): rows are written with agent-scope (sc1, write-through) stores, every
+// storing wave drains them (s_waitcnt vmcnt(0)) before the workgroup barrier, one lane then adds to the agent-scope counter;
+// the reducer executes ONE agent-scope acquire after its ticket and reads the rows with plain vector loads
+// (cdna_hip_programming.md, guideline 16 recipe R1 in its counter form).  Counters: ngroups + 1 words per domain, zero
+// before the first launch; the reducers put them back to zero, so graph replays and later launches need no memset.
+struct BxStatTree {
+  float* rows;          // [ndom][nrows][NV][Cw]
+  double* mid;          // [ndom][ngroups][NV][Cw]
+  unsigned* cnt;        // [ndom][ngroups + 1]
+  int nrows, G, ngroups, Cw;
+};
+static inline void bx_stat_tree_shape(int nrows, int* G, int* ngroups) {
+  int g = nrows <= 96 ? nrows : 64;
+  while ((nrows + g - 1) / g > 128) g *= 2;
+  *G = g < 1 ? 1 : g; *ngroups = nrows > 0 ? (nrows + *G - 1) / *G : 1;
+}
+#define BX_STAT_TREE_LDS(NV) ((NV) * 256 * 8 + 16)
+__device__ __forceinline__ void bx_store_agent(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void bx_store_agent(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one level of the tree: publish done by the caller; returns (workgroup-uniform) whether this workgroup drew the last ticket
+__device__ __forceinline__ bool bx_last_ticket(unsigned* cnt, unsigned expected, unsigned* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // EVERY storing wave drains its sc1 stores
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = t == expected - 1u;
+    if (last) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *flag = last ? 1u : 0u;
+  }
+  __syncthreads();
+  return *flag != 0u;
+}
+// fixed-order column sums of rows [r0, r1) of src[(r*NV + k)*Cw + c] (Src = float or double) -> tot[k] in threads c < Cw
+template <int NV, typename Src>
+__device__ __forceinline__ void bx_sum_rows(const Src* src, int r0, int r1, int Cw, double (&tot)[NV], double* sp) {
+  const int S = 256 / Cw, c = threadIdx.x % Cw, sl = threadIdx.x / Cw;
+  double acc[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+  int r = r0 + sl;
+  for (; r + 3 * S < r1; r += 4 * S) {             // 4*NV independent loads in flight; adds stay in row order
+    Src t[4][NV];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) t[u][k] = src[((size_t)(r + u * S) * NV + k) * Cw + c];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) acc[k] += (double)t[u][k];
+  }
+  for (; r < r1; r += S)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] += (double)src[((size_t)r * NV + k) * Cw + c];
+  __syncthreads();                                  // sp may still be read by a previous level
+#pragma unroll
+  for (int k = 0; k < NV; ++k) sp[k * 256 + threadIdx.x] = acc[k];
+  __syncthreads();
+  if ((int)threadIdx.x < Cw) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double s = 0.0;
+      for (int q = 0; q < S; ++q) s += sp[k * 256 + q * Cw + threadIdx.x];
+      tot[k] = s;
+    }
+  }
+}
+// Called by all 256 threads of a workgroup; threads c < Cw pass the workgroup's partial sums val[k] of channel c.
+// lds: BX_STAT_TREE_LDS(NV) bytes, 8-byte aligned, not in use by any wave of the workgroup.
+template <int NV>
+__device__ __forceinline__ bool bx_stat_tree_arrive(const BxStatTree& t, int dom, int row, const float (&val)[NV], double (&tot)[NV], char* lds) {
+  double* sp = reinterpret_cast<double*>(lds);
+  unsigned* flag = reinterpret_cast<unsigned*>(lds + NV * 256 * 8);
+  float* rows = t.rows + (size_t)dom * t.nrows * NV * t.Cw;
+  unsigned* cnt = t.cnt + (size_t)dom * (t.ngroups + 1);
+  if ((int)threadIdx.x < t.Cw) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) bx_store_agent(rows + ((size_t)row * NV + k) * t.Cw + threadIdx.x, val[k]);
+  }
+  const int grp = row / t.G, r0 = grp * t.G, r1 = r0 + t.G < t.nrows ? r0 + t.G : t.nrows;
+  if (!bx_last_ticket(cnt + grp, (unsigned)(r1 - r0), flag)) return false;
+  bx_sum_rows<NV, float>(rows, r0, r1, t.Cw, tot, sp);
+  if (t.ngroups == 1) return true;
+  double* mid = t.mid + (size_t)dom * t.ngroups * NV * t.Cw;
+  if ((int)threadIdx.x < t.Cw) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) bx_store_agent(mid + ((size_t)grp * NV + k) * t.Cw + threadIdx.x, tot[k]);
+  }
+  if (!bx_last_ticket(cnt + t.ngroups, (unsigned)t.ngroups, flag)) return false;
+  bx_sum_rows<NV, double>(mid, 0, t.ngroups, t.Cw, tot, sp);
+  return true;
+}
+
 static inline int bx_finalize_cg(int C) { return C < 16 ? C : 16; }      // channels per finalize workgroup
 static inline int bx_finalize_grid(int C) { const int cg = bx_finalize_cg(C); return (C + cg - 1) / cg; }
 
-// forward 2: statistics -> (scale, shift); running-stat update (unbiased variance, momentum).  Launch with 256 threads.
-static __global__ void k_bn_finalize(const float* __restrict__ partials, int nblk, double count, int C, int training,
-                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
-                              float* __restrict__ rvar, int64_t* __restrict__ nbt, float momentum, float eps,
-                              float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
-                              float* __restrict__ save_invstd) {
-  double tot[2] = {0.0, 0.0};
-  const int CG = C < 16 ? C : 16, c0 = blockIdx.x * CG;            // grid = bx_finalize_grid(C)
-  if (training) sum_partials_256<2>(partials, nblk, C, c0, CG, tot);
-  const int c = c0 + threadIdx.x;
-  if ((int)threadIdx.x >= CG || c >= C) return;
+// batch statistics of one channel -> (scale, shift), saved statistics, running-stat update (unbiased variance, momentum)
+__device__ __forceinline__ void bx_bn_finalize_channel(int c, bool training, double sum, double sumsq, double count, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                       int64_t* __restrict__ nbt, float momentum, float eps, float* __restrict__ scale,
+                                                       float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
   float mean, invstd;
   if (training) {
-    const double m = tot[0] / count;
-    double var = tot[1] / count - m * m;
+    const double m = sum / count;
+    double var = sumsq / count - m * m;
     if (var < 0.0) var = 0.0;
     mean = (float)m;
     invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -234,6 +336,27 @@ static __global__ void k_bn_finalize(const float* __restrict__ partials, int nbl
   shift[c] = beta[c] - mean * sc;
   save_mean[c] = mean;
   save_invstd[c] = invstd;
+}
+// what a training-mode finalize needs besides the sums (the in-launch form carries it as one kernel argument)
+struct BxBnFinalize {
+  const float* gamma; const float* beta; float* rmean; float* rvar; int64_t* nbt; float momentum, eps;
+  float* scale; float* shift; float* save_mean; float* save_invstd; double count;
+};
+__device__ __forceinline__ void bx_bn_finalize_channel(int c, double sum, double sumsq, const BxBnFinalize& f) {
+  bx_bn_finalize_channel(c, true, sum, sumsq, f.count, f.gamma, f.beta, f.rmean, f.rvar, f.nbt, f.momentum, f.eps, f.scale, f.shift, f.save_mean, f.save_invstd);
+}
+// forward 2 (separate-launch form): statistics -> (scale, shift).  Launch with 1024 threads, grid = bx_finalize_grid(C).
+static __global__ void k_bn_finalize(const float* __restrict__ partials, int nblk, double count, int C, int training,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+                              float* __restrict__ rvar, int64_t* __restrict__ nbt, float momentum, float eps,
+                              float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
+                              float* __restrict__ save_invstd) {
+  double tot[2] = {0.0, 0.0};
+  const int CG = C < 16 ? C : 16, c0 = blockIdx.x * CG;            // grid = bx_finalize_grid(C)
+  if (training) sum_partials_256<2>(partials, nblk, C, c0, CG, tot);
+  const int c = c0 + threadIdx.x;
+  if ((int)threadIdx.x >= CG || c >= C) return;
+  bx_bn_finalize_channel(c, training != 0, tot[0], tot[1], count, gamma, beta, rmean, rvar, nbt, momentum, eps, scale, shift, save_mean, save_invstd);
 }
 
 // out[i] = sum_k part[k*n + i], fixed order.  A 256-thread workgroup covers NO = 256/S outputs x S chunk slices

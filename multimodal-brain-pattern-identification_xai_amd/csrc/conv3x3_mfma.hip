@@ -155,16 +155,20 @@ __device__ __forceinline__ int lds_chunk(int c, int p) {
   return c;
 }
 
-template <int CK, int NC, int TW>
+// IMGS (round 2): a workgroup's pixel tile may span the SAME 8 x TW window of IMGS consecutive images (their halo tiles sit one
+// after the other in LDS).  The weight fragments a wave fetches per K-step then feed IMGS times as many MFMAs: the late stages
+// (8x16 and 16x32 maps, 64-channel chunks) ran 4-8 MFMAs per K-step per wave and spent 470-830 cycles on each (in-kernel stamps).
+template <int CK, int NC, int TW, int IMGS = 1>
 __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const bf16_t* __restrict__ mask_src, const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
     int H, int W, int Ci, int Co, int relu, int tiles_x, int tiles_y, uint32_t x_bytes) {
   constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CKB = CK * 2, NCH = CK / 8, KS = (9 * CK + 31) / 32;
-  constexpr int MP = TH * TW / 64;          // 16-pixel tiles per wave
+  constexpr int MP = IMGS * TH * TW / 64;   // 16-pixel tiles per wave
+  constexpr int TPI = TH * TW / 16;         // 16-pixel tiles per image
   constexpr int TPR = TW / 16;              // 16-pixel tiles per tile row
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int bid = blockIdx.x;
-  const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, b = bid / (tiles_x * tiles_y);
+  const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, b = (bid / (tiles_x * tiles_y)) * IMGS;      // first image of the tile
   const int y0 = ty * TH, x0 = tx * TW, co_base = blockIdx.y * (NC * 16);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
 
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   const int nchunk = Ci / CK;
   // staging: every thread issues ALL of its 16-byte global loads before the first LDS write (a rolled
   // load->wait->write loop serialises one HBM round trip per iteration)
-  constexpr int NU = HH * HWID * NCH, NR = (NU + 255) / 256;
+  constexpr int NU = IMGS * HH * HWID * NCH, NR = (NU + 255) / 256;
   // halo loads through a raw buffer resource (out-of-image lanes point past the end and read zeros): no divergent
   // branches, 32-bit offsets, per-thread invariants hoisted out of the chunk loop (see k_conv_mfma_p)
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
@@ -186,9 +190,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   for (int k = 0; k < NR; ++k) {
     const int u = threadIdx.x + k * 256;
     const int p = u / NCH, c = u % NCH;
-    const int iy = y0 + p / HWID - 1, ix = x0 + p % HWID - 1;
+    const int img = p / (HH * HWID), pl = p - img * (HH * HWID);
+    const int iy = y0 + pl / HWID - 1, ix = x0 + pl % HWID - 1;
     const bool ok = u < NU && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-    hoff[k] = ok ? (uint32_t)((((b * H + iy) * W + ix) * Ci + c * 8) * 2) : 0x80000000u;
+    hoff[k] = ok ? (uint32_t)(((((b + img) * H + iy) * W + ix) * Ci + c * 8) * 2) : 0x80000000u;
   }
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     uint4 rv[NR];
@@ -230,8 +235,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
       const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
       for (int i = 0; i < MP; ++i) {
-        const int t = wave * MP + i;
-        const int p = (t / TPR + dy) * HWID + (t % TPR) * 16 + li + dx;
+        const int t = wave * MP + i, img = t / TPI, tl = t % TPI;
+        const int p = (img * HH + tl / TPR + dy) * HWID + (tl % TPR) * 16 + li + dx;
         bf16x8 bv = *reinterpret_cast<const bf16x8*>(lds + p * CKB + 16 * lds_chunk<CK>(c, p));
         if (!valid) bv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   }
   // epilogue: lane = (pixel li of tile t, output channels co_base + n*16 + 4g .. +3).  y / mask / addend share one shape:
   // 32-bit byte offsets through buffer resources, out-of-image lanes point past the end (loads read 0, stores are dropped)
-  const uint32_t y_bytes = (uint32_t)((size_t)gridDim.x / (tiles_x * tiles_y) * H * W * Co * 2);
+  const uint32_t y_bytes = (uint32_t)((size_t)gridDim.x / (tiles_x * tiles_y) * IMGS * H * W * Co * 2);
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src ? mask_src : y), 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend : y), 0, y_bytes, 0x00020000);
@@ -258,10 +263,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   u32x2 mk[MP][NC], ad[MP][NC];
 #pragma unroll
   for (int i = 0; i < MP; ++i) {
-    const int t = wave * MP + i;
-    const int oy = y0 + t / TPR, ox = x0 + (t % TPR) * 16 + li;
+    const int t = wave * MP + i, img = t / TPI, tl = t % TPI;
+    const int oy = y0 + tl / TPR, ox = x0 + (tl % TPR) * 16 + li;
     const bool inb = oy < H && ox < W;
-    const uint32_t orow = lane_off + (uint32_t)((((t / TPR) * W + (t % TPR) * 16) * Co) * 2);
+    const uint32_t orow = lane_off + (uint32_t)((((img * H + tl / TPR) * W + (tl % TPR) * 16) * Co) * 2);
 #pragma unroll
     for (int n = 0; n < NC; ++n) offs[i][n] = inb ? orow + (uint32_t)(n * 32) : 0x80000000u;
   }
@@ -600,6 +605,27 @@ static int launch_conv(const void* x, const void* wp, const float* bias, const v
                          (const bf16_t*)wp, bias, (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Co, relu, tiles_x, tiles_y, ntiles,
                          (uint32_t)((size_t)B * H * W * CK * 2));
       BX_CHECK_LAUNCH("bx_conv3x3(mfma persistent)");
+      return BX_OK;
+    }
+  }
+  // two-image tiles where one 8 x 16 tile IS the image and the layer is wide (stage 5, 256 output channels): measured at B=64
+  // 21.0 -> 15.6 us (256->256 forward), 21.7 -> 16.5 (its dgrad), 11.9 -> 9.9 (128->256 forward); every other shape got slower
+  // with IMGS = 2 or 4 (fewer, longer workgroups), see DESIGN section 6.  BX_CONV_IMGS=1|2 overrides for sweeps.
+  if (CK == 64) {
+    static const int imgs_env = getenv("BX_CONV_IMGS") ? atoi(getenv("BX_CONV_IMGS")) : 0;
+    const bool two = imgs_env ? imgs_env == 2 : (tiles_x * tiles_y == 1 && Co >= 256);
+    if (two && B % 2 == 0) {
+      const size_t lds2 = lds * 2;
+      static bool attr_done = false;
+      if (lds2 > 64 * 1024 && !attr_done) {
+        if (hipFuncSetAttribute((const void*)k_conv_mfma<CK, NC, TW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+          BX_FAIL(BX_EHIP, "bx_conv3x3(mfma): cannot reserve %zu bytes of LDS", lds2);
+        attr_done = true;
+      }
+      dim3 grid2((unsigned)(tiles_x * tiles_y * (B / 2)), (unsigned)(Co / (16 * NC)));
+      hipLaunchKernelGGL((k_conv_mfma<CK, NC, TW, 2>), grid2, dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)mask,
+                         (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2));
+      BX_CHECK_LAUNCH("bx_conv3x3(mfma, two-image tiles)");
       return BX_OK;
     }
   }

@@ -9,6 +9,7 @@
 // the partials in double precision.  No atomics: results are run-to-run deterministic.
 #include "bx_common.h"
 
+#define TAIL_MAX_GROUPS 128         // BxStatTree: bx_stat_tree_shape never makes more groups
 #define TAIL_MAX_BLOCKS 2048        // layout bound of the partial buffers; the launch cap is tail_block_cap()
 
 struct TailGeom {
@@ -73,10 +74,10 @@ __device__ __forceinline__ void block_channel_reduce(float (*vals)[8], float* ld
 // ------------------------------------------------------------------------------------------------
 // forward 1: pooled = pool2x2(y3) (stored, needed again by backward) + per-workgroup (sum, sumsq)
 template <typename T>
-__global__ __launch_bounds__(256) void k_pool_stats(const T* __restrict__ y3, T* __restrict__ pooled, float* __restrict__ partials,
+__global__ __launch_bounds__(256) void k_pool_stats(const T* __restrict__ y3, T* __restrict__ pooled, float* partials,
                                                      TailGeom g, int pool, int want_stats, const float* __restrict__ w1x1, int Cin,
-                                                     float* __restrict__ wT) {
-  __shared__ float lds[2048];
+                                                     float* __restrict__ wT, BxStatTree tree, BxBnFinalize fin) {
+  __shared__ __attribute__((aligned(16))) float lds[2048];
   {                                                     // wT[ci][c] = W1x1[c][ci] (zero rows for padded inputs): read by k_tail_apply
     const int nw = g.Cin_p * g.C, per = (nw + (int)gridDim.x - 1) / (int)gridDim.x;     // each workgroup transposes a slice
     const int lo = (int)blockIdx.x * per, cnt = nw - lo < per ? nw - lo : per;
@@ -127,6 +128,13 @@ __global__ __launch_bounds__(256) void k_pool_stats(const T* __restrict__ y3, T*
   if (!want_stats) return;
   float red[2];
   block_channel_reduce<2>(acc, lds, g.C, g.ncg, g.slots, red);
+  if (tree.cnt) {                                       // the last workgroup to arrive finalizes (no k_bn_finalize launch)
+    double tot[2];
+    __syncthreads();                                    // block_channel_reduce's LDS reads are done
+    if (bx_stat_tree_arrive<2>(tree, 0, blockIdx.x, red, tot, reinterpret_cast<char*>(lds)) && (int)threadIdx.x < g.C)
+      bx_bn_finalize_channel(threadIdx.x, tot[0], tot[1], fin);
+    return;
+  }
   if ((int)threadIdx.x < g.C) {
     partials[((size_t)blockIdx.x * 2 + 0) * g.C + threadIdx.x] = red[0];
     partials[((size_t)blockIdx.x * 2 + 1) * g.C + threadIdx.x] = red[1];
@@ -254,11 +262,12 @@ extern "C" size_t bx_block_tail_workspace(const bxTailDesc* d) {
   TailGeom g;
   if (!d || make_geom(d, &g)) return 0;
   const size_t Ho = d->H / 2, Wo = d->W / 2;
-  size_t fwd = ((size_t)TAIL_MAX_BLOCKS * 2 + 2) * d->C * sizeof(float) + (size_t)d->Cin_p * d->C * sizeof(float);
+  size_t fwd = ((size_t)TAIL_MAX_BLOCKS * 2 + 2) * d->C * sizeof(float) + (size_t)d->Cin_p * d->C * sizeof(float)
+             + (size_t)TAIL_MAX_GROUPS * 2 * d->C * sizeof(double);                                  // reduction-tree group sums
   size_t bwd = ((size_t)TAIL_MAX_BLOCKS * 3 + 3) * d->C * sizeof(float)                 // partials + coefficients
              + bx_align_up((size_t)d->B * Ho * Wo * d->Cin_p * sizeof(float), 256)       // dXs (half-res, fp32)
              + (size_t)2048 * 256 * sizeof(float) + (size_t)65 * d->C * d->Cin_p * sizeof(float);   // conv1x1 weight-grad partials (+1 slab for compaction)
-  return bx_align_up(fwd > bwd ? fwd : bwd, 256);
+  return bx_align_up(fwd > bwd ? fwd : bwd, 256) + (size_t)TAIL_MAX_GROUPS * 3 * d->C * sizeof(double);    // + backward reduction-tree group sums
 }
 
 extern "C" int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void* x, const float* w1x1, int Cin,
@@ -286,11 +295,23 @@ extern "C" int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void
   float* shift = scale + g.C;
   float* wT = shift + g.C;
   const float p = d->training ? d->dropout_p : 0.f;
+  // with d->sync the statistics finalize rides in the pooling kernel (last workgroup to arrive, see BxStatTree)
+  const bool in_launch = d->training && d->sync && g.C <= 256 && 256 % g.C == 0;
+  BxStatTree tree = {};
+  BxBnFinalize fin = {};
+  if (in_launch) {
+    tree.rows = partials; tree.cnt = d->sync + BX_TAIL_SYNC_FWD; tree.nrows = nblk; tree.Cw = g.C;
+    bx_stat_tree_shape(nblk, &tree.G, &tree.ngroups);
+    tree.mid = (double*)(wT + (size_t)g.Cin_p * g.C);                     // ngroups x 2 x C doubles (workspace formula)
+    BX_REQUIRE(tree.ngroups + 1 <= BX_TAIL_SYNC_BWD - BX_TAIL_SYNC_FWD, "bx_block_tail_fwd: %d reduction groups exceed the sync block", tree.ngroups);
+    fin = BxBnFinalize{bn_weight, bn_bias, running_mean, running_var, num_batches_tracked, d->momentum, d->eps, scale, shift, save_mean, save_invstd,
+                       (double)g.npool};
+  }
   BX_DISPATCH_DTYPE(d->dtype, T,
     hipLaunchKernelGGL((k_pool_stats<T>), dim3(nblk), dim3(256), 0, s, (const T*)y3, (T*)pooled, partials, g, d->pool, d->training,
-                       w1x1, Cin, wT));
+                       w1x1, Cin, wT, tree, fin));
   BX_CHECK_LAUNCH("bx_block_tail_fwd(pool)");
-  if (d->training) {
+  if (d->training && !in_launch) {
     hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.C)), dim3(1024), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight, bn_bias,
                        running_mean, running_var, num_batches_tracked, d->momentum, d->eps, scale, shift, save_mean, save_invstd);
     BX_CHECK_LAUNCH("bx_block_tail_fwd(finalize)");
@@ -307,11 +328,21 @@ extern "C" int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void
 // ================================================================================================
 // backward
 // reduce: per channel  s1 = sum dD,  s2 = sum dD * xhat,  s3 = sum dOut   (dD = dOut * dropout multiplier)
+// what the BatchNorm-backward finalize needs besides the three sums
+struct TailBwdFin { const float* gamma; const float* invstd; float* coef; float* dgamma; float* dbeta; float* db1x1; double count; int training; };
+__device__ __forceinline__ void tail_bwd_finalize_channel(int c, int C, const double (&s)[3], const TailBwdFin& f) {
+  if (f.dbeta) f.dbeta[c] = (float)s[0];
+  if (f.dgamma) f.dgamma[c] = (float)s[1];
+  if (f.db1x1) f.db1x1[c] = (float)s[2];
+  f.coef[c] = f.gamma[c] * f.invstd[c];
+  f.coef[C + c] = f.training ? (float)(s[0] / f.count) : 0.f;
+  f.coef[2 * C + c] = f.training ? (float)(s[1] / f.count) : 0.f;
+}
 template <typename T>
 __device__ __forceinline__ void tail_bwd_reduce_body(const T* __restrict__ dout, const T* __restrict__ pooled,
     const float* __restrict__ mean, const float* __restrict__ invstd, const uint64_t* __restrict__ seed, float dropout_p,
-    uint32_t salt, float* __restrict__ partials, const TailGeom& g, int bid, int nblocks) {
-  __shared__ float lds[2048];
+    uint32_t salt, float* partials, const TailGeom& g, int bid, int nblocks, const BxStatTree& tree, const TailBwdFin& fin) {
+  __shared__ __attribute__((aligned(16))) float lds[2048];
   const int cg = threadIdx.x % g.ncg, slot = threadIdx.x / g.ncg;
   const uint64_t sd = (dropout_p > 0.f && seed) ? seed[0] : 0;
   const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
@@ -344,6 +375,13 @@ __device__ __forceinline__ void tail_bwd_reduce_body(const T* __restrict__ dout,
   }
   float red[3];
   block_channel_reduce<3>(acc, lds, g.C, g.ncg, g.slots, red);
+  if (tree.cnt) {                                       // the last reduction workgroup to arrive finalizes (no mid launch)
+    double tot[3];
+    __syncthreads();
+    if (bx_stat_tree_arrive<3>(tree, 0, bid, red, tot, reinterpret_cast<char*>(lds)) && (int)threadIdx.x < g.C)
+      tail_bwd_finalize_channel(threadIdx.x, g.C, tot, fin);
+    return;
+  }
   if ((int)threadIdx.x < g.C)
 #pragma unroll
     for (int k = 0; k < 3; ++k) partials[((size_t)bid * 3 + k) * g.C + threadIdx.x] = red[k];
@@ -357,19 +395,48 @@ __device__ __forceinline__ void tail_bwd_finalize_body(const float* __restrict__
   sum_partials_256<3>(partials, nblk, C, c0, CG, s);
   const int c = c0 + threadIdx.x;
   if ((int)threadIdx.x >= CG || c >= C) return;
-  if (dbeta) dbeta[c] = (float)s[0];
-  if (dgamma) dgamma[c] = (float)s[1];
-  if (db1x1) db1x1[c] = (float)s[2];
-  coef[c] = gamma[c] * invstd[c];
-  coef[C + c] = training ? (float)(s[0] / count) : 0.f;
-  coef[2 * C + c] = training ? (float)(s[1] / count) : 0.f;
+  tail_bwd_finalize_channel(c, C, s, TailBwdFin{gamma, invstd, coef, dgamma, dbeta, db1x1, count, training});
 }
+
+// fixed-order sum of the 1x1 weight-gradient partials: one 256-thread group covers NO = 256/S outputs x S chunk slices;
+// (c, ci) of the padded layout goes to dw[c][ci < Cin].  Runs as a role of k_tail_bwd_mid (four groups per workgroup) or, when
+// the finalize rides in the front kernel, of k_tail_bwd_apply (one group per extra workgroup) -- the sums are the same.
+__device__ __forceinline__ void w1x1_sum_group(const float* __restrict__ wpart, float* __restrict__ dw, int nchunk, int C, int Cin, int Cin_p,
+                                               int S, int group, int t, float* sm) {
+  const int n = C * Cin_p, NO = 256 / S;
+  const int o = t % NO, sl = t / NO;
+  const int i = group * NO + o;
+  float s = 0.f;
+  if (i < n) {
+    int k = sl;
+    for (; k + 3 * S < nchunk; k += 4 * S) {
+      const float v0 = wpart[(size_t)k * n + i], v1 = wpart[(size_t)(k + S) * n + i];
+      const float v2 = wpart[(size_t)(k + 2 * S) * n + i], v3 = wpart[(size_t)(k + 3 * S) * n + i];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; k < nchunk; k += S) s += wpart[(size_t)k * n + i];
+  }
+  sm[t] = s;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    float r = sm[o];
+    for (int k = 1; k < S; ++k) r += sm[k * NO + o];
+    const int c = i / Cin_p, ci = i - c * Cin_p;
+    if (ci < Cin) dw[(size_t)c * Cin + ci] = r;
+  }
+}
+struct TailWsum { const float* wpart; float* dw; int nchunk, Cin, S, n_apply; };     // n_apply = workgroups of the apply role (0: no sum role)
 
 // apply: dP = a*(dD - k1 - xhat*k2); route through the 2x2 pool and conv3's ReLU to full resolution
 template <typename T>
 __global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ dout, const T* __restrict__ pooled, const T* __restrict__ y3,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
-    const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, int pool, T* __restrict__ dz3, TailGeom g) {
+    const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, int pool, T* __restrict__ dz3, TailGeom g, TailWsum ws) {
+  if (ws.n_apply && (int)blockIdx.x >= ws.n_apply) {            // extra workgroups: the 1x1 weight-gradient sum rides here
+    __shared__ float sm[256];
+    w1x1_sum_group(ws.wpart, ws.dw, ws.nchunk, g.C, ws.Cin, g.Cin_p, ws.S, (int)blockIdx.x - ws.n_apply, threadIdx.x, sm);
+    return;
+  }
   const int cg = threadIdx.x % g.ncg, slot = threadIdx.x / g.ncg;
   const uint64_t sd = (dropout_p > 0.f && seed) ? seed[0] : 0;
   const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
@@ -380,7 +447,8 @@ __global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ do
     mu[j] = mean[c]; is[j] = invstd[c]; a[j] = coef[c]; k1[j] = coef[g.C + c]; k2[j] = coef[2 * g.C + c];
   }
   const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (long long pp = (long long)blockIdx.x * g.slots + slot; pp < g.npool; pp += (long long)gridDim.x * g.slots) {
+  const long long napply = ws.n_apply ? ws.n_apply : (int)gridDim.x;
+  for (long long pp = (long long)blockIdx.x * g.slots + slot; pp < g.npool; pp += napply * g.slots) {
     int ox, oy, b;
     px_decode(pp, g.Wo, g.Ho, ox, oy, b);
     float go[8], pv[8], dp[8];
@@ -766,11 +834,13 @@ struct TailFrontArgs {
   float dropout_p;
   uint32_t salt;
   int n_red, n_w, wg_x, wg_y, ppc, Cin;
+  BxStatTree tree;          // tree.cnt != NULL: the reduction role finalizes in-launch
+  TailBwdFin fin;
 };
 template <typename T, int CIV, int MF>      // MF = Cin_p of the MFMA input-gradient role, 0 = VALU role with CIV channels per thread
 __global__ __launch_bounds__(256) void k_tail_bwd_front(TailFrontArgs<T> a, TailGeom g) {
   int bid = blockIdx.x;
-  if (bid < a.n_red) { tail_bwd_reduce_body<T>(a.dout, a.pooled, a.mean, a.invstd, a.seed, a.dropout_p, a.salt, a.partials, g, bid, a.n_red); return; }
+  if (bid < a.n_red) { tail_bwd_reduce_body<T>(a.dout, a.pooled, a.mean, a.invstd, a.seed, a.dropout_p, a.salt, a.partials, g, bid, a.n_red, a.tree, a.fin); return; }
   bid -= a.n_red;
   if (bid < a.n_w) {
     const int bx = bid % a.wg_x, r = bid / a.wg_x;
@@ -792,28 +862,7 @@ __global__ __launch_bounds__(1024) void k_tail_bwd_mid(const float* __restrict__
     return;
   }
   __shared__ float sm[1024];
-  const int n = C * Cin_p, NO = 256 / S;
-  const int grp = threadIdx.x >> 8, t = threadIdx.x & 255;
-  const int o = t % NO, sl = t / NO;
-  const int i = (((int)blockIdx.x - n_fin) * 4 + grp) * NO + o;
-  float s = 0.f;
-  if (i < n) {
-    int k = sl;
-    for (; k + 3 * S < nchunk; k += 4 * S) {
-      const float v0 = wpart[(size_t)k * n + i], v1 = wpart[(size_t)(k + S) * n + i];
-      const float v2 = wpart[(size_t)(k + 2 * S) * n + i], v3 = wpart[(size_t)(k + 3 * S) * n + i];
-      s += v0; s += v1; s += v2; s += v3;
-    }
-    for (; k < nchunk; k += S) s += wpart[(size_t)k * n + i];
-  }
-  sm[threadIdx.x] = s;
-  __syncthreads();
-  if (sl == 0 && i < n) {
-    float r = sm[grp * 256 + o];
-    for (int k = 1; k < S; ++k) r += sm[grp * 256 + k * NO + o];
-    const int c = i / Cin_p, ci = i - c * Cin_p;
-    if (ci < Cin) dw[(size_t)c * Cin + ci] = r;
-  }
+  w1x1_sum_group(wpart, dw, nchunk, C, Cin, Cin_p, S, ((int)blockIdx.x - n_fin) * 4 + (threadIdx.x >> 8), threadIdx.x & 255, sm + (threadIdx.x >> 8) * 256);
 }
 
 extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const void* y3, const void* x, const void* pooled,
@@ -862,11 +911,22 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
   const int n_dxs = !dx_skip ? 0 : mf ? bx_ceil_div(g.npool, skip_mfma_pixels(mf)) : bx_ceil_div(g.npool * (g.Cin_p / (narrow ? 4 : 8)), 256);
   const int n_w = nchunk * wg_y * wg_z;
   const size_t front_lds = (dx_skip && !mf) ? (size_t)64 * g.Cin_p * sizeof(float) : 0;
+  const bool in_launch = d->sync && 256 % g.C == 0;
+  BxStatTree tree = {};
+  TailBwdFin fin = {};
+  if (in_launch) {
+    tree.rows = partials; tree.cnt = d->sync + BX_TAIL_SYNC_BWD; tree.nrows = nblk; tree.Cw = g.C;
+    bx_stat_tree_shape(nblk, &tree.G, &tree.ngroups);
+    tree.mid = (double*)((char*)workspace + bx_align_up(bx_block_tail_workspace(d) - (size_t)TAIL_MAX_GROUPS * 3 * g.C * sizeof(double), 8));
+    BX_REQUIRE(tree.ngroups + 1 <= BX_TAIL_SYNC_WORDS - BX_TAIL_SYNC_BWD, "bx_block_tail_bwd: %d reduction groups exceed the sync block", tree.ngroups);
+    fin = TailBwdFin{bn_weight, save_invstd, coef, d_bn_weight, d_bn_bias, d_b1x1, (double)g.npool, d->training};
+  }
   BX_DISPATCH_DTYPE(d->dtype, T, {
     TailFrontArgs<T> a;
     a.dout = (const T*)dout; a.pooled = (const T*)pooled; a.x = (const T*)x; a.mean = save_mean; a.invstd = save_invstd; a.w1x1 = w1x1;
     a.seed = seed; a.partials = partials; a.wpart = wpart; a.dxs = dxs; a.dx_even = even ? (T*)dx_skip : (T*)nullptr;
     a.dropout_p = p; a.salt = d->salt; a.n_red = nblk; a.n_w = n_w; a.wg_x = nchunk > 0 ? nchunk : 1; a.wg_y = wg_y; a.ppc = ppc; a.Cin = Cin;
+    a.tree = tree; a.fin = fin;
     const dim3 grid(nblk + n_w + n_dxs);
     if (mf == 16) hipLaunchKernelGGL((k_tail_bwd_front<T, 8, 16>), grid, dim3(256), front_lds, s, a, g);
     else if (mf == 32) hipLaunchKernelGGL((k_tail_bwd_front<T, 8, 32>), grid, dim3(256), front_lds, s, a, g);
@@ -876,18 +936,25 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
     else hipLaunchKernelGGL((k_tail_bwd_front<T, 8, 0>), grid, dim3(256), front_lds, s, a, g);
   });
   BX_CHECK_LAUNCH("bx_block_tail_bwd(front)");
-  // ---- mid: finalize | weight-gradient sum
-  {
-    const int n_fin = bx_finalize_grid(g.C), n = g.C * g.Cin_p;
-    const int S = d_w1x1 ? bx_partial_slices(n, nchunk) : 4;
-    const int n_sum = d_w1x1 ? bx_ceil_div(n, 4 * (256 / S)) : 0;
+  // ---- mid: finalize | weight-gradient sum.  In-launch form: the finalize was done by the front kernel's last reduction workgroup
+  // and the sum rides as extra workgroups of the apply kernel (it only feeds the optimizer).
+  const int n_sum_elems = g.C * g.Cin_p;
+  const int S = d_w1x1 ? bx_partial_slices(n_sum_elems, nchunk) : 4;
+  TailWsum wsum = {};
+  int n_sum256 = 0;
+  if (!in_launch) {
+    const int n_fin = bx_finalize_grid(g.C);
+    const int n_sum = d_w1x1 ? bx_ceil_div(n_sum_elems, 4 * (256 / S)) : 0;
     hipLaunchKernelGGL(k_tail_bwd_mid, dim3(n_fin + n_sum), dim3(1024), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight,
                        save_invstd, coef, d_bn_weight, d_bn_bias, d_b1x1, n_fin, wpart, d_w1x1, nchunk, Cin, g.Cin_p, S);
+    BX_CHECK_LAUNCH("bx_block_tail_bwd(mid)");
+  } else if (d_w1x1) {
+    n_sum256 = bx_ceil_div(n_sum_elems, 256 / S);
+    wsum = TailWsum{wpart, d_w1x1, nchunk, Cin, S, tail_blocks_all(g)};
   }
-  BX_CHECK_LAUNCH("bx_block_tail_bwd(mid)");
   BX_DISPATCH_DTYPE(d->dtype, T,
-    hipLaunchKernelGGL((k_tail_bwd_apply<T>), dim3(tail_blocks_all(g)), dim3(256), 0, s, (const T*)dout, (const T*)pooled, (const T*)y3, save_mean,
-                       save_invstd, coef, seed, p, d->salt, d->pool, (T*)dz3, g));
+    hipLaunchKernelGGL((k_tail_bwd_apply<T>), dim3(tail_blocks_all(g) + n_sum256), dim3(256), 0, s, (const T*)dout, (const T*)pooled, (const T*)y3,
+                       save_mean, save_invstd, coef, seed, p, d->salt, d->pool, (T*)dz3, g, wsum));
   BX_CHECK_LAUNCH("bx_block_tail_bwd(apply)");
   if (dx_skip) {
     if (!even) {

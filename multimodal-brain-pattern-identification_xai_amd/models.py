@@ -51,6 +51,15 @@ class Block(nn.Module):
         self._keep = None         # set by ops.keep_block_activations (parity tooling)
         self._prepacked, self._pack_base = None, 0      # set per forward by Spectrogram_Model (one pack launch for all stages)
         self._seed = None                               # idem: one dropout seed launch for all stages
+        self._sync = None                               # device words of the in-launch statistics finalizes (bxTailDesc.sync)
+
+    def _sync_words(self, device):
+        """zeroed counter words owned by this block: the library's kernels count arrivals in them and leave them zero"""
+        if not ops.TAIL_IN_LAUNCH:
+            return None
+        if self._sync is None or self._sync.device != device:
+            self._sync = torch.zeros(ops.L.BX_TAIL_SYNC_WORDS, dtype=torch.int32, device=device)
+        return self._sync
 
     def forward(self, x):
         dt = self.compute_dtype
@@ -66,7 +75,7 @@ class Block(nn.Module):
         cfg = ops.block_cfg(pool=self.pool_type, training=self.training, dropout_p=self.dropout.p if self.training else 0.0,
                             eps=bn.eps, momentum=0.1 if bn.momentum is None else bn.momentum, salt=self.salt,
                             preact=self._preact, capture=self._capture, prepacked=self._prepacked, pack_base=self._pack_base, seed=self._seed,
-                            keep=self._keep)
+                            keep=self._keep, sync=self._sync_words(xi.device))
         out = ops.BlockFn.apply(xi, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.conv3.weight,
                                 self.conv3.bias, bn.weight, bn.bias, self.conv1x1.weight, self.conv1x1.bias,
                                 bn.running_mean, bn.running_var, bn.num_batches_tracked, cfg)

@@ -332,6 +332,8 @@ def _conv(x, packed, bias, mask_src, addend, relu: bool, dtype):
 # returned gradient right away, so nothing may be pending then).  Per device: the pending descriptor, two partial buffers
 # used alternately (the pending partials must outlive the next launch) and the tensors to keep alive meanwhile.
 WGRAD_CHAIN = _os.environ.get("BX_WGRAD_CHAIN", "1") == "1"
+# batch-statistics finalizes inside the kernels that produce the partial sums (bxTailDesc.sync); 0 = separate finalize launches
+TAIL_IN_LAUNCH = _os.environ.get("BX_TAIL_IN_LAUNCH", "1") == "1"
 _WG_CHAIN = {}
 
 
@@ -394,7 +396,7 @@ def _wgrad(x, dz, w: torch.Tensor, b: torch.Tensor, chain: bool = False):
 def _tail_desc(x, y3, cfg) -> L.TailDesc:
     B, H, W, Cc = y3.shape
     return L.TailDesc(B, H, W, x.shape[3], Cc, L.BX_POOL_MAX if cfg.pool == "max" else L.BX_POOL_AVG, 1 if cfg.training else 0,
-                      cfg.eps, cfg.momentum, float(cfg.dropout_p), cfg.salt, bx_dtype(y3.dtype))
+                      cfg.eps, cfg.momentum, float(cfg.dropout_p), cfg.salt, bx_dtype(y3.dtype), _p(cfg.sync))
 
 
 class BlockFn(torch.autograd.Function):
@@ -792,7 +794,7 @@ class AttentionFn(torch.autograd.Function):
 
 def block_cfg(**kw) -> SimpleNamespace:
     base = dict(pool="max", training=False, dropout_p=0.0, eps=1e-5, momentum=0.1, salt=0, preact=0, capture=None,
-                prepacked=None, pack_base=0, seed=None, keep=None)
+                prepacked=None, pack_base=0, seed=None, keep=None, sync=None)
     base.update(kw)
     return SimpleNamespace(**base)
 

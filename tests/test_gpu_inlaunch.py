@@ -1,0 +1,59 @@
+"""GPU: the in-launch statistics finalizes (bxTailDesc.sync: last workgroup to arrive sums the partial rows and finalizes)
+against the separate-launch form of the same kernels.  Both sum float partial rows in double in row order; only the grouping
+of the double sums differs, so results agree to double rounding before the final float conversion."""
+import pytest
+import torch
+
+import brainxai
+from brainxai import ops
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+# (cin, cout, batch, H, W): 512 partial rows -> two-level tree; 128 rows -> two groups; 16 rows -> one level
+CASES = [(4, 16, 16, 128, 128), (16, 32, 8, 32, 64), (128, 256, 4, 8, 16), (64, 128, 6, 16, 32)]
+
+
+def _run(in_launch, dtype, case, pool):
+    cin, cout, batch, h, w = case
+    old = ops.TAIL_IN_LAUNCH
+    ops.TAIL_IN_LAUNCH = in_launch
+    try:
+        torch.manual_seed(3)
+        blk = brainxai.Block(cin, cout, pool, (2, 2), dropout_p=0.25).to(DEV).train()
+        blk.compute_dtype = dtype
+        ops.manual_seed(77, DEV)
+        outs = []
+        for it in range(3):                      # three calls through the same counter words: they must come back to zero
+            x = torch.randn(batch, cin, h, w, generator=torch.Generator().manual_seed(5 + it)).to(DEV).requires_grad_(True)
+            blk.zero_grad()
+            out = blk(x)
+            (out.float() * torch.linspace(-1, 1, out.numel(), device=DEV).view_as(out)).sum().backward()
+            outs.append([out.detach().float().cpu(), x.grad.cpu()] + [p.grad.detach().clone().cpu() for p in blk.parameters()]
+                        + [blk.bn.running_mean.clone().cpu(), blk.bn.running_var.clone().cpu(), blk.bn.num_batches_tracked.clone().cpu()])
+        torch.cuda.synchronize()
+        if in_launch:
+            assert blk._sync is not None and int(blk._sync.abs().sum()) == 0, "counter words must be left at zero"
+        else:
+            assert blk._sync is None
+        return outs
+    finally:
+        ops.TAIL_IN_LAUNCH = old
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_in_launch_finalize_equals_separate_launches(case, dtype):
+    pool = "max" if case[0] % 3 else "avg"
+    a = _run(True, dtype, case, pool)
+    b = _run(False, dtype, case, pool)
+    for it, (ra, rb) in enumerate(zip(a, b)):
+        for k, (ta, tb) in enumerate(zip(ra, rb)):
+            ta, tb = ta.double(), tb.double()
+            scale = float(tb.abs().max()) + 1e-30
+            err = float((ta - tb).abs().max()) / scale
+            # statistics differ by double-rounding only; in bf16 a one-ulp change of (scale, shift) may move a stored bf16 value
+            tol = 1e-6 if dtype == torch.float32 else 2e-2
+            assert err <= tol, (it, k, err)
+            if dtype == torch.bfloat16:
+                assert float((ta != tb).double().mean()) < 1e-3, (it, k)

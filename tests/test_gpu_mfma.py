@@ -46,6 +46,32 @@ def test_conv_mfma_forward(cin, cout, h, w):
     assert frac_equal > 0.98, frac_equal
 
 
+@pytest.mark.parametrize("cin,cout,batch", [(128, 256, 4), (256, 256, 6), (256, 256, 5)])
+def test_conv_mfma_two_image_tiles(cin, cout, batch):
+    """stage-5 shapes (the 8 x 16 tile is the whole image, 256 output channels): even batches run two images per workgroup,
+    odd batches the one-image kernel; both must equal the direct kernel and the fp32 reference, image by image"""
+    torch.manual_seed(cin + cout + batch)
+    h, w = 8, 16
+    x = _bf(torch.randn(batch, cin, h, w))
+    wt = _bf(torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5))
+    b = torch.randn(cout)
+    ymask, add = _bf(torch.randn(batch, cout, h, w)), _bf(torch.randn(batch, cout, h, w))
+    want = F.conv2d(x, wt, b, padding=1) * (ymask > 0) + add
+    xn, mn, an = (ops.to_nhwc(t.to(DEV), torch.bfloat16) for t in (x, ymask, add))
+    packed = ops._pack(wt.to(DEV), False)
+    lib = L.load()
+    outs = {}
+    for name, algo in (("direct", L.BX_ALGO_DIRECT), ("mfma", L.BX_ALGO_MFMA)):
+        y = torch.empty(batch, h, w, cout, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.bx_conv3x3(xn.data_ptr(), packed[0].data_ptr(), packed[1].data_ptr(), b.to(DEV).data_ptr(), mn.data_ptr(), an.data_ptr(),
+                               y.data_ptr(), batch, h, w, cin, cout, L.BX_BF16, 0, algo, torch.cuda.current_stream().cuda_stream), name)
+        outs[name] = ops.to_nchw_f32(y, cout).cpu()
+    torch.cuda.synchronize()
+    for i in range(batch):
+        assert rel_err(outs["mfma"][i], want[i]) < 8e-3, i
+        assert rel_err(outs["mfma"][i], outs["direct"][i]) < 8e-3, i
+
+
 @pytest.mark.parametrize("cin,cout,h,w", [(16, 16, 12, 20), (32, 16, 9, 33), (64, 32, 8, 16), (128, 64, 6, 7), (256, 128, 4, 8)])
 def test_conv_mfma_data_gradient_epilogue(cin, cout, h, w):
     """flip/transpose pack + ReLU-mask + addend epilogue: dX = conv(dZ, W^T flipped) * (Y > 0) + A"""
