@@ -116,8 +116,8 @@ typedef struct {
   uint32_t salt;
   int dtype;
   uint32_t* sync;       /* NULL, or BX_TAIL_SYNC_WORDS device words owned by THIS block instance, zero before the first call
-                         * (the library leaves them zero): the batch-statistics finalizes then ride in the kernels that
-                         * produce the partial sums (last workgroup to arrive) instead of taking launches of their own.
+                         * (the library leaves them zero): where bx_set_tree_max_rows allows it, the batch-statistics
+                         * finalizes ride in the kernels that produce the partial sums (last workgroup to arrive).
                          * One block instance must not run on two streams at once with the same words. */
 } bxTailDesc;
 #define BX_TAIL_SYNC_WORDS 8192
@@ -133,6 +133,22 @@ int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void* x, const 
                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
                       const uint64_t* seed, void* pooled, void* out, float* save_mean, float* save_invstd,
                       void* workspace, size_t workspace_bytes, bxStream stream);
+/* Policy of the in-launch finalizes (bxTailDesc.sync): a statistics pass with at most `rows` rows of partial sums is finished by
+ * its last workgroup, a larger one by a separate finalize launch whose workgroups split the channels.  Default 0 = always the
+ * separate launch (or the environment variable BX_TREE_MAX_ROWS at first use): measured on MI355X the in-launch form costs
+ * every workgroup a drained store + ticket round trip and was 4-10 us SLOWER per pass than the ~6.5 us launch it removes
+ * (DESIGN section 6).  Results do not depend on the choice beyond the rounding of double-precision sums. */
+int bx_set_tree_max_rows(int rows);
+/* conv3 + tail forward in two launches (bf16 storage, MFMA-capable C; otherwise BX_EUNSUPPORTED and the caller uses
+ * bx_conv3x3 + bx_block_tail_fwd): y3 = relu(conv3x3(y2, w3) + b3) is stored for backward, and conv3's epilogue also
+ * writes pooled = pool2x2(y3) and the batch statistics, so the pool never re-reads y3 from HBM.  w3_mfma is conv3's
+ * MFMA operand from bx_conv3x3_pack (flip 0).  Same workspace size and the same
+ * outputs as bx_block_tail_fwd (M:62-76). */
+int bx_block_conv3_tail_fwd(const bxTailDesc* d, const void* y2, const void* w3_mfma, const float* b3, void* y3,
+                            const void* x, const float* w1x1, int Cin, const float* b1x1, const float* bn_weight,
+                            const float* bn_bias, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                            const uint64_t* seed, void* pooled, void* out, float* save_mean, float* save_invstd,
+                            void* workspace, size_t workspace_bytes, bxStream stream);
 /* Backward of the tail.  dout [B,H/2,W/2,C].  Produces
  *   dz3 [B,H,W,C]: gradient w.r.t. conv3's pre-activation (pool backward AND conv3's ReLU mask applied),
  *   dx_skip [B,H,W,Cin_p] (may be NULL): gradient reaching the block input through the skip path,

@@ -213,10 +213,10 @@ __device__ __forceinline__ void sum_partials_256(const float* __restrict__ parti
 // (cdna_hip_programming.md, guideline 16 recipe R1 in its counter form).  Counters: ngroups + 1 words per domain, zero
 // before the first launch; the reducers put them back to zero, so graph replays and later launches need no memset.
 struct BxStatTree {
-  float* rows;          // [ndom][nrows][NV][Cw]
-  double* mid;          // [ndom][ngroups][NV][Cw]
-  unsigned* cnt;        // [ndom][ngroups + 1]
-  int nrows, G, ngroups, Cw;
+  float* rows;          // [nrows][NV][ld]: a domain (workgroups that share channels c0 .. c0+Cw-1) writes columns c0 .. c0+Cw-1 of every row
+  double* mid;          // [ngroups][NV][ld]
+  unsigned* cnt;        // [ndom][ngroups + 1]; NULL = rows only (a separate launch sums them)
+  int nrows, G, ngroups, Cw, ld;
 };
 static inline void bx_stat_tree_shape(int nrows, int* G, int* ngroups) {
   int g = nrows <= 96 ? nrows : 64;
@@ -247,9 +247,9 @@ __device__ __forceinline__ bool bx_last_ticket(unsigned* cnt, unsigned expected,
   __syncthreads();
   return *flag != 0u;
 }
-// fixed-order column sums of rows [r0, r1) of src[(r*NV + k)*Cw + c] (Src = float or double) -> tot[k] in threads c < Cw
+// fixed-order column sums of rows [r0, r1) of src[(r*NV + k)*ld + c] (Src = float or double) -> tot[k] in threads c < Cw
 template <int NV, typename Src>
-__device__ __forceinline__ void bx_sum_rows(const Src* src, int r0, int r1, int Cw, double (&tot)[NV], double* sp) {
+__device__ __forceinline__ void bx_sum_rows(const Src* src, int r0, int r1, int Cw, int ld, double (&tot)[NV], double* sp) {
   const int S = 256 / Cw, c = threadIdx.x % Cw, sl = threadIdx.x / Cw;
   double acc[NV];
 #pragma unroll
@@ -260,7 +260,7 @@ __device__ __forceinline__ void bx_sum_rows(const Src* src, int r0, int r1, int 
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int k = 0; k < NV; ++k) t[u][k] = src[((size_t)(r + u * S) * NV + k) * Cw + c];
+      for (int k = 0; k < NV; ++k) t[u][k] = src[((size_t)(r + u * S) * NV + k) * ld + c];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -268,7 +268,7 @@ __device__ __forceinline__ void bx_sum_rows(const Src* src, int r0, int r1, int 
   }
   for (; r < r1; r += S)
 #pragma unroll
-    for (int k = 0; k < NV; ++k) acc[k] += (double)src[((size_t)r * NV + k) * Cw + c];
+    for (int k = 0; k < NV; ++k) acc[k] += (double)src[((size_t)r * NV + k) * ld + c];
   __syncthreads();                                  // sp may still be read by a previous level
 #pragma unroll
   for (int k = 0; k < NV; ++k) sp[k * 256 + threadIdx.x] = acc[k];
@@ -282,29 +282,36 @@ __device__ __forceinline__ void bx_sum_rows(const Src* src, int r0, int r1, int 
     }
   }
 }
-// Called by all 256 threads of a workgroup; threads c < Cw pass the workgroup's partial sums val[k] of channel c.
+// Called by all 256 threads of a workgroup; threads c < Cw pass the workgroup's partial sums val[k] of channel c0 + c.
 // lds: BX_STAT_TREE_LDS(NV) bytes, 8-byte aligned, not in use by any wave of the workgroup.
 template <int NV>
-__device__ __forceinline__ bool bx_stat_tree_arrive(const BxStatTree& t, int dom, int row, const float (&val)[NV], double (&tot)[NV], char* lds) {
+__device__ __forceinline__ bool bx_stat_tree_arrive(const BxStatTree& t, int dom, int c0, int row, const float (&val)[NV], double (&tot)[NV], char* lds) {
   double* sp = reinterpret_cast<double*>(lds);
   unsigned* flag = reinterpret_cast<unsigned*>(lds + NV * 256 * 8);
-  float* rows = t.rows + (size_t)dom * t.nrows * NV * t.Cw;
+  float* rows = t.rows + c0;
+  if (!t.cnt) {                                       // rows only: plain stores, the kernel boundary publishes them
+    if ((int)threadIdx.x < t.Cw) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) rows[((size_t)row * NV + k) * t.ld + threadIdx.x] = val[k];
+    }
+    return false;
+  }
   unsigned* cnt = t.cnt + (size_t)dom * (t.ngroups + 1);
   if ((int)threadIdx.x < t.Cw) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) bx_store_agent(rows + ((size_t)row * NV + k) * t.Cw + threadIdx.x, val[k]);
+    for (int k = 0; k < NV; ++k) bx_store_agent(rows + ((size_t)row * NV + k) * t.ld + threadIdx.x, val[k]);
   }
   const int grp = row / t.G, r0 = grp * t.G, r1 = r0 + t.G < t.nrows ? r0 + t.G : t.nrows;
   if (!bx_last_ticket(cnt + grp, (unsigned)(r1 - r0), flag)) return false;
-  bx_sum_rows<NV, float>(rows, r0, r1, t.Cw, tot, sp);
+  bx_sum_rows<NV, float>(rows, r0, r1, t.Cw, t.ld, tot, sp);
   if (t.ngroups == 1) return true;
-  double* mid = t.mid + (size_t)dom * t.ngroups * NV * t.Cw;
+  double* mid = t.mid + c0;
   if ((int)threadIdx.x < t.Cw) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) bx_store_agent(mid + ((size_t)grp * NV + k) * t.Cw + threadIdx.x, tot[k]);
+    for (int k = 0; k < NV; ++k) bx_store_agent(mid + ((size_t)grp * NV + k) * t.ld + threadIdx.x, tot[k]);
   }
   if (!bx_last_ticket(cnt + t.ngroups, (unsigned)t.ngroups, flag)) return false;
-  bx_sum_rows<NV, double>(mid, 0, t.ngroups, t.Cw, tot, sp);
+  bx_sum_rows<NV, double>(mid, 0, t.ngroups, t.Cw, t.ld, tot, sp);
   return true;
 }
 
@@ -345,6 +352,24 @@ struct BxBnFinalize {
 __device__ __forceinline__ void bx_bn_finalize_channel(int c, double sum, double sumsq, const BxBnFinalize& f) {
   bx_bn_finalize_channel(c, true, sum, sumsq, f.count, f.gamma, f.beta, f.rmean, f.rvar, f.nbt, f.momentum, f.eps, f.scale, f.shift, f.save_mean, f.save_invstd);
 }
+// conv3 of a Block with the 2x2 pool and the BatchNorm batch statistics in its epilogue (bf16 MFMA kernels): the launcher fills the
+// tree's shape from the grid it chooses; rows / mid / cnt and their capacities come from the caller (the tail's workspace and sync words)
+struct BxConvPoolEpi {
+  void* pooled;                   // [B, H/2, W/2, Co] bf16
+  int pool, want_stats, Ho, Wo;
+  BxStatTree tree;                // domain = output-channel group of the grid (blockIdx.y), row = blockIdx.x
+  BxBnFinalize fin;
+  const float* w1x1; float* wT;   // side job: wT[ci][c] = W1x1[c][ci] for the tail's apply kernel (zero rows beyond Cin1)
+  int Cin1, Cin1_p;
+  size_t rows_cap_floats; int cnt_cap_words;
+  int tree_max_rows;              // more partial rows than this: rows only (tree.cnt is cleared), the caller launches the finalize
+};
+// in-launch finalize only for trees of at most this many rows (BX_TREE_MAX_ROWS; 0 = always a separate finalize launch)
+int bx_tree_max_rows();
+int bx_conv3x3_mfma_supported(int Ci, int Co, int dtype);
+int bx_conv3x3_mfma_pool_launch(const void* x, const void* packed_mfma, const float* bias, void* y, int B, int H, int W, int Ci, int Co,
+                                BxConvPoolEpi* pe, hipStream_t s);
+
 // forward 2 (separate-launch form): statistics -> (scale, shift).  Launch with 1024 threads, grid = bx_finalize_grid(C).
 static __global__ void k_bn_finalize(const float* __restrict__ partials, int nblk, double count, int C, int training,
                               const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,

@@ -155,13 +155,100 @@ __device__ __forceinline__ int lds_chunk(int c, int p) {
   return c;
 }
 
+// lane exchanges inside a row of 16 lanes as DPP modifiers (no LDS crossbar trip): quad_perm [1,0,3,2] / [2,3,0,1], row_ror:4 / :8
+template <int CTRL> __device__ __forceinline__ float dpp16(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {       // every lane of the row gets the sum of its 16 lanes (fixed order)
+  v += dpp16<0xB1>(v); v += dpp16<0x4E>(v); v += dpp16<0x124>(v); v += dpp16<0x128>(v);
+  return v;
+}
+// ---- pooled epilogue (conv3 of a Block): 2x2 pool of the values AS STORED + per-channel (sum, sum of squares) of the pooled map -------
+// Accumulator layout: lane (li = pixel of the 16-pixel tile, g) holds channels co_base + n*16 + 4g .. +3 of tile t = wave*MP + i; the tile
+// one image row below is i + TPR, the horizontal neighbour is lane li ^ 1.  Even-li lanes of even tile rows own a pooled pixel.
+// The average adds in k_pool_stats' order ((y,x) + (y,x+1) + (y+1,x) + (y+1,x+1)) so both forms store the same bits.
+template <int MP, int NC, int TPR, typename PixFn>
+__device__ __forceinline__ void conv_pool_tiles(const f32x4 (&q)[MP][NC], const BxConvPoolEpi& pe, const __amdgpu_buffer_rsrc_t& pres, int Co,
+                                                int co_base, PixFn pix, float (&st)[2][NC][4]) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+#pragma unroll
+  for (int i = 0; i < MP; ++i) {
+    if ((i / TPR) % 2) continue;                       // bottom rows are consumed by the tile above (MP = 2*TPR*IMGS)
+    int bimg, oy, ox;
+    pix(i, bimg, oy, ox);                              // image, row and column of this lane's pixel in tile i
+    const bool own = !(li & 1) && (oy >> 1) < pe.Ho && (ox >> 1) < pe.Wo;
+    const uint32_t po = own ? (uint32_t)(((((bimg * pe.Ho + (oy >> 1)) * pe.Wo + (ox >> 1)) * Co) + co_base + 4 * g) * 2) : 0x80000000u;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t0 = q[i][n][r], b0 = q[i + TPR][n][r];
+        const float t1 = dpp16<0xB1>(t0), b1 = dpp16<0xB1>(b0);          // the horizontal neighbour (lane ^ 1)
+        v[r] = pe.pool == BX_POOL_MAX ? fmaxf(fmaxf(t0, t1), fmaxf(b0, b1)) : 0.25f * (t0 + t1 + b0 + b1);
+      }
+      const uint32_t lo = pack2bf(v[0], v[1]), hi = pack2bf(v[2], v[3]);
+      __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, pres, po + (uint32_t)(n * 32), 0, 0);
+      if (own) {                                       // statistics of the pooled values as stored
+        const float w[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[0][n][r] += w[r]; st[1][n][r] += w[r] * w[r]; }
+      }
+    }
+  }
+}
+// workgroup sums of st -> one row of the reduction tree; the last workgroup of the channel group finalizes its 16*NC channels
+template <int NC>
+__device__ __forceinline__ void conv_pool_finish(float (&st)[2][NC][4], const BxConvPoolEpi& pe, int co_base, char* lds) {
+  if (!pe.want_stats) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+  constexpr int CW = NC * 16;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int n = 0; n < NC; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st[k][n][r] = row16_sum(st[k][n][r]);
+      }
+  __syncthreads();                                     // every wave is done with the halo tiles in LDS
+  float* stage = reinterpret_cast<float*>(lds + BX_STAT_TREE_LDS(2));          // [4 waves][2][CW]
+  if (li == 0) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int n = 0; n < NC; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(wave * 2 + k) * CW + n * 16 + 4 * g + r] = st[k][n][r];
+  }
+  __syncthreads();
+  float val[2] = {0.f, 0.f};
+  if ((int)threadIdx.x < CW) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      val[k] = ((stage[(0 + k) * CW + threadIdx.x] + stage[(2 + k) * CW + threadIdx.x]) + stage[(4 + k) * CW + threadIdx.x]) + stage[(6 + k) * CW + threadIdx.x];
+  }
+  double tot[2];
+  if (bx_stat_tree_arrive<2>(pe.tree, blockIdx.y, co_base, blockIdx.x, val, tot, lds) && (int)threadIdx.x < CW)
+    bx_bn_finalize_channel(co_base + threadIdx.x, tot[0], tot[1], pe.fin);
+}
+// side job of the pooled form: each workgroup transposes a slice of the block's 1x1 weights for the tail's apply kernel
+__device__ __forceinline__ void conv_pool_transpose_w1x1(const BxConvPoolEpi& pe, int C) {
+  const int nw = pe.Cin1_p * C, nwg = (int)(gridDim.x * gridDim.y), wg = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  const int per = (nw + nwg - 1) / nwg, lo = wg * per, hi = lo + per < nw ? lo + per : nw;
+  for (int i = lo + (int)threadIdx.x; i < hi; i += 256) {
+    const int ci = i / C, c = i - ci * C;
+    pe.wT[i] = ci < pe.Cin1 ? pe.w1x1[(size_t)c * pe.Cin1 + ci] : 0.f;
+  }
+}
+
 // IMGS (round 2): a workgroup's pixel tile may span the SAME 8 x TW window of IMGS consecutive images (their halo tiles sit one
 // after the other in LDS).  The weight fragments a wave fetches per K-step then feed IMGS times as many MFMAs: the late stages
 // (8x16 and 16x32 maps, 64-channel chunks) ran 4-8 MFMAs per K-step per wave and spent 470-830 cycles on each (in-kernel stamps).
-template <int CK, int NC, int TW, int IMGS = 1>
+template <int CK, int NC, int TW, int IMGS = 1, bool POOL = false>
 __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const bf16_t* __restrict__ mask_src, const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
-    int H, int W, int Ci, int Co, int relu, int tiles_x, int tiles_y, uint32_t x_bytes) {
+    int H, int W, int Ci, int Co, int relu, int tiles_x, int tiles_y, uint32_t x_bytes, BxConvPoolEpi pe) {
   constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CKB = CK * 2, NCH = CK / 8, KS = (9 * CK + 31) / 32;
   constexpr int MP = IMGS * TH * TW / 64;   // 16-pixel tiles per wave
   constexpr int TPI = TH * TW / 16;         // 16-pixel tiles per image
@@ -171,6 +258,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, b = (bid / (tiles_x * tiles_y)) * IMGS;      // first image of the tile
   const int y0 = ty * TH, x0 = tx * TW, co_base = blockIdx.y * (NC * 16);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+  if (POOL) conv_pool_transpose_w1x1(pe, Co);
 
   f32x4 acc[MP][NC];
 #pragma unroll
@@ -270,6 +358,32 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
 #pragma unroll
     for (int n = 0; n < NC; ++n) offs[i][n] = inb ? orow + (uint32_t)(n * 32) : 0x80000000u;
   }
+  if constexpr (POOL) {          // conv3 of a Block: y = relu(conv + bias) stored, then pool + statistics from the stored values
+#pragma unroll
+    for (int i = 0; i < MP; ++i)
+#pragma unroll
+      for (int n = 0; n < NC; ++n) {
+        const float v[4] = {fmaxf(acc[i][n][0] + bz[n].x, 0.f), fmaxf(acc[i][n][1] + bz[n].y, 0.f), fmaxf(acc[i][n][2] + bz[n].z, 0.f),
+                            fmaxf(acc[i][n][3] + bz[n].w, 0.f)};
+        const u32x2 out = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        __builtin_amdgcn_raw_buffer_store_b64(out, yres, offs[i][n], 0, 0);
+        acc[i][n] = (f32x4){__uint_as_float(out.x << 16), __uint_as_float(out.x & 0xffff0000u), __uint_as_float(out.y << 16),
+                            __uint_as_float(out.y & 0xffff0000u)};
+      }
+    const uint32_t p_bytes = (uint32_t)((size_t)gridDim.x / (tiles_x * tiles_y) * IMGS * pe.Ho * pe.Wo * Co * 2);
+    const __amdgpu_buffer_rsrc_t pres = __builtin_amdgcn_make_buffer_rsrc(pe.pooled, 0, p_bytes, 0x00020000);
+    float st[2][NC][4];
+#pragma unroll
+    for (int n = 0; n < NC; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[0][n][r] = st[1][n][r] = 0.f;
+    conv_pool_tiles<MP, NC, TPR>(acc, pe, pres, Co, co_base, [&](int i, int& bimg, int& oy, int& ox) {
+      const int t = wave * MP + i, img = t / TPI, tl = t % TPI;
+      bimg = b + img; oy = y0 + tl / TPR; ox = x0 + (tl % TPR) * 16 + li;
+    }, st);
+    conv_pool_finish<NC>(st, pe, co_base, lds);
+    return;
+  }
   if (mask_src) {
 #pragma unroll
     for (int i = 0; i < MP; ++i)
@@ -309,14 +423,251 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   }
 }
 
+#ifdef BX_CONV_STAMPS
+// Diagnostic build only (hipcc -DBX_CONV_STAMPS, tools/conv_stamps.py): shader-clock stamps of one workgroup in four.
+// Slots per workgroup: [start, first halo image staged, end of chunk 0..3, epilogue stores issued].
+__device__ unsigned long long bx_conv_stamps[64 * 8];
+extern "C" int bx_debug_conv_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(bx_conv_stamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -1;
+}
+#define BX_CSTAMP(i) do { if (cstamp_wg >= 0 && threadIdx.x == 0) bx_conv_stamps[cstamp_wg * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BX_CSTAMP(i) do { } while (0)
+#endif
+// Channel-split variant for the 64-channel-chunk layers (stages 3-5, Ci % 64 == 0, Co % 64 == 0).
+// k_conv_mfma gives each wave a quarter of the workgroup's PIXELS and all of its NC*16 output channels, so the four waves fetch the
+// same weight fragments (4 x NC KB per K-step through the CU's 64 B/clk vector-memory path: 128-256 cycles for 128 cycles of MFMA)
+// and a weight prefetch ring costs NC*4 registers per stage.  Here a wave owns 16*NCW output channels and ALL pixel tiles of the
+// workgroup: every weight fragment is fetched by exactly one wave (4x fewer bytes through the L1), the ring is NCW*4 registers per
+// stage (depth 6, five K-steps ahead, across chunk boundaries), and each pixel fragment read from LDS feeds NCW MFMAs.
+// LDS image: the halo rows are padded to a multiple of 8 pixels so that the bank swizzle (16-byte chunk c of pixel p at c ^ (p & 7))
+// depends on (lane, dx) only -- every fragment read of a K-step is one of six per-lane base addresses plus an immediate offset.
+// The next chunk's halo is fetched into registers while the current chunk is multiplied.
+template <int NCW, int TW, int IMGS, bool POOL>
+__global__ __launch_bounds__(256) void k_conv_mfma_c(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+    const bf16_t* __restrict__ mask_src, const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
+    int H, int W, int Ci, int Co, int relu, int tiles_x, int tiles_y, uint32_t x_bytes, BxConvPoolEpi pe) {
+  constexpr int CK = 64, TH = 8, HWR = TW + 2, HWID = (TW + 2 + 7) / 8 * 8, HH = TH + 2, CKB = CK * 2, NCH = CK / 8, KS = 18, D = 6;
+  constexpr int MPT = IMGS * TH * TW / 16;  // 16-pixel tiles of the workgroup (every wave computes all of them)
+  constexpr int TPI = TH * TW / 16, TPR = TW / 16;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int bid = blockIdx.x;
+  const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, b = (bid / (tiles_x * tiles_y)) * IMGS;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+  const int co_base = blockIdx.y * (4 * NCW * 16) + wave * (NCW * 16);          // this WAVE's first output channel
+#ifdef BX_CONV_STAMPS
+  const int cstamp_lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  const int cstamp_wg = (cstamp_lin % 4 == 1 && cstamp_lin / 4 < 64) ? cstamp_lin / 4 : -1;
+#endif
+  BX_CSTAMP(0);
+  if (POOL) conv_pool_transpose_w1x1(pe, Co);
+
+  f32x4 acc[MPT][NCW];
+#pragma unroll
+  for (int i = 0; i < MPT; ++i)
+#pragma unroll
+    for (int n = 0; n < NCW; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nchunk = Ci / CK;
+  constexpr int NU = IMGS * HH * HWR * NCH, NR = (NU + 255) / 256;
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
+  uint32_t hoff[NR], lpos[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int u = threadIdx.x + k * 256;
+    const int pr = u / NCH, c = u % NCH;
+    const int img = pr / (HH * HWR), pl = pr - img * (HH * HWR);
+    const int row = pl / HWR, col = pl - row * HWR;
+    const int iy = y0 + row - 1, ix = x0 + col - 1;
+    const bool ok = u < NU && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    hoff[k] = ok ? (uint32_t)(((((b + img) * H + iy) * W + ix) * Ci + c * 8) * 2) : 0x80000000u;
+    const int P = (img * HH + row) * HWID + col;
+    lpos[k] = (uint32_t)(P * CKB + 16 * (c ^ (P & 7)));
+  }
+  // per-lane fragment base addresses: [dx][half of the chunk]
+  uint32_t a0[3][2];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) a0[dx][h] = (uint32_t)((li + dx) * CKB + 16 * ((h * 4 + g) ^ ((li + dx) & 7)));
+
+  uint4 rv[NR];
+  auto fetch = [&]() {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xres, hoff[k], 0, 0);
+      rv[k] = make_uint4(v.x, v.y, v.z, v.w);
+      hoff[k] += (uint32_t)(CK * 2);                          // next chunk of input channels (an invalid lane stays >= 2^31)
+    }
+  };
+  fetch();
+  // weight ring: slot of global K-step gs is gs % D (KS % D == 0, so slots are compile-time inside the unrolled chunk)
+  bf16x8 a[D][NCW];
+  const bf16_t* wlane = wp + ((size_t)(co_base + li)) * 32 + 8 * g;
+  auto load_a = [&](int gs, bf16x8 (&dst)[NCW]) {
+#pragma unroll
+    for (int n = 0; n < NCW; ++n) dst[n] = *reinterpret_cast<const bf16x8*>(wlane + ((size_t)gs * Co + n * 16) * 32);
+  };
+#pragma unroll
+  for (int s = 0; s < D - 1; ++s) load_a(s, a[s]);
+
+  // Two LDS images: chunk c is multiplied out of image c & 1 while chunk c + 1's halo, fetched at the start of chunk c, is written
+  // into the other image in the middle of chunk c (its loads have landed by then and the wait counts only the loads older than the
+  // weight prefetches issued since).  A single image needed `s_waitcnt vmcnt(0)` at every chunk boundary, i.e. it also waited for
+  // the five weight fragments just requested for the next chunk -- one exposed L2 round trip per chunk.
+  constexpr int IMG_BYTES = IMGS * HH * HWID * CKB;
+  auto stage_write = [&](char* img) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+      if ((int)threadIdx.x + k * 256 < NU) *reinterpret_cast<uint4*>(img + lpos[k]) = rv[k];
+  };
+  stage_write(lds);
+  __syncthreads();
+  BX_CSTAMP(1);
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const char* cur = lds + (chunk & 1) * IMG_BYTES;
+    char* nxt = lds + ((chunk + 1) & 1) * IMG_BYTES;
+    const bool more = chunk + 1 < nchunk;
+    if (more) fetch();                        // next chunk's halo rides under this chunk's MFMAs
+    // Pixel fragments run R MFMA slots ahead of their use in a register ring, the order pinned with scheduling barriers: left to
+    // itself hipcc sinks every ds_read to its MFMA (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, one LDS round trip per MFMA).
+    constexpr int R = MPT < 8 ? MPT : 8, NIT = KS * MPT;
+    bf16x8 ring[R];
+    auto frag = [&](int idx) -> bf16x8 {      // idx = s * MPT + i, compile-time after unrolling
+      const int s = idx / MPT, i = idx % MPT;
+      const int tap = s / 2, dy = tap / 3, dx = tap - 3 * dy, half = s & 1;
+      const int img = i / TPI, tl = i % TPI;
+      const int off = ((img * HH + tl / TPR + dy) * HWID + (tl % TPR) * 16) * CKB;
+      return *reinterpret_cast<const bf16x8*>(cur + a0[dx][half] + off);
+    };
+#pragma unroll
+    for (int j = 0; j < R; ++j) ring[j] = frag(j);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (more || s + D - 1 < KS) load_a(chunk * KS + s + D - 1, a[(s + D - 1) % D]);
+      if (s == KS / 2 && more) stage_write(nxt);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MPT; ++i) {
+        const int idx = s * MPT + i;
+#pragma unroll
+        for (int n = 0; n < NCW; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s % D][n], ring[idx % R], acc[i][n], 0, 0, 0);
+        if (idx + R < NIT) ring[idx % R] = frag(idx + R);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();                          // this image may be overwritten, the other one is complete
+    if (chunk < 4) BX_CSTAMP(2 + chunk);
+  }
+  // epilogue: lane = (pixel li of tile i, output channels co_base + n*16 + 4g .. +3), as in k_conv_mfma
+  const uint32_t y_bytes = (uint32_t)((size_t)gridDim.x / (tiles_x * tiles_y) * IMGS * H * W * Co * 2);
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src ? mask_src : y), 0, y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend : y), 0, y_bytes, 0x00020000);
+  float4 bz[NCW];
+#pragma unroll
+  for (int n = 0; n < NCW; ++n)
+    bz[n] = bias ? *reinterpret_cast<const float4*>(bias + co_base + n * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint32_t lane_off = (uint32_t)((((b * H + y0) * W + x0 + li) * Co + co_base + 4 * g) * 2);
+  uint32_t offs[MPT];
+#pragma unroll
+  for (int i = 0; i < MPT; ++i) {
+    const int img = i / TPI, tl = i % TPI;
+    const int oy = y0 + tl / TPR, ox = x0 + (tl % TPR) * 16 + li;
+    const bool inb = oy < H && ox < W;
+    offs[i] = inb ? lane_off + (uint32_t)((((img * H + tl / TPR) * W + (tl % TPR) * 16) * Co) * 2) : 0x80000000u;
+  }
+  if constexpr (POOL) {
+#pragma unroll
+    for (int i = 0; i < MPT; ++i)
+#pragma unroll
+      for (int n = 0; n < NCW; ++n) {
+        const float v[4] = {fmaxf(acc[i][n][0] + bz[n].x, 0.f), fmaxf(acc[i][n][1] + bz[n].y, 0.f), fmaxf(acc[i][n][2] + bz[n].z, 0.f),
+                            fmaxf(acc[i][n][3] + bz[n].w, 0.f)};
+        const u32x2 out = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        __builtin_amdgcn_raw_buffer_store_b64(out, yres, offs[i] + (uint32_t)(n * 32), 0, 0);
+        acc[i][n] = (f32x4){__uint_as_float(out.x << 16), __uint_as_float(out.x & 0xffff0000u), __uint_as_float(out.y << 16),
+                            __uint_as_float(out.y & 0xffff0000u)};
+      }
+    const uint32_t p_bytes = (uint32_t)((size_t)gridDim.x / (tiles_x * tiles_y) * IMGS * pe.Ho * pe.Wo * Co * 2);
+    const __amdgpu_buffer_rsrc_t pres = __builtin_amdgcn_make_buffer_rsrc(pe.pooled, 0, p_bytes, 0x00020000);
+    float st[2][NCW][4];
+#pragma unroll
+    for (int n = 0; n < NCW; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[0][n][r] = st[1][n][r] = 0.f;
+    conv_pool_tiles<MPT, NCW, TPR>(acc, pe, pres, Co, co_base, [&](int i, int& bimg, int& oy, int& ox) {
+      const int img = i / TPI, tl = i % TPI;
+      bimg = b + img; oy = y0 + tl / TPR; ox = x0 + (tl % TPR) * 16 + li;
+    }, st);
+    // a wave holds ALL pixels of the workgroup for its channels: the row of partial sums needs no exchange between waves
+    if (pe.want_stats) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int n = 0; n < NCW; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[k][n][r] = row16_sum(st[k][n][r]);
+      if (li == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int n = 0; n < NCW; ++n)
+            *reinterpret_cast<float4*>(pe.tree.rows + ((size_t)blockIdx.x * 2 + k) * pe.tree.ld + co_base + n * 16 + 4 * g) =
+                make_float4(st[k][n][0], st[k][n][1], st[k][n][2], st[k][n][3]);
+      }
+    }
+    return;
+  }
+  u32x2 mk[MPT][NCW], ad[MPT][NCW];
+  if (mask_src) {
+#pragma unroll
+    for (int i = 0; i < MPT; ++i)
+#pragma unroll
+      for (int n = 0; n < NCW; ++n) mk[i][n] = __builtin_amdgcn_raw_buffer_load_b64(mres, offs[i] + (uint32_t)(n * 32), 0, 0);
+  }
+  if (addend) {
+#pragma unroll
+    for (int i = 0; i < MPT; ++i)
+#pragma unroll
+      for (int n = 0; n < NCW; ++n) ad[i][n] = __builtin_amdgcn_raw_buffer_load_b64(ares, offs[i] + (uint32_t)(n * 32), 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < MPT; ++i) {
+#pragma unroll
+    for (int n = 0; n < NCW; ++n) {
+      float v[4] = {acc[i][n][0] + bz[n].x, acc[i][n][1] + bz[n].y, acc[i][n][2] + bz[n].z, acc[i][n][3] + bz[n].w};
+      if (relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (mask_src) {
+        const u32x2 m = mk[i][n];
+        const uint32_t mm[4] = {m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (mm[r] != 0u && mm[r] < 0x8000u) ? v[r] : 0.f;
+      }
+      if (addend) {
+        const u32x2 a2 = ad[i][n];
+        v[0] += __uint_as_float(a2.x << 16); v[1] += __uint_as_float(a2.x & 0xffff0000u);
+        v[2] += __uint_as_float(a2.y << 16); v[3] += __uint_as_float(a2.y & 0xffff0000u);
+      }
+      const u32x2 out = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      __builtin_amdgcn_raw_buffer_store_b64(out, yres, offs[i] + (uint32_t)(n * 32), 0, 0);
+    }
+  }
+  BX_CSTAMP(6);
+}
+
 // Persistent variant for single-chunk layers (Ci == CK <= 32: the HBM-bound early stages).  A workgroup walks tiles
 // blockIdx.x, blockIdx.x + gridDim.x, ...; the NEXT tile's halo is fetched into registers before the current tile's
 // MFMAs and epilogue, so every CU always has input loads in flight (the one-shot kernel exposes one HBM round trip per
 // workgroup and relies on occupancy alone to hide it).
-template <int CK, int NC, int TW>
+template <int CK, int NC, int TW, bool POOL = false>
 __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const bf16_t* __restrict__ mask_src, const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
-    int H, int W, int Co, int relu, int tiles_x, int tiles_y, int ntiles, uint32_t x_bytes) {
+    int H, int W, int Co, int relu, int tiles_x, int tiles_y, int ntiles, uint32_t x_bytes, BxConvPoolEpi pe) {
   constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CKB = CK * 2, NCH = CK / 8, KS = (9 * CK + 31) / 32;
   constexpr int MP = TH * TW / 64, TPR = TW / 16;
   constexpr int NU = HH * HWID * NCH, NR = (NU + 255) / 256;
@@ -361,6 +712,17 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
   for (int n = 0; n < NC; ++n)
     bz[n] = bias ? *reinterpret_cast<const float4*>(bias + co_base + n * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
   if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  // pooled form: statistics accumulate over the workgroup's tiles in registers; one reduction-tree row per workgroup at the end
+  float st[2][NC][4];
+  __amdgpu_buffer_rsrc_t pres = yres;
+  if constexpr (POOL) {
+    conv_pool_transpose_w1x1(pe, Co);
+    pres = __builtin_amdgcn_make_buffer_rsrc(pe.pooled, 0, (uint32_t)((size_t)(ntiles / (tiles_x * tiles_y)) * pe.Ho * pe.Wo * Co * 2), 0x00020000);
+#pragma unroll
+    for (int n = 0; n < NC; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[0][n][r] = st[1][n][r] = 0.f;
+  }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int y0 = ty * TH, x0 = tx * TW;
@@ -421,6 +783,24 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
 #pragma unroll
       for (int n = 0; n < NC; ++n) offs[i][n] = inb ? orow + (uint32_t)(n * 32) : 0x80000000u;
     }
+    if constexpr (POOL) {
+#pragma unroll
+      for (int i = 0; i < MP; ++i)
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+          const float v[4] = {fmaxf(acc[i][n][0] + bz[n].x, 0.f), fmaxf(acc[i][n][1] + bz[n].y, 0.f), fmaxf(acc[i][n][2] + bz[n].z, 0.f),
+                              fmaxf(acc[i][n][3] + bz[n].w, 0.f)};
+          const u32x2 out = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          __builtin_amdgcn_raw_buffer_store_b64(out, yres, offs[i][n], 0, 0);
+          acc[i][n] = (f32x4){__uint_as_float(out.x << 16), __uint_as_float(out.x & 0xffff0000u), __uint_as_float(out.y << 16),
+                              __uint_as_float(out.y & 0xffff0000u)};
+        }
+      conv_pool_tiles<MP, NC, TPR>(acc, pe, pres, Co, co_base, [&](int i, int& bimg, int& oy, int& ox) {
+        const int t = wave * MP + i;
+        bimg = b; oy = y0 + t / TPR; ox = x0 + (t % TPR) * 16 + li;
+      }, st);
+      continue;
+    }
     if (mask_src) {
 #pragma unroll
       for (int i = 0; i < MP; ++i)
@@ -458,6 +838,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
       }
     }
   }
+  if constexpr (POOL) conv_pool_finish<NC>(st, pe, co_base, lds);
 }
 
 // K-split variant for Ci >= 64 (the MFMA-bound late stages, where maps are small and a workgroup-per-tile kernel is a
@@ -591,19 +972,47 @@ static int launch_conv_ks(const void* x, const void* wp, const float* bias, cons
   return BX_OK;
 }
 
+// the pooled form's reduction tree: one row per workgroup of a channel group; checks the caller's buffers against the grid chosen here
+template <int NC>
+static int pool_tree_shape(BxConvPoolEpi* pe, int grid_x, int ygroups, int Co) {
+  pe->tree.nrows = grid_x; pe->tree.Cw = NC * 16; pe->tree.ld = Co;
+  bx_stat_tree_shape(grid_x, &pe->tree.G, &pe->tree.ngroups);
+  if (!pe->want_stats) return BX_OK;
+  if (grid_x > pe->tree_max_rows) pe->tree.cnt = nullptr;
+  BX_REQUIRE((size_t)grid_x * 2 * Co <= pe->rows_cap_floats, "bx_conv3x3(pooled): %d partial rows exceed the workspace", grid_x);
+  BX_REQUIRE(!pe->tree.cnt || ygroups * (pe->tree.ngroups + 1) <= pe->cnt_cap_words, "bx_conv3x3(pooled): %d x %d reduction groups exceed the sync words",
+             ygroups, pe->tree.ngroups);
+  return BX_OK;
+}
 template <int CK, int NC, int TW>
 static int launch_conv(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
-                       int B, int H, int W, int Ci, int Co, int relu, hipStream_t s) {
+                       int B, int H, int W, int Ci, int Co, int relu, hipStream_t s, BxConvPoolEpi* pe = nullptr) {
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + 7) / 8;
-  const size_t lds = (size_t)10 * (TW + 2) * CK * 2;
-  if (CK <= 32 && Ci == CK) {
+  size_t lds = (size_t)10 * (TW + 2) * CK * 2;
+  const BxConvPoolEpi none = {};
+  if (pe) {
+    const size_t need = BX_STAT_TREE_LDS(2) + (size_t)4 * 2 * NC * 16 * sizeof(float);       // conv_pool_finish reuses the halo tile's LDS
+    if (lds < need) lds = need;
+  }
+  if constexpr (CK <= 32) if (Ci == CK) {
     const int ntiles = tiles_x * tiles_y * B, ygroups = Co / (16 * NC);
     int gx = 2048 / ygroups;                       // ~8 workgroups per CU in total, each walking ntiles/gx tiles
     if (gx > ntiles) gx = ntiles;
     if (ntiles >= 4 * gx && (size_t)B * H * W * CK * 2 < ((size_t)1 << 31)) {       // 32-bit byte offsets in the halo fetch
+      if (pe) {
+        if constexpr (CK >= 16) {
+          const int rc = pool_tree_shape<NC>(pe, gx, ygroups, Co);
+          if (rc != BX_OK) return rc;
+          hipLaunchKernelGGL((k_conv_mfma_p<CK, NC, TW, true>), dim3((unsigned)gx, (unsigned)ygroups), dim3(256), lds, s, (const bf16_t*)x,
+                             (const bf16_t*)wp, bias, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (bf16_t*)y, H, W, Co, 1, tiles_x, tiles_y, ntiles,
+                             (uint32_t)((size_t)B * H * W * CK * 2), *pe);
+          BX_CHECK_LAUNCH("bx_conv3x3(mfma persistent, pooled)");
+          return BX_OK;
+        }
+      }
       hipLaunchKernelGGL((k_conv_mfma_p<CK, NC, TW>), dim3((unsigned)gx, (unsigned)ygroups), dim3(256), lds, s, (const bf16_t*)x,
                          (const bf16_t*)wp, bias, (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Co, relu, tiles_x, tiles_y, ntiles,
-                         (uint32_t)((size_t)B * H * W * CK * 2));
+                         (uint32_t)((size_t)B * H * W * CK * 2), none);
       BX_CHECK_LAUNCH("bx_conv3x3(mfma persistent)");
       return BX_OK;
     }
@@ -611,7 +1020,7 @@ static int launch_conv(const void* x, const void* wp, const float* bias, const v
   // two-image tiles where one 8 x 16 tile IS the image and the layer is wide (stage 5, 256 output channels): measured at B=64
   // 21.0 -> 15.6 us (256->256 forward), 21.7 -> 16.5 (its dgrad), 11.9 -> 9.9 (128->256 forward); every other shape got slower
   // with IMGS = 2 or 4 (fewer, longer workgroups), see DESIGN section 6.  BX_CONV_IMGS=1|2 overrides for sweeps.
-  if (CK == 64) {
+  if constexpr (CK == 64) {
     static const int imgs_env = getenv("BX_CONV_IMGS") ? atoi(getenv("BX_CONV_IMGS")) : 0;
     const bool two = imgs_env ? imgs_env == 2 : (tiles_x * tiles_y == 1 && Co >= 256);
     if (two && B % 2 == 0) {
@@ -623,38 +1032,117 @@ static int launch_conv(const void* x, const void* wp, const float* bias, const v
         attr_done = true;
       }
       dim3 grid2((unsigned)(tiles_x * tiles_y * (B / 2)), (unsigned)(Co / (16 * NC)));
+      if (pe) {
+        const int rc = pool_tree_shape<NC>(pe, (int)grid2.x, (int)grid2.y, Co);
+        if (rc != BX_OK) return rc;
+        static bool attr_done_p = false;
+        if (lds2 > 64 * 1024 && !attr_done_p) {
+          if (hipFuncSetAttribute((const void*)k_conv_mfma<CK, NC, TW, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+            BX_FAIL(BX_EHIP, "bx_conv3x3(mfma): cannot reserve %zu bytes of LDS", lds2);
+          attr_done_p = true;
+        }
+        hipLaunchKernelGGL((k_conv_mfma<CK, NC, TW, 2, true>), grid2, dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)nullptr,
+                           (const bf16_t*)nullptr, (bf16_t*)y, H, W, Ci, Co, 1, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), *pe);
+        BX_CHECK_LAUNCH("bx_conv3x3(mfma, two-image tiles, pooled)");
+        return BX_OK;
+      }
       hipLaunchKernelGGL((k_conv_mfma<CK, NC, TW, 2>), grid2, dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)mask,
-                         (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2));
+                         (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), none);
       BX_CHECK_LAUNCH("bx_conv3x3(mfma, two-image tiles)");
       return BX_OK;
     }
   }
   dim3 grid((unsigned)(tiles_x * tiles_y * B), (unsigned)(Co / (16 * NC)));
+  if (pe) {
+    if constexpr (CK >= 16) {
+      const int rc = pool_tree_shape<NC>(pe, (int)grid.x, (int)grid.y, Co);
+      if (rc != BX_OK) return rc;
+      hipLaunchKernelGGL((k_conv_mfma<CK, NC, TW, 1, true>), grid, dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)nullptr,
+                         (const bf16_t*)nullptr, (bf16_t*)y, H, W, Ci, Co, 1, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), *pe);
+      BX_CHECK_LAUNCH("bx_conv3x3(mfma, pooled)");
+      return BX_OK;
+    }
+    BX_FAIL(BX_EUNSUPPORTED, "bx_conv3x3(pooled): needs at least 16 input channels");
+  }
   hipLaunchKernelGGL((k_conv_mfma<CK, NC, TW>), grid, dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)wp, bias,
-                     (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2));
+                     (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), none);
   BX_CHECK_LAUNCH("bx_conv3x3(mfma)");
   return BX_OK;
+}
+// channel-split kernel for Ci % 64 == 0, Co % 64 == 0 (BX_CONV_C=0 keeps the pixel-split kernels)
+template <int NCW, int TW, int IMGS>
+static int launch_conv_c(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
+                         int B, int H, int W, int Ci, int Co, int relu, hipStream_t s, BxConvPoolEpi* pe) {
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + 7) / 8;
+  const size_t lds = (size_t)2 * IMGS * 10 * ((TW + 2 + 7) / 8 * 8) * 128;          // two halo images (double buffer)
+  dim3 grid((unsigned)(tiles_x * tiles_y * (B / IMGS)), (unsigned)(Co / (64 * NCW)));
+  const BxConvPoolEpi none = {};
+  auto attr = [&](const void* fn, bool& done) -> int {
+    if (lds > 64 * 1024 && !done) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        BX_FAIL(BX_EHIP, "bx_conv3x3(mfma): cannot reserve %zu bytes of LDS", lds);
+      done = true;
+    }
+    return BX_OK;
+  };
+  if (pe) {
+    pe->tree.nrows = (int)grid.x; pe->tree.Cw = NCW * 16; pe->tree.ld = Co;
+    bx_stat_tree_shape((int)grid.x, &pe->tree.G, &pe->tree.ngroups);
+    pe->tree.cnt = nullptr;                                   // rows only: the caller launches the finalize
+    BX_REQUIRE(!pe->want_stats || (size_t)grid.x * 2 * Co <= pe->rows_cap_floats, "bx_conv3x3(pooled): %u partial rows exceed the workspace", grid.x);
+    static bool done_p = false;
+    const int rc = attr((const void*)k_conv_mfma_c<NCW, TW, IMGS, true>, done_p);
+    if (rc != BX_OK) return rc;
+    hipLaunchKernelGGL((k_conv_mfma_c<NCW, TW, IMGS, true>), grid, dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)nullptr,
+                       (const bf16_t*)nullptr, (bf16_t*)y, H, W, Ci, Co, 1, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), *pe);
+    BX_CHECK_LAUNCH("bx_conv3x3(mfma channel-split, pooled)");
+    return BX_OK;
+  }
+  static bool done = false;
+  const int rc = attr((const void*)k_conv_mfma_c<NCW, TW, IMGS, false>, done);
+  if (rc != BX_OK) return rc;
+  hipLaunchKernelGGL((k_conv_mfma_c<NCW, TW, IMGS, false>), grid, dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)mask,
+                     (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), none);
+  BX_CHECK_LAUNCH("bx_conv3x3(mfma channel-split)");
+  return BX_OK;
+}
+// returns -1 when the channel-split kernel does not apply.  Measured at B=64 against the pixel-split kernels (us, forward / data gradient):
+//   16x32 128->128  14.1 / 17.5  vs 15.3 / 17.1      8x16 128->256  8.5 / 13.2 vs 9.6 / 12.4      8x16 256->256  13.6 / 15.0 vs 15.4 / 16.3
+//   32x64  64->64   18.3 / 24.8  vs 18.5 / 21.8     16x32  64->128  9.9 / 14.2 vs 10.2 / 10.5
+// so: forward (and pooled) layers with Co >= 128, data gradients only at 256 -> 256.  BX_CONV_C=0 never, 2 wherever it applies.
+static int try_conv_c(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
+                      int B, int H, int W, int Ci, int Co, int relu, hipStream_t s, BxConvPoolEpi* pe) {
+  static const int mode = getenv("BX_CONV_C") ? atoi(getenv("BX_CONV_C")) : 1;
+  if (!mode || Ci % 64 || Co % 64) return -1;
+  const bool dgrad = mask || addend;
+  if (mode == 1 && (dgrad ? (Ci < 256 || Co < 256) : Co < 128)) return -1;
+  if (W <= 16) {
+    const long long wgs = (long long)((H + 7) / 8) * B * (Co / 64);
+    if (B % 2 == 0 && wgs / 2 >= 256) return launch_conv_c<1, 16, 2>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe);
+    return launch_conv_c<1, 16, 1>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe);
+  }
+  return launch_conv_c<1, 32, 1>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe);
 }
 // Tile choice: small late-stage maps would launch fewer workgroups than the chip has CUs (each then serialises its
 // own stage -> MFMA chain); prefer 8x16 pixel tiles and fewer output channels per workgroup until >= 512 are in flight.
 template <int CK, int NC>
 static int launch_conv_tw(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
-                          int B, int H, int W, int Ci, int Co, int relu, hipStream_t s) {
+                          int B, int H, int W, int Ci, int Co, int relu, hipStream_t s, BxConvPoolEpi* pe = nullptr) {
   // 8x32 tiles wherever the map is wide enough: a workgroup re-reads its whole weight slab from L2 per pixel tile, so
   // twice the pixels per tile halves the dominant L2 traffic of the late stages (measured: 16x32 maps 22.4 -> 17.3 us)
-  if (W <= 16) return launch_conv<CK, NC, 16>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
-  return launch_conv<CK, NC, 32>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
+  if (W <= 16) return launch_conv<CK, NC, 16>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe);
+  return launch_conv<CK, NC, 32>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe);
 }
 template <int CK>
 static int launch_conv_nc(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
-                          int B, int H, int W, int Ci, int Co, int relu, hipStream_t s) {
+                          int B, int H, int W, int Ci, int Co, int relu, hipStream_t s, BxConvPoolEpi* pe = nullptr) {
   // output channels per workgroup: 64 while that still launches >= 512 workgroups, else 32 (keeps two per CU in flight)
   const int tw = W <= 16 ? 16 : 32;
   const long long tiles = (long long)((W + tw - 1) / tw) * ((H + 7) / 8) * B;
   static const long long nc4_min = getenv("BX_CONV_NC4_MIN") ? atoll(getenv("BX_CONV_NC4_MIN")) : 512;
-  if (Co % 64 == 0 && tiles * (Co / 64) >= nc4_min) return launch_conv_tw<CK, 4>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
-  if (Co % 32 == 0) return launch_conv_tw<CK, 2>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
-  return launch_conv_tw<CK, 1>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s);
+  if (Co % 64 == 0 && tiles * (Co / 64) >= nc4_min) return launch_conv_tw<CK, 4>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe);
+  if (Co % 32 == 0) return launch_conv_tw<CK, 2>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe);
+  return launch_conv_tw<CK, 1>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe);
 }
 int bx_conv3x3_mfma_launch(const void* x, const void* packed_mfma, const float* bias, const void* relu_mask_src,
                            const void* addend, void* y, int B, int H, int W, int Ci, int Co, int flags, hipStream_t s) {
@@ -668,11 +1156,31 @@ int bx_conv3x3_mfma_launch(const void* x, const void* packed_mfma, const float* 
     if (Ci == 128) return launch_conv_ks<2>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Co, relu, s);
     if (Ci == 256) return launch_conv_ks<4>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Co, relu, s);
   }
+  {
+    const int rc = try_conv_c(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s, nullptr);
+    if (rc >= 0) return rc;
+  }
   switch (mfma_ck(Ci)) {
     case 8:  return launch_conv_nc<8>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s);
     case 16: return launch_conv_nc<16>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s);
     case 32: return launch_conv_nc<32>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s);
     default: return launch_conv_nc<64>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s);
+  }
+}
+
+// conv3 of a Block: y = relu(conv + bias), pooled = pool2x2(y), batch statistics of pooled (+ finalize) -- one launch
+int bx_conv3x3_mfma_pool_launch(const void* x, const void* packed_mfma, const float* bias, void* y, int B, int H, int W, int Ci, int Co,
+                                BxConvPoolEpi* pe, hipStream_t s) {
+  BX_REQUIRE((size_t)B * H * W * (Ci > Co ? Ci : Co) * 2 < ((size_t)1 << 31), "bx_conv3x3(pooled): an activation tensor of 2 GiB or more is not supported");
+  BX_REQUIRE(Ci >= 16 && pe && pe->pooled, "bx_conv3x3(pooled): needs at least 16 input channels and a pooled output");
+  {
+    const int rc = try_conv_c(x, packed_mfma, bias, nullptr, nullptr, y, B, H, W, Ci, Co, 1, s, pe);
+    if (rc >= 0) return rc;
+  }
+  switch (mfma_ck(Ci)) {
+    case 16: return launch_conv_nc<16>(x, packed_mfma, bias, nullptr, nullptr, y, B, H, W, Ci, Co, 1, s, pe);
+    case 32: return launch_conv_nc<32>(x, packed_mfma, bias, nullptr, nullptr, y, B, H, W, Ci, Co, 1, s, pe);
+    default: return launch_conv_nc<64>(x, packed_mfma, bias, nullptr, nullptr, y, B, H, W, Ci, Co, 1, s, pe);
   }
 }
 

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_specreg_stats(const float* __restrict__
   const int o = offsets ? offsets[b] / 2 : 0;
   const float* src = raw + (size_t)b * Trows * C;
   double sum = 0.0, mn = INFINITY, mx = -INFINITY;
-  long long cnt = 0, nnan = 0;
+  long long cnt = 0;
   const long long n = (long long)win * C;
   for (long long i0 = tid; i0 < n; i0 += 256 * 8) {
     float v[8];
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_specreg_stats(const float* __restrict__
     for (int u = 0; u < 8; ++u) {
       if (i0 + (long long)u * 256 >= n) continue;
       const double d = (double)v[u];
-      if (d == d) { sum += d; ++cnt; mn = fmin(mn, d); mx = fmax(mx, d); } else ++nnan;
+      if (d == d) { sum += d; ++cnt; mn = fmin(mn, d); mx = fmax(mx, d); }
     }
   }
   ssum[tid] = sum; scnt[tid] = cnt; smin[tid] = mn; smax[tid] = mx;

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_pool_stats(const T* __restrict__ y3, T*
   if (tree.cnt) {                                       // the last workgroup to arrive finalizes (no k_bn_finalize launch)
     double tot[2];
     __syncthreads();                                    // block_channel_reduce's LDS reads are done
-    if (bx_stat_tree_arrive<2>(tree, 0, blockIdx.x, red, tot, reinterpret_cast<char*>(lds)) && (int)threadIdx.x < g.C)
+    if (bx_stat_tree_arrive<2>(tree, 0, 0, blockIdx.x, red, tot, reinterpret_cast<char*>(lds)) && (int)threadIdx.x < g.C)
       bx_bn_finalize_channel(threadIdx.x, tot[0], tot[1], fin);
     return;
   }
@@ -258,11 +258,26 @@ __global__ __launch_bounds__(256, 4) void k_tail_apply(const T* __restrict__ poo
   }
 }
 
+static int g_tree_max_rows = -1;
+int bx_tree_max_rows() {
+  if (g_tree_max_rows < 0) { const char* e = getenv("BX_TREE_MAX_ROWS"); g_tree_max_rows = e ? atoi(e) : 0; }
+  return g_tree_max_rows;
+}
+extern "C" int bx_set_tree_max_rows(int rows) {
+  BX_REQUIRE(rows >= 0, "bx_set_tree_max_rows: rows must be >= 0");
+  g_tree_max_rows = rows;
+  return BX_OK;
+}
+// rows of forward partial sums: the pooling kernel writes at most TAIL_MAX_BLOCKS, conv3's pooled epilogue one per 8 x 16 (or larger) tile
+static size_t tail_rows_cap(const bxTailDesc* d) {
+  const size_t conv_rows = (size_t)d->B * ((d->H + 7) / 8) * ((d->W + 15) / 16);
+  return conv_rows > TAIL_MAX_BLOCKS ? conv_rows : TAIL_MAX_BLOCKS;
+}
 extern "C" size_t bx_block_tail_workspace(const bxTailDesc* d) {
   TailGeom g;
   if (!d || make_geom(d, &g)) return 0;
   const size_t Ho = d->H / 2, Wo = d->W / 2;
-  size_t fwd = ((size_t)TAIL_MAX_BLOCKS * 2 + 2) * d->C * sizeof(float) + (size_t)d->Cin_p * d->C * sizeof(float)
+  size_t fwd = ((size_t)tail_rows_cap(d) * 2 + 2) * d->C * sizeof(float) + (size_t)d->Cin_p * d->C * sizeof(float)
              + (size_t)TAIL_MAX_GROUPS * 2 * d->C * sizeof(double);                                  // reduction-tree group sums
   size_t bwd = ((size_t)TAIL_MAX_BLOCKS * 3 + 3) * d->C * sizeof(float)                 // partials + coefficients
              + bx_align_up((size_t)d->B * Ho * Wo * d->Cin_p * sizeof(float), 256)       // dXs (half-res, fp32)
@@ -291,16 +306,16 @@ extern "C" int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void
   hipStream_t s = (hipStream_t)stream;
   const int nblk = tail_blocks(g);
   float* partials = (float*)workspace;
-  float* scale = partials + (size_t)TAIL_MAX_BLOCKS * 2 * g.C;
+  float* scale = partials + tail_rows_cap(d) * 2 * g.C;
   float* shift = scale + g.C;
   float* wT = shift + g.C;
   const float p = d->training ? d->dropout_p : 0.f;
   // with d->sync the statistics finalize rides in the pooling kernel (last workgroup to arrive, see BxStatTree)
-  const bool in_launch = d->training && d->sync && g.C <= 256 && 256 % g.C == 0;
+  const bool in_launch = d->training && d->sync && 256 % g.C == 0 && nblk <= bx_tree_max_rows();
   BxStatTree tree = {};
   BxBnFinalize fin = {};
   if (in_launch) {
-    tree.rows = partials; tree.cnt = d->sync + BX_TAIL_SYNC_FWD; tree.nrows = nblk; tree.Cw = g.C;
+    tree.rows = partials; tree.cnt = d->sync + BX_TAIL_SYNC_FWD; tree.nrows = nblk; tree.Cw = tree.ld = g.C;
     bx_stat_tree_shape(nblk, &tree.G, &tree.ngroups);
     tree.mid = (double*)(wT + (size_t)g.Cin_p * g.C);                     // ngroups x 2 x C doubles (workspace formula)
     BX_REQUIRE(tree.ngroups + 1 <= BX_TAIL_SYNC_BWD - BX_TAIL_SYNC_FWD, "bx_block_tail_fwd: %d reduction groups exceed the sync block", tree.ngroups);
@@ -322,6 +337,58 @@ extern "C" int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void
                        scale, shift, seed, p, d->salt, (T*)out, g, ev ? bn_weight : (const float*)nullptr, bn_bias, (const float*)running_mean,
                        (const float*)running_var, d->eps, save_mean, save_invstd));
   BX_CHECK_LAUNCH("bx_block_tail_fwd(apply)");
+  return BX_OK;
+}
+
+// conv3 + tail forward in two launches (bf16 MFMA path): conv3's epilogue pools the tile it holds in registers, sums the batch
+// statistics and (last workgroup per channel group) finalizes them; the apply kernel follows.  Replaces conv3 -> k_pool_stats ->
+// k_bn_finalize -> k_tail_apply: the 2x2 pool no longer re-reads conv3's output from HBM.
+extern "C" int bx_block_conv3_tail_fwd(const bxTailDesc* d, const void* y2, const void* w3_mfma, const float* b3, void* y3,
+                                       const void* x, const float* w1x1, int Cin, const float* b1x1, const float* bn_weight, const float* bn_bias,
+                                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                       const uint64_t* seed, void* pooled, void* out, float* save_mean, float* save_invstd,
+                                       void* workspace, size_t workspace_bytes, bxStream stream) {
+  BX_REQUIRE(d && y2 && w3_mfma && b3 && y3 && x && w1x1 && b1x1 && bn_weight && bn_bias && running_mean && running_var && pooled && out && save_mean
+             && save_invstd, "bx_block_conv3_tail_fwd: null pointer");
+  if (d->dtype != BX_BF16 || !bx_conv3x3_mfma_supported(d->C, d->C, d->dtype) || d->C < 16)
+    BX_FAIL(BX_EUNSUPPORTED, "bx_block_conv3_tail_fwd: needs bf16 storage and an MFMA-capable channel count (C=%d dtype=%d)", d->C, d->dtype);
+  TailGeom g;
+  const int ge = make_geom(d, &g);
+  BX_REQUIRE(ge == 0, "bx_block_conv3_tail_fwd: unsupported geometry (code %d)", ge);
+  BX_REQUIRE(Cin > 0 && Cin <= d->Cin_p, "bx_block_conv3_tail_fwd: Cin=%d exceeds Cin_p=%d", Cin, d->Cin_p);
+  BX_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "bx_block_conv3_tail_fwd: dropout_p must be in [0,1)");
+  BX_REQUIRE(d->dropout_p == 0.f || !d->training || seed, "bx_block_conv3_tail_fwd: dropout needs a device seed");
+  const size_t need = bx_block_tail_workspace(d);
+  if (!workspace || workspace_bytes < need) BX_FAIL(BX_EWORKSPACE, "bx_block_conv3_tail_fwd: workspace %zu < %zu", workspace_bytes, need);
+  const size_t xs_bytes = (size_t)g.slots * (g.Cin_p + 1) * sizeof(float);
+  BX_REQUIRE(xs_bytes <= 60 * 1024, "bx_block_conv3_tail_fwd: Cin_p too large for the LDS tile");
+  hipStream_t s = (hipStream_t)stream;
+  float* partials = (float*)workspace;
+  float* scale = partials + tail_rows_cap(d) * 2 * g.C;
+  float* shift = scale + g.C;
+  float* wT = shift + g.C;
+  BxConvPoolEpi pe = {};
+  pe.pooled = pooled; pe.pool = d->pool; pe.want_stats = d->training; pe.Ho = g.Ho; pe.Wo = g.Wo;
+  pe.w1x1 = w1x1; pe.wT = wT; pe.Cin1 = Cin; pe.Cin1_p = g.Cin_p;
+  if (d->training) {
+    pe.tree.rows = partials; pe.tree.mid = (double*)(wT + (size_t)g.Cin_p * g.C); pe.tree.cnt = d->sync ? d->sync + BX_TAIL_SYNC_FWD : nullptr;
+    pe.rows_cap_floats = tail_rows_cap(d) * 2 * g.C; pe.cnt_cap_words = BX_TAIL_SYNC_BWD - BX_TAIL_SYNC_FWD; pe.tree_max_rows = bx_tree_max_rows();
+    pe.fin = BxBnFinalize{bn_weight, bn_bias, running_mean, running_var, num_batches_tracked, d->momentum, d->eps, scale, shift, save_mean, save_invstd,
+                          (double)g.npool};
+  }
+  const int rc = bx_conv3x3_mfma_pool_launch(y2, w3_mfma, b3, y3, d->B, d->H, d->W, d->C, d->C, &pe, s);
+  if (rc != BX_OK) return rc;
+  if (d->training && !pe.tree.cnt) {                    // many partial rows: the separate finalize launch (its workgroups split the channels)
+    hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.C)), dim3(1024), 0, s, partials, pe.tree.nrows, (double)g.npool, g.C, 1, bn_weight, bn_bias,
+                       running_mean, running_var, num_batches_tracked, d->momentum, d->eps, scale, shift, save_mean, save_invstd);
+    BX_CHECK_LAUNCH("bx_block_conv3_tail_fwd(finalize)");
+  }
+  const float p = d->training ? d->dropout_p : 0.f;
+  const bool ev = !d->training;
+  hipLaunchKernelGGL((k_tail_apply<bf16_t, 8>), dim3(tail_blocks_all(g)), dim3(256), xs_bytes, s, (const bf16_t*)pooled, (const bf16_t*)x, wT, Cin, b1x1,
+                     scale, shift, seed, p, d->salt, (bf16_t*)out, g, ev ? bn_weight : (const float*)nullptr, bn_bias, (const float*)running_mean,
+                     (const float*)running_var, d->eps, save_mean, save_invstd);
+  BX_CHECK_LAUNCH("bx_block_conv3_tail_fwd(apply)");
   return BX_OK;
 }
 
@@ -378,7 +445,7 @@ __device__ __forceinline__ void tail_bwd_reduce_body(const T* __restrict__ dout,
   if (tree.cnt) {                                       // the last reduction workgroup to arrive finalizes (no mid launch)
     double tot[3];
     __syncthreads();
-    if (bx_stat_tree_arrive<3>(tree, 0, bid, red, tot, reinterpret_cast<char*>(lds)) && (int)threadIdx.x < g.C)
+    if (bx_stat_tree_arrive<3>(tree, 0, 0, bid, red, tot, reinterpret_cast<char*>(lds)) && (int)threadIdx.x < g.C)
       tail_bwd_finalize_channel(threadIdx.x, g.C, tot, fin);
     return;
   }
@@ -911,11 +978,11 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
   const int n_dxs = !dx_skip ? 0 : mf ? bx_ceil_div(g.npool, skip_mfma_pixels(mf)) : bx_ceil_div(g.npool * (g.Cin_p / (narrow ? 4 : 8)), 256);
   const int n_w = nchunk * wg_y * wg_z;
   const size_t front_lds = (dx_skip && !mf) ? (size_t)64 * g.Cin_p * sizeof(float) : 0;
-  const bool in_launch = d->sync && 256 % g.C == 0;
+  const bool in_launch = d->sync && 256 % g.C == 0 && nblk <= bx_tree_max_rows();
   BxStatTree tree = {};
   TailBwdFin fin = {};
   if (in_launch) {
-    tree.rows = partials; tree.cnt = d->sync + BX_TAIL_SYNC_BWD; tree.nrows = nblk; tree.Cw = g.C;
+    tree.rows = partials; tree.cnt = d->sync + BX_TAIL_SYNC_BWD; tree.nrows = nblk; tree.Cw = tree.ld = g.C;
     bx_stat_tree_shape(nblk, &tree.G, &tree.ngroups);
     tree.mid = (double*)((char*)workspace + bx_align_up(bx_block_tail_workspace(d) - (size_t)TAIL_MAX_GROUPS * 3 * g.C * sizeof(double), 8));
     BX_REQUIRE(tree.ngroups + 1 <= BX_TAIL_SYNC_WORDS - BX_TAIL_SYNC_BWD, "bx_block_tail_bwd: %d reduction groups exceed the sync block", tree.ngroups);

@@ -334,6 +334,8 @@ def _conv(x, packed, bias, mask_src, addend, relu: bool, dtype):
 WGRAD_CHAIN = _os.environ.get("BX_WGRAD_CHAIN", "1") == "1"
 # batch-statistics finalizes inside the kernels that produce the partial sums (bxTailDesc.sync); 0 = separate finalize launches
 TAIL_IN_LAUNCH = _os.environ.get("BX_TAIL_IN_LAUNCH", "1") == "1"
+# conv3 of a Block pools and sums the batch statistics in its epilogue (bx_block_conv3_tail_fwd); 0 = conv3, then the pooling kernel
+FUSE_POOL = _os.environ.get("BX_FUSE_POOL", "1") == "1"
 _WG_CHAIN = {}
 
 
@@ -413,10 +415,18 @@ class BlockFn(torch.autograd.Function):
         dt = x.dtype
         ws_, bs_ = (w1, w2, w3), (b1, b2, b3)
         acts, pre = [x], None
+        B, H, W, _ = x.shape
+        Cc = w3.shape[0]
+        # conv3 with the pool and the batch statistics in its epilogue (two launches for conv3 + tail instead of four)
+        fused = FUSE_POOL and dt == torch.bfloat16 and CONV_ALGO != L.BX_ALGO_DIRECT and cfg.preact != 3 and Cc >= 16 and CONV_PROFILE is None
+        packed3 = None
         for k in range(3):
             packed = cfg.prepacked.get(cfg.pack_base + k, False) if cfg.prepacked is not None else None
             if packed is None:
                 packed = _pack(ws_[k], flip=False, dtype=dt)
+            if k == 2 and fused and packed[1] is not None:
+                packed3 = packed
+                break
             if cfg.preact == k + 1:
                 pre = _conv(acts[-1], packed, bs_[k], None, None, False, dt)
                 y = torch.empty_like(pre)
@@ -424,9 +434,6 @@ class BlockFn(torch.autograd.Function):
             else:
                 y = _conv(acts[-1], packed, bs_[k], None, None, True, dt)
             acts.append(y)
-        y3 = acts[3]
-        B, H, W, Cc = y3.shape
-        desc = _tail_desc(x, y3, cfg)
         seed = None
         if cfg.training and cfg.dropout_p > 0:
             seed = cfg.seed if cfg.seed is not None else next_seed(x.device)       # the model hands one seed to all stages (salts differ)
@@ -434,9 +441,20 @@ class BlockFn(torch.autograd.Function):
         out = torch.empty_like(pooled)
         mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
         invstd = torch.empty_like(mean)
-        ws = workspace(lib.bx_block_tail_workspace(C.byref(desc)), x.device)
-        L.check(lib.bx_block_tail_fwd(C.byref(desc), _p(y3), _p(x), _p(w11), w11.shape[1], _p(b11), _p(bnw), _p(bnb), _p(rm), _p(rv), _p(nbt),
-                                      _p(seed), _p(pooled), _p(out), _p(mean), _p(invstd), _p(ws), ws.numel(), _stream()), "bx_block_tail_fwd")
+        if packed3 is not None:
+            y3 = torch.empty(B, H, W, Cc, dtype=dt, device=x.device)
+            desc = _tail_desc(x, y3, cfg)
+            ws = workspace(lib.bx_block_tail_workspace(C.byref(desc)), x.device)
+            L.check(lib.bx_block_conv3_tail_fwd(C.byref(desc), _p(acts[2]), _p(packed3[1]), _p(b3), _p(y3), _p(x), _p(w11), w11.shape[1], _p(b11),
+                                                _p(bnw), _p(bnb), _p(rm), _p(rv), _p(nbt), _p(seed), _p(pooled), _p(out), _p(mean), _p(invstd),
+                                                _p(ws), ws.numel(), _stream()), "bx_block_conv3_tail_fwd")
+            acts.append(y3)
+        else:
+            y3 = acts[3]
+            desc = _tail_desc(x, y3, cfg)
+            ws = workspace(lib.bx_block_tail_workspace(C.byref(desc)), x.device)
+            L.check(lib.bx_block_tail_fwd(C.byref(desc), _p(y3), _p(x), _p(w11), w11.shape[1], _p(b11), _p(bnw), _p(bnb), _p(rm), _p(rv), _p(nbt),
+                                          _p(seed), _p(pooled), _p(out), _p(mean), _p(invstd), _p(ws), ws.numel(), _stream()), "bx_block_tail_fwd")
         ctx.cfg, ctx.desc, ctx.seed = cfg, desc, seed
         ctx.save_for_backward(x, acts[1], acts[2], y3, pooled, mean, invstd, w1, b1, w2, b2, w3, b3, bnw, bnb, w11, b11)
         if pre is not None:

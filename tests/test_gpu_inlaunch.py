@@ -5,6 +5,7 @@ import pytest
 import torch
 
 import brainxai
+from brainxai import _lib as L
 from brainxai import ops
 
 pytestmark = pytest.mark.gpu
@@ -14,10 +15,11 @@ DEV = torch.device("cuda:0")
 CASES = [(4, 16, 16, 128, 128), (16, 32, 8, 32, 64), (128, 256, 4, 8, 16), (64, 128, 6, 16, 32)]
 
 
-def _run(in_launch, dtype, case, pool):
+def _run(in_launch, dtype, case, pool, fuse_pool=False, max_rows=1 << 20):
     cin, cout, batch, h, w = case
-    old = ops.TAIL_IN_LAUNCH
-    ops.TAIL_IN_LAUNCH = in_launch
+    old = ops.TAIL_IN_LAUNCH, ops.FUSE_POOL
+    ops.TAIL_IN_LAUNCH, ops.FUSE_POOL = in_launch, fuse_pool
+    L.check(L.load().bx_set_tree_max_rows(max_rows), "bx_set_tree_max_rows")      # the default policy (0) never finalizes in-launch
     try:
         torch.manual_seed(3)
         blk = brainxai.Block(cin, cout, pool, (2, 2), dropout_p=0.25).to(DEV).train()
@@ -38,7 +40,8 @@ def _run(in_launch, dtype, case, pool):
             assert blk._sync is None
         return outs
     finally:
-        ops.TAIL_IN_LAUNCH = old
+        ops.TAIL_IN_LAUNCH, ops.FUSE_POOL = old
+        L.load().bx_set_tree_max_rows(0)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -47,13 +50,34 @@ def test_in_launch_finalize_equals_separate_launches(case, dtype):
     pool = "max" if case[0] % 3 else "avg"
     a = _run(True, dtype, case, pool)
     b = _run(False, dtype, case, pool)
+    _compare(a, b, dtype)
+
+
+@pytest.mark.parametrize("pool", ["max", "avg"])
+@pytest.mark.parametrize("case", CASES + [(16, 16, 5, 18, 34), (32, 64, 3, 9, 50)])
+def test_conv3_pooled_epilogue_equals_pooling_kernel(case, pool):
+    """bf16: conv3 with the 2x2 pool + batch statistics in its epilogue (bx_block_conv3_tail_fwd) against conv3 followed by the
+    pooling kernel; pooled values are bit-identical by construction (same stored inputs, same order of additions), the statistics
+    differ by the grouping of the double sums only.  The ragged cases have odd H/W remainders and tiles that leave the image."""
+    a = _run(True, torch.bfloat16, case, pool, fuse_pool=True)
+    b = _run(True, torch.bfloat16, case, pool, fuse_pool=False)
+    _compare(a, b, torch.bfloat16)
+    c = _run(True, torch.bfloat16, case, pool, fuse_pool=True, max_rows=0)       # pooled epilogue writes rows, separate finalize launch
+    _compare(c, b, torch.bfloat16)
+
+
+def _compare(a, b, dtype):
     for it, (ra, rb) in enumerate(zip(a, b)):
         for k, (ta, tb) in enumerate(zip(ra, rb)):
             ta, tb = ta.double(), tb.double()
             scale = float(tb.abs().max()) + 1e-30
             err = float((ta - tb).abs().max()) / scale
-            # statistics differ by double-rounding only; in bf16 a one-ulp change of (scale, shift) may move a stored bf16 value
+            # statistics differ by double-rounding only; in bf16 a one-ulp change of (scale, shift) may move a few stored bf16 values,
+            # and every gradient downstream is a sum over those
             tol = 1e-6 if dtype == torch.float32 else 2e-2
             assert err <= tol, (it, k, err)
             if dtype == torch.bfloat16:
-                assert float((ta != tb).double().mean()) < 1e-3, (it, k)
+                if k == 0:
+                    assert float((ta != tb).double().mean()) < 1e-3, (it, k)
+                else:
+                    assert float((ta - tb).norm() / (tb.norm() + 1e-30)) < 2e-3, (it, k)

@@ -72,7 +72,8 @@ def test_conv_mfma_two_image_tiles(cin, cout, batch):
         assert rel_err(outs["mfma"][i], outs["direct"][i]) < 8e-3, i
 
 
-@pytest.mark.parametrize("cin,cout,h,w", [(16, 16, 12, 20), (32, 16, 9, 33), (64, 32, 8, 16), (128, 64, 6, 7), (256, 128, 4, 8)])
+@pytest.mark.parametrize("cin,cout,h,w", [(16, 16, 12, 20), (32, 16, 9, 33), (64, 32, 8, 16), (128, 64, 6, 7), (256, 128, 4, 8), (256, 256, 8, 16),
+                                              (256, 256, 11, 37)])
 def test_conv_mfma_data_gradient_epilogue(cin, cout, h, w):
     """flip/transpose pack + ReLU-mask + addend epilogue: dX = conv(dZ, W^T flipped) * (Y > 0) + A"""
     torch.manual_seed(7 + cin)

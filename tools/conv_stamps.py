@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""In-kernel timeline of k_wgrad_own (diagnostic build, never the shipped library): compiles conv3x3_mfma.hip with
+-DBX_CONV_STAMPS into a scratch .so, runs one weight-gradient launch per shape and prints, for the sampled workgroups, the
+shader-clock deltas between: start -> first tile staged -> end of tile 0..3 -> partial stored (s_memtime ticks = shader cycles).
+
+    python tools/wgrad_stamps.py            (on the GPU box)
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = os.path.join(ROOT, "multimodal-brain-pattern-identification_xai_amd")
+out = "/tmp/libbrainxai_cstamps.so"
+srcs = ["core.hip", "conv3x3.hip", "conv3x3_mfma.hip", "tail.hip", "heads.hip", "eeg.hip", "eeg_mfma.hip", "eeg_deep.hip", "attrib.hip", "montage.hip", "specprep.hip"]
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-DBX_CONV_STAMPS", "-shared",
+                       *[os.path.join(PKG, "csrc", f) for f in srcs], "-o", out])
+import torch  # noqa: E402
+import brainxai  # noqa: E402
+from brainxai import _lib as L, ops  # noqa: E402
+L.LIB_PATH = out
+L._lib = None
+lib = L.load()
+lib.bx_debug_conv_stamps.restype = C.c_int
+lib.bx_debug_conv_stamps.argtypes = [C.c_void_p]
+dev = torch.device("cuda:0")
+for (H, W, ci, co) in ((32, 64, 64, 64), (16, 32, 128, 128), (8, 16, 128, 256), (8, 16, 256, 256)):
+    B = 64
+    x = torch.randn(B, H, W, ci, device=dev).bfloat16()
+    w = torch.randn(co, ci, 3, 3, device=dev) / (3 * ci ** 0.5)
+    bias = torch.zeros(co, device=dev)
+    packed = ops._pack(w, False, torch.bfloat16)
+    for _ in range(3):
+        ops._conv(x, packed, bias, None, None, True, torch.bfloat16)
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 512)()
+    assert lib.bx_debug_conv_stamps(C.cast(buf, C.c_void_p)) == 0
+    nch = min(4, ci // 64)
+    rows = [[buf[i * 8 + k] for k in range(7)] for i in range(64)]
+    rows = [r for r in rows if r[0] and r[6] > r[0]]
+    t0 = min(r[0] for r in rows)
+    print(f"== {H}x{W} {ci}->{co}: {len(rows)} sampled workgroups; columns: start offset | staged | chunk0..{nch - 1} | epilogue (cycles)")
+    for r in rows[:10]:
+        seq = [r[0], r[1]] + [r[2 + k] for k in range(nch)] + [r[6]]
+        d = [r[0] - t0] + [seq[k + 1] - seq[k] for k in range(len(seq) - 1)]
+        print("   " + " ".join(f"{v:8d}" for v in d))
+    life = sorted(r[6] - r[0] for r in rows)
+    print(f"   workgroup lifetime: median {life[len(life) // 2]} cycles, max {life[-1]}; last end - first start {max(r[6] for r in rows) - t0}")
