@@ -311,6 +311,9 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
       }
     }
     __syncthreads();
+    // Measured here and dropped (round 2): a pinned read-ahead ring for the pixel fragments as in k_conv_mfma_c (every shape 3-5 %
+    // slower: with NC >= 2 MFMAs per fragment and 2-4 waves per SIMD the scheduler's own order already hides the LDS latency), and
+    // requesting the bias before the chunk loop instead of in the epilogue (no change; 4-60 more registers).
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       if (s + 2 < KS) load_a(s + 2, a[(s + 2) % 3]);
