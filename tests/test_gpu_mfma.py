@@ -205,3 +205,46 @@ def test_wgrad_chained_reduce_matches_immediate():
     assert rc != 0
     L.check(lib.bx_conv3x3_wgrad_finish(ctypes.byref(pend), 0), "finish")
     torch.cuda.synchronize()
+
+
+# the benchmark's stage shapes at its full batch: (cin, cout, H, W)
+BENCH_LAYERS = [(16, 16, 128, 256), (16, 32, 64, 128), (32, 32, 64, 128), (32, 64, 32, 64), (64, 64, 32, 64), (64, 128, 16, 32),
+                (128, 128, 16, 32), (128, 256, 8, 16), (256, 256, 8, 16)]
+
+
+@pytest.mark.parametrize("cin,cout,h,w", BENCH_LAYERS)
+def test_conv_family_adjoint_identity_at_bench_size(cin, cout, h, w):
+    """Size-independent property at BASELINE's full batch (B=64), every stage shape, the kernels the benchmark actually launches:
+    forward, data-gradient and weight-gradient kernels are three views of ONE trilinear form,
+        <conv(x, w), dz>  ==  <x, conv^T(dz, w)>  ==  <w, wgrad(x, dz)>,
+    so an indexing slip in any tile variant (two-image tiles, channel-split waves, persistent tiles, split reductions) breaks an
+    equality that no oracle run is needed for.  All operands are positive, so the form is of the order of its norm bound and a
+    misplaced or missing tile shifts it by its share of the elements; bf16 outputs carry 2^-9 relative rounding per element,
+    unbiased, which over 10^7..10^8 terms is ~1e-6 of the sum; the weight-gradient side is fp32."""
+    B = 64
+    g = torch.Generator(device="cpu").manual_seed(cin * 7 + cout + h)
+    x = ops.to_nhwc(torch.rand(B, cin, h, w, generator=g).to(DEV), torch.bfloat16)
+    dz = ops.to_nhwc(torch.rand(B, cout, h, w, generator=g).to(DEV), torch.bfloat16)
+    wt = _bf(torch.rand(cout, cin, 3, 3, generator=g) / (9 * cin)).to(DEV)
+    y = ops._conv(x, ops._pack(wt, False, torch.bfloat16), None, None, None, False, torch.bfloat16)
+    dx = ops._conv(dz, ops._pack(wt, True, torch.bfloat16), None, None, None, False, torch.bfloat16)
+    lib = L.load()
+    dw, db = torch.empty(cout, cin, 3, 3, device=DEV), torch.empty(cout, device=DEV)
+    need = lib.bx_conv3x3_wgrad_workspace(B, h, w, x.shape[3], cout, L.BX_BF16, L.BX_ALGO_AUTO)
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    L.check(lib.bx_conv3x3_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), db.data_ptr(), B, h, w, cin, x.shape[3], cout, L.BX_BF16,
+                                 L.BX_ALGO_AUTO, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "wgrad")
+    a = float((y.double() * dz.double()).sum())
+    b = float((x.double() * dx.double()).sum())
+    c = float((wt.double() * dw.double()).sum())
+    assert a > 0.5 * float(y.double().norm() * dz.double().norm())  # positive operands: the form is of the order of its bound
+    # observed: the three agree to 1.4e-5 .. 3.1e-5 with a fixed sign (sums of same-sign terms in the MFMA's fp32 accumulator are
+    # not unbiased); a tile pattern that drops or misplaces 1e-3 of the elements moves a side by ~1e-3
+    print(f"[adjoint] {cin}->{cout} {h}x{w}: <y,dz>={a:.6e} <x,dx>/<y,dz>-1={b / a - 1:+.2e} <w,dw>/<y,dz>-1={c / a - 1:+.2e}")
+    assert abs(a - c) <= 1e-4 * a, (a, c)
+    assert abs(a - b) <= 1e-4 * a, (a, b)
+    if h * w <= 512:                                                # anchor the late stages to an fp64 evaluation of the same form
+        xd = ops.to_nchw_f32(x, cin).double()
+        e = float((F.conv2d(xd, wt.double(), padding=1) * ops.to_nchw_f32(dz, cout).double()).sum())
+        assert max(abs(a - e), abs(b - e), abs(c - e)) <= 1e-4 * e, (a, b, c, e)
+    assert abs(float(db.double().sum()) - float(dz.double().sum())) <= 1e-5 * float(dz.double().abs().sum())
