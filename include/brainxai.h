@@ -103,6 +103,13 @@ int bx_conv3x3_wgrad_chained(const void* x, const void* dz, float* dw_oihw, floa
                              int Ci_p, int Co, int dtype, int algo, void* workspace, size_t workspace_bytes,
                              bxWgradPending* pending, bxStream stream);
 int bx_conv3x3_wgrad_finish(bxWgradPending* pending, bxStream stream);
+/* bx_conv3x3 that also ends a weight-gradient chain: a valid *pending is summed by extra workgroups of THIS launch (the
+ * last weight gradient of a Block's backward is followed by that layer's data gradient, which then carries the sum
+ * instead of a reduce launch of its own); *pending is invalid on return.  Paths that cannot carry it (fp32 / direct
+ * kernels) finish the chain with a separate launch first.  Same arguments and results as bx_conv3x3 otherwise. */
+int bx_conv3x3_carry(const void* x, const float* packed_f32, const void* packed_mfma, const float* bias,
+                     const void* relu_mask_src, const void* addend, void* y, int B, int H, int W, int Ci, int Co,
+                     int dtype, int flags, int algo, bxWgradPending* pending, bxStream stream);
 
 /* ---- Block tail: 2x2 pool -> BatchNorm2d -> Dropout -> + conv1x1(bilinear(x))  (M:67-76) ------ */
 typedef struct {

@@ -78,6 +78,7 @@ SIGNATURES = {
     "bx_scale_dev": (i32, [vp, vp, vp, sz, vp]),
     "bx_abs": (i32, [vp, vp, sz, vp]),
     "bx_conv3x3": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "bx_conv3x3_carry": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, P(WgradPending), vp]),
     "bx_conv3x3_wgrad_workspace": (sz, [i32, i32, i32, i32, i32, i32, i32]),
     "bx_conv3x3_wgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "bx_conv3x3_wgrad_chained": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, P(WgradPending), vp]),

@@ -7,7 +7,7 @@
 
 // implemented in conv3x3_mfma.hip
 int bx_conv3x3_mfma_launch(const void* x, const void* packed_mfma, const float* bias, const void* relu_mask_src,
-                           const void* addend, void* y, int B, int H, int W, int Ci, int Co, int flags, hipStream_t s);
+                           const void* addend, void* y, int B, int H, int W, int Ci, int Co, int flags, hipStream_t s, bxWgradPending* carry);
 int bx_conv3x3_mfma_supported(int Ci, int Co, int dtype);
 void bx_conv3x3_mfma_pack_launch(const float* w_oihw, void* packed, int Cout, int Cin, int I_p, int O_p, int tf, hipStream_t s);
 size_t bx_wgrad_mfma_workspace(int B, int H, int W, int Ci_p, int Co);
@@ -132,9 +132,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_direct(const T* __restrict__ x,
   }
 }
 
-extern "C" int bx_conv3x3(const void* x, const float* packed_f32, const void* packed_mfma, const float* bias,
-                          const void* relu_mask_src, const void* addend, void* y,
-                          int B, int H, int W, int Ci, int Co, int dtype, int flags, int algo, bxStream stream) {
+static int conv3x3_impl(const void* x, const float* packed_f32, const void* packed_mfma, const float* bias,
+                        const void* relu_mask_src, const void* addend, void* y,
+                        int B, int H, int W, int Ci, int Co, int dtype, int flags, int algo, bxWgradPending* carry, bxStream stream) {
   BX_DTYPE_OK(dtype);
   BX_REQUIRE(x && y && B > 0 && H > 0 && W > 0, "bx_conv3x3: bad arguments");
   BX_REQUIRE(Ci % 8 == 0 && Co % 8 == 0, "bx_conv3x3: Ci (%d) and Co (%d) must be multiples of 8 (pad the tensors)", Ci, Co);
@@ -144,7 +144,11 @@ extern "C" int bx_conv3x3(const void* x, const float* packed_f32, const void* pa
   if (algo == BX_ALGO_MFMA) {
     if (!packed_mfma || !bx_conv3x3_mfma_supported(Ci, Co, dtype))
       BX_FAIL(BX_EUNSUPPORTED, "bx_conv3x3: MFMA path needs bf16 storage, packed_mfma and Ci%%8==0, Co%%16==0 (Ci=%d Co=%d dtype=%d)", Ci, Co, dtype);
-    return bx_conv3x3_mfma_launch(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, flags, s);
+    return bx_conv3x3_mfma_launch(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, flags, s, carry);
+  }
+  if (carry && carry->valid) {                                 // the direct kernels cannot carry a reduce: finish the chain first
+    const int rc = bx_wgrad_mfma_finish(carry, s);
+    if (rc) return rc;
   }
   BX_REQUIRE(packed_f32, "bx_conv3x3: direct path needs packed_f32");
   const long long ngroups = (long long)B * H * ((W + 3) / 4);
@@ -154,6 +158,17 @@ extern "C" int bx_conv3x3(const void* x, const float* packed_f32, const void* pa
                        (const T*)relu_mask_src, (const T*)addend, (T*)y, B, H, W, Ci, Co, (flags & BX_EPI_RELU) ? 1 : 0));
   BX_CHECK_LAUNCH("bx_conv3x3(direct)");
   return BX_OK;
+}
+extern "C" int bx_conv3x3(const void* x, const float* packed_f32, const void* packed_mfma, const float* bias,
+                          const void* relu_mask_src, const void* addend, void* y,
+                          int B, int H, int W, int Ci, int Co, int dtype, int flags, int algo, bxStream stream) {
+  return conv3x3_impl(x, packed_f32, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, dtype, flags, algo, nullptr, stream);
+}
+extern "C" int bx_conv3x3_carry(const void* x, const float* packed_f32, const void* packed_mfma, const float* bias,
+                                const void* relu_mask_src, const void* addend, void* y,
+                                int B, int H, int W, int Ci, int Co, int dtype, int flags, int algo, bxWgradPending* pending, bxStream stream) {
+  BX_REQUIRE(pending, "bx_conv3x3_carry: pending is NULL");
+  return conv3x3_impl(x, packed_f32, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, dtype, flags, algo, pending, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

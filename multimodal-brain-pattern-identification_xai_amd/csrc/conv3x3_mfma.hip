@@ -148,6 +148,13 @@ extern "C" int bx_conv3x3_pack_many_layout(const bxPackJob* jobs_device, int njo
   return BX_OK;
 }
 
+// A pending weight-gradient partial sum (see k_wgrad_reduce3 below) can ride in a convolution launch as `nred` extra workgroups at
+// the front of grid.x (channel group 0 does the work, the others leave): the last weight gradient of a Block's backward is
+// followed by that layer's data gradient, whose launch then carries the sum instead of a k_wgrad_reduce3 launch of its own.
+struct WgradRedJob { const float* partial; float* dw; float* db; int nsplit, Cin, Co, S, MA, NB, ztiles, nfrag4, nblocks; };
+__device__ __forceinline__ void wgrad_reduce3_body(const WgradRedJob& jb, int bid, float4* sm);
+static WgradRedJob wgrad_job_from(const bxWgradPending* pd, bool chained);
+
 template <int CK>
 __device__ __forceinline__ int lds_chunk(int c, int p) {
   if (CK == 32) return c ^ ((p >> 1) & 3);
@@ -248,13 +255,18 @@ __device__ __forceinline__ void conv_pool_transpose_w1x1(const BxConvPoolEpi& pe
 template <int CK, int NC, int TW, int IMGS = 1, bool POOL = false>
 __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const bf16_t* __restrict__ mask_src, const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
-    int H, int W, int Ci, int Co, int relu, int tiles_x, int tiles_y, uint32_t x_bytes, BxConvPoolEpi pe) {
+    int H, int W, int Ci, int Co, int relu, int tiles_x, int tiles_y, uint32_t x_bytes, BxConvPoolEpi pe, WgradRedJob red, int nred) {
   constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CKB = CK * 2, NCH = CK / 8, KS = (9 * CK + 31) / 32;
   constexpr int MP = IMGS * TH * TW / 64;   // 16-pixel tiles per wave
   constexpr int TPI = TH * TW / 16;         // 16-pixel tiles per image
   constexpr int TPR = TW / 16;              // 16-pixel tiles per tile row
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int bid = blockIdx.x;
+  if ((int)blockIdx.x < nred) {             // carried weight-gradient sum (nred = 0 in ordinary launches)
+    if (blockIdx.y == 0 && (int)blockIdx.x < red.nblocks) wgrad_reduce3_body(red, (int)blockIdx.x, reinterpret_cast<float4*>(lds));
+    return;
+  }
+  const int bid = (int)blockIdx.x - nred;
+  const int gx = (int)gridDim.x - nred;
   const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, b = (bid / (tiles_x * tiles_y)) * IMGS;      // first image of the tile
   const int y0 = ty * TH, x0 = tx * TW, co_base = blockIdx.y * (NC * 16);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
@@ -337,7 +349,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   }
   // epilogue: lane = (pixel li of tile t, output channels co_base + n*16 + 4g .. +3).  y / mask / addend share one shape:
   // 32-bit byte offsets through buffer resources, out-of-image lanes point past the end (loads read 0, stores are dropped)
-  const uint32_t y_bytes = (uint32_t)((size_t)gridDim.x / (tiles_x * tiles_y) * IMGS * H * W * Co * 2);
+  const uint32_t y_bytes = (uint32_t)((size_t)gx / (tiles_x * tiles_y) * IMGS * H * W * Co * 2);
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src ? mask_src : y), 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend : y), 0, y_bytes, 0x00020000);
@@ -373,7 +385,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
         acc[i][n] = (f32x4){__uint_as_float(out.x << 16), __uint_as_float(out.x & 0xffff0000u), __uint_as_float(out.y << 16),
                             __uint_as_float(out.y & 0xffff0000u)};
       }
-    const uint32_t p_bytes = (uint32_t)((size_t)gridDim.x / (tiles_x * tiles_y) * IMGS * pe.Ho * pe.Wo * Co * 2);
+    const uint32_t p_bytes = (uint32_t)((size_t)gx / (tiles_x * tiles_y) * IMGS * pe.Ho * pe.Wo * Co * 2);
     const __amdgpu_buffer_rsrc_t pres = __builtin_amdgcn_make_buffer_rsrc(pe.pooled, 0, p_bytes, 0x00020000);
     float st[2][NC][4];
 #pragma unroll
@@ -670,11 +682,16 @@ __global__ __launch_bounds__(256) void k_conv_mfma_c(const bf16_t* __restrict__ 
 template <int CK, int NC, int TW, bool POOL = false>
 __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const bf16_t* __restrict__ mask_src, const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
-    int H, int W, int Co, int relu, int tiles_x, int tiles_y, int ntiles, uint32_t x_bytes, BxConvPoolEpi pe) {
+    int H, int W, int Co, int relu, int tiles_x, int tiles_y, int ntiles, uint32_t x_bytes, BxConvPoolEpi pe, WgradRedJob red, int nred) {
   constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CKB = CK * 2, NCH = CK / 8, KS = (9 * CK + 31) / 32;
   constexpr int MP = TH * TW / 64, TPR = TW / 16;
   constexpr int NU = HH * HWID * NCH, NR = (NU + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  if ((int)blockIdx.x < nred) {             // carried weight-gradient sum (see k_conv_mfma)
+    if (blockIdx.y == 0 && (int)blockIdx.x < red.nblocks) wgrad_reduce3_body(red, (int)blockIdx.x, reinterpret_cast<float4*>(lds));
+    return;
+  }
+  const int first_tile = (int)blockIdx.x - nred, tile_stride = (int)gridDim.x - nred;
   const int co_base = blockIdx.y * (NC * 16);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
   uint4 rv[NR];
@@ -714,7 +731,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
 #pragma unroll
   for (int n = 0; n < NC; ++n)
     bz[n] = bias ? *reinterpret_cast<const float4*>(bias + co_base + n * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  if (first_tile < ntiles) fetch(first_tile);
   // pooled form: statistics accumulate over the workgroup's tiles in registers; one reduction-tree row per workgroup at the end
   float st[2][NC][4];
   __amdgpu_buffer_rsrc_t pres = yres;
@@ -726,7 +743,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 4; ++r) st[0][n][r] = st[1][n][r] = 0.f;
   }
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = first_tile; tile < ntiles; tile += tile_stride) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int y0 = ty * TH, x0 = tx * TW;
     __syncthreads();                          // previous tile's fragment reads are done
@@ -739,7 +756,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
       }
     }
     __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+    if (tile + tile_stride < ntiles) fetch(tile + tile_stride);
     f32x4 acc[MP][NC];
 #pragma unroll
     for (int i = 0; i < MP; ++i)
@@ -989,10 +1006,14 @@ static int pool_tree_shape(BxConvPoolEpi* pe, int grid_x, int ygroups, int Co) {
 }
 template <int CK, int NC, int TW>
 static int launch_conv(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
-                       int B, int H, int W, int Ci, int Co, int relu, hipStream_t s, BxConvPoolEpi* pe = nullptr) {
+                       int B, int H, int W, int Ci, int Co, int relu, hipStream_t s, BxConvPoolEpi* pe = nullptr, const WgradRedJob* red = nullptr) {
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + 7) / 8;
   size_t lds = (size_t)10 * (TW + 2) * CK * 2;
   const BxConvPoolEpi none = {};
+  const WgradRedJob nored = {};
+  const int nred = red && !pe ? red->nblocks : 0;          // workgroups in front of grid.x that sum a pending weight gradient
+  const WgradRedJob& rj = nred ? *red : nored;
+  if (nred && lds < 4096) lds = 4096;
   if (pe) {
     const size_t need = BX_STAT_TREE_LDS(2) + (size_t)4 * 2 * NC * 16 * sizeof(float);       // conv_pool_finish reuses the halo tile's LDS
     if (lds < need) lds = need;
@@ -1008,14 +1029,14 @@ static int launch_conv(const void* x, const void* wp, const float* bias, const v
           if (rc != BX_OK) return rc;
           hipLaunchKernelGGL((k_conv_mfma_p<CK, NC, TW, true>), dim3((unsigned)gx, (unsigned)ygroups), dim3(256), lds, s, (const bf16_t*)x,
                              (const bf16_t*)wp, bias, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (bf16_t*)y, H, W, Co, 1, tiles_x, tiles_y, ntiles,
-                             (uint32_t)((size_t)B * H * W * CK * 2), *pe);
+                             (uint32_t)((size_t)B * H * W * CK * 2), *pe, nored, 0);
           BX_CHECK_LAUNCH("bx_conv3x3(mfma persistent, pooled)");
           return BX_OK;
         }
       }
-      hipLaunchKernelGGL((k_conv_mfma_p<CK, NC, TW>), dim3((unsigned)gx, (unsigned)ygroups), dim3(256), lds, s, (const bf16_t*)x,
+      hipLaunchKernelGGL((k_conv_mfma_p<CK, NC, TW>), dim3((unsigned)(gx + nred), (unsigned)ygroups), dim3(256), lds, s, (const bf16_t*)x,
                          (const bf16_t*)wp, bias, (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Co, relu, tiles_x, tiles_y, ntiles,
-                         (uint32_t)((size_t)B * H * W * CK * 2), none);
+                         (uint32_t)((size_t)B * H * W * CK * 2), none, rj, nred);
       BX_CHECK_LAUNCH("bx_conv3x3(mfma persistent)");
       return BX_OK;
     }
@@ -1034,9 +1055,9 @@ static int launch_conv(const void* x, const void* wp, const float* bias, const v
           BX_FAIL(BX_EHIP, "bx_conv3x3(mfma): cannot reserve %zu bytes of LDS", lds2);
         attr_done = true;
       }
-      dim3 grid2((unsigned)(tiles_x * tiles_y * (B / 2)), (unsigned)(Co / (16 * NC)));
+      dim3 grid2((unsigned)(tiles_x * tiles_y * (B / 2) + nred), (unsigned)(Co / (16 * NC)));
       if (pe) {
-        const int rc = pool_tree_shape<NC>(pe, (int)grid2.x, (int)grid2.y, Co);
+        const int rc = pool_tree_shape<NC>(pe, (int)grid2.x, (int)grid2.y, Co);      // pe => nred == 0
         if (rc != BX_OK) return rc;
         static bool attr_done_p = false;
         if (lds2 > 64 * 1024 && !attr_done_p) {
@@ -1045,30 +1066,30 @@ static int launch_conv(const void* x, const void* wp, const float* bias, const v
           attr_done_p = true;
         }
         hipLaunchKernelGGL((k_conv_mfma<CK, NC, TW, 2, true>), grid2, dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)nullptr,
-                           (const bf16_t*)nullptr, (bf16_t*)y, H, W, Ci, Co, 1, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), *pe);
+                           (const bf16_t*)nullptr, (bf16_t*)y, H, W, Ci, Co, 1, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), *pe, nored, 0);
         BX_CHECK_LAUNCH("bx_conv3x3(mfma, two-image tiles, pooled)");
         return BX_OK;
       }
       hipLaunchKernelGGL((k_conv_mfma<CK, NC, TW, 2>), grid2, dim3(256), lds2, s, (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)mask,
-                         (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), none);
+                         (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), none, rj, nred);
       BX_CHECK_LAUNCH("bx_conv3x3(mfma, two-image tiles)");
       return BX_OK;
     }
   }
-  dim3 grid((unsigned)(tiles_x * tiles_y * B), (unsigned)(Co / (16 * NC)));
+  dim3 grid((unsigned)(tiles_x * tiles_y * B + nred), (unsigned)(Co / (16 * NC)));
   if (pe) {
     if constexpr (CK >= 16) {
       const int rc = pool_tree_shape<NC>(pe, (int)grid.x, (int)grid.y, Co);
       if (rc != BX_OK) return rc;
       hipLaunchKernelGGL((k_conv_mfma<CK, NC, TW, 1, true>), grid, dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)nullptr,
-                         (const bf16_t*)nullptr, (bf16_t*)y, H, W, Ci, Co, 1, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), *pe);
+                         (const bf16_t*)nullptr, (bf16_t*)y, H, W, Ci, Co, 1, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), *pe, nored, 0);
       BX_CHECK_LAUNCH("bx_conv3x3(mfma, pooled)");
       return BX_OK;
     }
     BX_FAIL(BX_EUNSUPPORTED, "bx_conv3x3(pooled): needs at least 16 input channels");
   }
   hipLaunchKernelGGL((k_conv_mfma<CK, NC, TW>), grid, dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)wp, bias,
-                     (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), none);
+                     (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), none, rj, nred);
   BX_CHECK_LAUNCH("bx_conv3x3(mfma)");
   return BX_OK;
 }
@@ -1130,44 +1151,48 @@ static int try_conv_c(const void* x, const void* wp, const float* bias, const vo
 // own stage -> MFMA chain); prefer 8x16 pixel tiles and fewer output channels per workgroup until >= 512 are in flight.
 template <int CK, int NC>
 static int launch_conv_tw(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
-                          int B, int H, int W, int Ci, int Co, int relu, hipStream_t s, BxConvPoolEpi* pe = nullptr) {
+                          int B, int H, int W, int Ci, int Co, int relu, hipStream_t s, BxConvPoolEpi* pe = nullptr, const WgradRedJob* red = nullptr) {
   // 8x32 tiles wherever the map is wide enough: a workgroup re-reads its whole weight slab from L2 per pixel tile, so
   // twice the pixels per tile halves the dominant L2 traffic of the late stages (measured: 16x32 maps 22.4 -> 17.3 us)
-  if (W <= 16) return launch_conv<CK, NC, 16>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe);
-  return launch_conv<CK, NC, 32>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe);
+  if (W <= 16) return launch_conv<CK, NC, 16>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe, red);
+  return launch_conv<CK, NC, 32>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe, red);
 }
 template <int CK>
 static int launch_conv_nc(const void* x, const void* wp, const float* bias, const void* mask, const void* addend, void* y,
-                          int B, int H, int W, int Ci, int Co, int relu, hipStream_t s, BxConvPoolEpi* pe = nullptr) {
+                          int B, int H, int W, int Ci, int Co, int relu, hipStream_t s, BxConvPoolEpi* pe = nullptr, const WgradRedJob* red = nullptr) {
   // output channels per workgroup: 64 while that still launches >= 512 workgroups, else 32 (keeps two per CU in flight)
   const int tw = W <= 16 ? 16 : 32;
   const long long tiles = (long long)((W + tw - 1) / tw) * ((H + 7) / 8) * B;
   static const long long nc4_min = getenv("BX_CONV_NC4_MIN") ? atoll(getenv("BX_CONV_NC4_MIN")) : 512;
-  if (Co % 64 == 0 && tiles * (Co / 64) >= nc4_min) return launch_conv_tw<CK, 4>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe);
-  if (Co % 32 == 0) return launch_conv_tw<CK, 2>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe);
-  return launch_conv_tw<CK, 1>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe);
+  if (Co % 64 == 0 && tiles * (Co / 64) >= nc4_min) return launch_conv_tw<CK, 4>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe, red);
+  if (Co % 32 == 0) return launch_conv_tw<CK, 2>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe, red);
+  return launch_conv_tw<CK, 1>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe, red);
 }
 int bx_conv3x3_mfma_launch(const void* x, const void* packed_mfma, const float* bias, const void* relu_mask_src,
-                           const void* addend, void* y, int B, int H, int W, int Ci, int Co, int flags, hipStream_t s) {
+                           const void* addend, void* y, int B, int H, int W, int Ci, int Co, int flags, hipStream_t s, bxWgradPending* carry) {
   const int relu = (flags & BX_EPI_RELU) ? 1 : 0;
+  // a pending weight-gradient sum rides in this launch (pixel-split kernels only); the job is built like a chained reduce's
+  WgradRedJob job = {};
+  const WgradRedJob* red = nullptr;
+  if (carry && carry->valid) { job = wgrad_job_from(carry, true); red = &job; carry->valid = 0; }
   // the kernels address activations with 32-bit byte offsets through buffer resources
   BX_REQUIRE((size_t)B * H * W * (Ci > Co ? Ci : Co) * 2 < ((size_t)1 << 31), "bx_conv3x3(mfma): an activation tensor of 2 GiB or more is not supported (B=%d H=%d W=%d)", B, H, W);
   // K-split variant: measured equal to the tile-per-workgroup kernel on MI355X (round 1: fwd +8 %, dgrad -3 %), so it is
   // opt-in (BX_KSPLIT=1) until its main loop gets LDS double buffering
-  if (Co % 64 == 0 && getenv("BX_KSPLIT")) {
+  if (!red && Co % 64 == 0 && getenv("BX_KSPLIT")) {
     if (Ci == 64)  return launch_conv_ks<1>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Co, relu, s);
     if (Ci == 128) return launch_conv_ks<2>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Co, relu, s);
     if (Ci == 256) return launch_conv_ks<4>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Co, relu, s);
   }
-  {
+  if (!red) {
     const int rc = try_conv_c(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s, nullptr);
     if (rc >= 0) return rc;
   }
   switch (mfma_ck(Ci)) {
-    case 8:  return launch_conv_nc<8>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s);
-    case 16: return launch_conv_nc<16>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s);
-    case 32: return launch_conv_nc<32>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s);
-    default: return launch_conv_nc<64>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s);
+    case 8:  return launch_conv_nc<8>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s, nullptr, red);
+    case 16: return launch_conv_nc<16>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s, nullptr, red);
+    case 32: return launch_conv_nc<32>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s, nullptr, red);
+    default: return launch_conv_nc<64>(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, relu, s, nullptr, red);
   }
 }
 
@@ -1191,7 +1216,6 @@ int bx_conv3x3_mfma_pool_launch(const void* x, const void* packed_mfma, const fl
 // accumulator fragments followed by Co bias sums.  A workgroup covers NO = 256/S float4 groups x S split slices
 // (S = 4, 16 or 64: small outputs get many slices so that the chip is filled and no thread walks hundreds of splits);
 // slices are combined through LDS in slice order.
-struct WgradRedJob { const float* partial; float* dw; float* db; int nsplit, Cin, Co, S, MA, NB, ztiles, nfrag4, nblocks; };
 __device__ __forceinline__ void wgrad_reduce3_body(const WgradRedJob& jb, int bid, float4* sm) {
   const float* __restrict__ partial = jb.partial;
   float* __restrict__ dw = jb.dw;

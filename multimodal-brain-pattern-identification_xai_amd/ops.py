@@ -314,16 +314,23 @@ class PackPlan:
         return self.views.get((i, flip))
 
 
-def _conv(x, packed, bias, mask_src, addend, relu: bool, dtype):
+def _conv(x, packed, bias, mask_src, addend, relu: bool, dtype, carry: bool = False):
+    """carry=True: a pending chained weight-gradient sum of this device rides in the convolution's launch (bx_conv3x3_carry)."""
     pf, pm, ip, op = packed
     B, H, W, Ci = x.shape
     if Ci != ip:
         raise RuntimeError(f"brainxai: conv input has {Ci} channels, packed weights expect {ip}")
     y = torch.empty(B, H, W, op, dtype=dtype, device=x.device)
     algo = CONV_ALGO if x.dtype == torch.bfloat16 else L.BX_ALGO_DIRECT
+    st = _wg_chain_state(x.device) if carry and WGRAD_CARRY else None
     with _Timed("fwd" if bias is not None else "dgrad"):
-        L.check(L.load().bx_conv3x3(_p(x), _p(pf), _p(pm), _p(bias), _p(mask_src), _p(addend), _p(y), B, H, W, Ci, op,
-                                    bx_dtype(dtype), L.BX_EPI_RELU if relu else 0, algo, _stream()), "bx_conv3x3")
+        if st is not None and st.pend.valid and st.stream == _stream():
+            L.check(L.load().bx_conv3x3_carry(_p(x), _p(pf), _p(pm), _p(bias), _p(mask_src), _p(addend), _p(y), B, H, W, Ci, op,
+                                              bx_dtype(dtype), L.BX_EPI_RELU if relu else 0, algo, C.byref(st.pend), _stream()), "bx_conv3x3_carry")
+            st.keep = None
+        else:
+            L.check(L.load().bx_conv3x3(_p(x), _p(pf), _p(pm), _p(bias), _p(mask_src), _p(addend), _p(y), B, H, W, Ci, op,
+                                        bx_dtype(dtype), L.BX_EPI_RELU if relu else 0, algo, _stream()), "bx_conv3x3")
     return y
 
 
@@ -332,6 +339,8 @@ def _conv(x, packed, bias, mask_src, addend, relu: bool, dtype):
 # returned gradient right away, so nothing may be pending then).  Per device: the pending descriptor, two partial buffers
 # used alternately (the pending partials must outlive the next launch) and the tensors to keep alive meanwhile.
 WGRAD_CHAIN = _os.environ.get("BX_WGRAD_CHAIN", "1") == "1"
+# the last pending sum of a Block's backward rides in conv1's data-gradient launch; 0 = a k_wgrad_reduce3 launch per Block
+WGRAD_CARRY = _os.environ.get("BX_WGRAD_CARRY", "1") == "1"
 # batch-statistics finalizes inside the kernels that produce the partial sums (bxTailDesc.sync); 0 = separate finalize launches
 TAIL_IN_LAUNCH = _os.environ.get("BX_TAIL_IN_LAUNCH", "1") == "1"
 # conv3 of a Block pools and sums the batch statistics in its epilogue (bx_block_conv3_tail_fwd); 0 = conv3, then the pooling kernel
@@ -508,7 +517,7 @@ class BlockFn(torch.autograd.Function):
                 if cfg.preact == k:
                     cfg.capture["grad"] = dz
             elif need_dx:
-                dz = _conv(dz, packed or _pack(wts[0], flip=True, dtype=dt), None, None, dx_skip, False, dt)
+                dz = _conv(dz, packed or _pack(wts[0], flip=True, dtype=dt), None, None, dx_skip, False, dt, carry=need_w and side is None)
         if need_w and side is None:
             wgrad_flush(x.device)                           # conv1's partial sum: nothing may be pending when the gradients are returned
         dx = dz if need_dx else None

@@ -248,3 +248,47 @@ def test_conv_family_adjoint_identity_at_bench_size(cin, cout, h, w):
         e = float((F.conv2d(xd, wt.double(), padding=1) * ops.to_nchw_f32(dz, cout).double()).sum())
         assert max(abs(a - e), abs(b - e), abs(c - e)) <= 1e-4 * e, (a, b, c, e)
     assert abs(float(db.double().sum()) - float(dz.double().sum())) <= 1e-5 * float(dz.double().abs().sum())
+
+
+@pytest.mark.parametrize("conv_shape", [(64, 32, 16, 32), (32, 16, 40, 72), (256, 128, 8, 16), (16, 16, 64, 96)])
+def test_conv_launch_carries_pending_weight_gradient_sum(conv_shape):
+    """bx_conv3x3_carry: the pending partial sum of a chained weight gradient is finished by extra workgroups of a convolution
+    launch (pixel-split and persistent kernels); the convolution's own result and the summed gradient are bit-identical to the
+    separate launches, and nothing is left pending."""
+    import ctypes
+    lib = L.load()
+    torch.manual_seed(9)
+    B, cin, cout, h, w = 4, 64, 64, 16, 32
+    xn = ops.to_nhwc(torch.randn(B, cin, h, w, device=DEV), torch.bfloat16)
+    dzn = ops.to_nhwc(torch.randn(B, cout, h, w, device=DEV) * 0.1, torch.bfloat16)
+    need = lib.bx_conv3x3_wgrad_workspace(B, h, w, cin, cout, L.BX_BF16, L.BX_ALGO_MFMA)
+    want_dw, want_db = torch.empty(cout, cin, 3, 3, device=DEV), torch.empty(cout, device=DEV)
+    ws0 = torch.empty(need, dtype=torch.uint8, device=DEV)
+    L.check(lib.bx_conv3x3_wgrad(xn.data_ptr(), dzn.data_ptr(), want_dw.data_ptr(), want_db.data_ptr(), B, h, w, cin, cin, cout, L.BX_BF16,
+                                 L.BX_ALGO_MFMA, ws0.data_ptr(), ws0.numel(), 0), "wgrad")
+    # the convolution that will carry the sum (a data-gradient-style call: mask + addend epilogue)
+    ci2, co2, h2, w2 = conv_shape
+    wt = _bf(torch.randn(ci2, co2, 3, 3) / (3 * ci2 ** 0.5)).to(DEV)       # layer co2 -> ci2; its data gradient maps ci2 -> co2
+    packed = ops._pack(wt, True, torch.bfloat16)
+    g2 = ops.to_nhwc(torch.randn(3, ci2, h2, w2, device=DEV), torch.bfloat16)
+    mk = ops.to_nhwc(torch.randn(3, co2, h2, w2, device=DEV), torch.bfloat16)
+    ad = ops.to_nhwc(torch.randn(3, co2, h2, w2, device=DEV), torch.bfloat16)
+    y_plain = torch.empty(3, h2, w2, packed[3], dtype=torch.bfloat16, device=DEV)
+    L.check(lib.bx_conv3x3(g2.data_ptr(), None, packed[1].data_ptr(), None, mk.data_ptr(), ad.data_ptr(), y_plain.data_ptr(), 3, h2, w2, g2.shape[3],
+                           packed[3], L.BX_BF16, 0, L.BX_ALGO_MFMA, 0), "conv")
+    pend = L.WgradPending()
+    dw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV)
+    db = torch.full((cout,), float("nan"), device=DEV)
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    L.check(lib.bx_conv3x3_wgrad_chained(xn.data_ptr(), dzn.data_ptr(), dw.data_ptr(), db.data_ptr(), B, h, w, cin, cin, cout, L.BX_BF16,
+                                         L.BX_ALGO_MFMA, ws.data_ptr(), ws.numel(), ctypes.byref(pend), 0), "wgrad chained")
+    assert pend.valid == 1
+    torch.cuda.synchronize()
+    assert torch.isnan(dw).all()
+    y_carry = torch.empty_like(y_plain)
+    L.check(lib.bx_conv3x3_carry(g2.data_ptr(), None, packed[1].data_ptr(), None, mk.data_ptr(), ad.data_ptr(), y_carry.data_ptr(), 3, h2, w2,
+                                 g2.shape[3], packed[3], L.BX_BF16, 0, L.BX_ALGO_MFMA, ctypes.byref(pend), 0), "conv carry")
+    assert pend.valid == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y_carry, y_plain)
+    assert rel_err(dw.cpu(), want_dw.cpu()) < 1e-6 and rel_err(db.cpu(), want_db.cpu()) < 1e-6
