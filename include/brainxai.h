@@ -221,6 +221,11 @@ typedef struct {
   float eps, momentum, dropout_p;
   uint32_t salt;        /* bit 31 set: one mask entry per (sample, channel) = nn.Dropout2d (models.py:255) */
   int dtype;            /* storage of the big intermediates (conv1 output)           */
+  int collapse;         /* 1: training passes with bf16 storage, K1 = 64, T >= 96, T % 8 == 0 never form the conv1 output
+                         * [B,F1,Chans,T]: the electrodes are mixed first, BatchNorm1's statistics come from the input's
+                         * autocorrelation, and the gradients of conv1 / bn1 / depthwiseConv from one correlation of dL/du
+                         * with the input.  Such a pass has NO input gradient (dx must be NULL);
+                         * forward and backward must see the same flag.  0: the layer-by-layer path. */
 } bxEegDesc;
 /* Parameter block: pointers to the fp32 tensors of the module, reference names in comments. */
 typedef struct {

@@ -105,15 +105,23 @@ __device__ __forceinline__ float bx_ldf_or0(__amdgpu_buffer_rsrc_t r, int elem, 
 }
 
 // ---- wave / block reductions (wave = 64 lanes) ----------------------------------------------------
+// Every lane gets the result.  Inside a row of 16 lanes the exchange is a DPP modifier on the add itself (quad_perm [1,0,3,2] and
+// [2,3,0,1], row_ror:4, row_ror:8); the four row totals meet through v_readlane.  The __shfl_xor butterfly this replaces compiles
+// to ds_bpermute_b32 -- an LDS-crossbar round trip per step, six dependent ones per value: a kernel that ends in 65 wave sums
+// (k_eegc_stats) spent 16 us in them.  Fixed order, so results are reproducible (they differ from the butterfly's in the last bit).
+template <int CTRL> __device__ __forceinline__ float bx_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float bx_lane(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += bx_dpp<0xB1>(v); v += bx_dpp<0x4E>(v); v += bx_dpp<0x124>(v); v += bx_dpp<0x128>(v);
+  return (bx_lane(v, 0) + bx_lane(v, 16)) + (bx_lane(v, 32) + bx_lane(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+  v = fmaxf(v, bx_dpp<0xB1>(v)); v = fmaxf(v, bx_dpp<0x4E>(v)); v = fmaxf(v, bx_dpp<0x124>(v)); v = fmaxf(v, bx_dpp<0x128>(v));
+  return fmaxf(fmaxf(bx_lane(v, 0), bx_lane(v, 16)), fmaxf(bx_lane(v, 32), bx_lane(v, 48)));
 }
 
 // LogSoftmax backward for one row, dz_n = dy_n - softmax_n * sum_j dy_j, evaluated WITHOUT its cancellation:

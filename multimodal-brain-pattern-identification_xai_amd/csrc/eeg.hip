@@ -21,6 +21,23 @@ size_t bx_eeg_conv1_wgrad_mfma_lds(int T);
 int bx_eeg_conv1_wgrad_mfma_launch(const void* c1, const float* dd, const float* x, const float* dw, const float* mean1, const float* inv1,
                                    const float* coef, float* w1part, int B, int Ch, int T, int FD, int coef_stride, hipStream_t s);
 
+// collapsed front end (eeg_collapse.hip / eeg_mfma.hip)
+size_t bx_eegc_stat_floats();
+int bx_eegc_forward(const float* x, const float* w1, const float* wd, const float* gamma, const float* beta, float* rmean, float* rvar, int64_t* nbt,
+                    float momentum, float eps, float* mean1, float* inv1, float* sc1, float* sh1, double* RS, float* stat_ws, float* u,
+                    float* bn2_partials, int* bn2_rows, int B, int Ch, int T, hipStream_t s);
+int bx_eegc_corr_launch(const float* gmap, const float* x, float* cpart, float* gpart, int B, int Ch, int T, int nsplit, hipStream_t s);
+int bx_eegc_grads(const float* cpart, const float* gpart, int nsplit, const float* w1, const float* wd, const float* mean1, const float* inv1,
+                  const float* sc1, const float* sh1, const double* RS, float* ep, float* d_wd, float* d_gamma, float* d_beta, float* d_w1,
+                  int B, int Ch, int T, hipStream_t s);
+#define EEGC_RS_BYTES ((size_t)(64 * 64 + 64) * sizeof(double))
+#define EEGC_MAX_SPLIT 32
+// The collapsed front end applies to: training mode, bf16 storage (its backward rounds the MFMA operands to bf16, which the fp32
+// parity path must not), the reference's 64-tap kernel, rows long enough for the edge terms, T % 8 == 0, no input gradient.
+static bool eeg_collapsed(const bxEegDesc* d) {
+  return d->collapse && d->training && d->dtype == BX_BF16 && d->K1 == 64 && d->T >= 96 && d->T % 8 == 0;
+}
+
 struct EegGeom {
   int B, Ch, T, F1, D, FD, F2, K1, K2, P1, P2, T1, T2, padl1, padl2;
   size_t off_c1, off_d, off_p1, off_s, off_stats, total;   // saved arena (bytes)
@@ -36,7 +53,11 @@ static int eeg_geom(const bxEegDesc* d, EegGeom* g) {
   if (g->T2 < 1) return -5;
   g->padl1 = (d->K1 - 1) / 2; g->padl2 = (d->K2 - 1) / 2;
   size_t o = 0;
-  g->off_c1 = o; o += bx_align_up((size_t)g->B * g->F1 * g->Ch * g->T * bx_esize(d->dtype), 256);
+  {   // conv1 output, or (collapsed front end) the input's sufficient statistics R[64][64], S[64] in fp64
+    size_t c1b = (size_t)g->B * g->F1 * g->Ch * g->T * bx_esize(d->dtype);
+    if (c1b < EEGC_RS_BYTES) c1b = EEGC_RS_BYTES;
+    g->off_c1 = o; o += bx_align_up(c1b, 256);
+  }
   g->off_d = o;  o += bx_align_up((size_t)g->B * g->FD * g->T * 4, 256);
   g->off_p1 = o; o += bx_align_up((size_t)g->B * g->FD * g->T1 * 4, 256);
   g->off_s = o;  o += bx_align_up((size_t)g->B * g->F2 * g->T1 * 4, 256);
@@ -74,8 +95,19 @@ static EegWs eeg_ws(const EegGeom& g) {
   w.off_du3 = o; o += bx_align_up((size_t)g.B * g.F2 * g.T1 * 4, 256);
   w.off_dp1 = o; o += bx_align_up((size_t)g.B * g.FD * g.T1 * 4, 256);
   w.off_du2 = o; o += bx_align_up((size_t)g.B * g.FD * g.T * 4, 256);
-  w.off_r = o;   o += bx_align_up((size_t)g.B * (g.FD * g.Ch + g.FD) * 4, 256);
-  w.off_w1p = o; o += bx_align_up((size_t)rows * g.F1 * g.K1 * 4, 256);
+  {   // also the collapsed backward's per-electrode contributions [Ch][520] and sum-of-g partials [16][16]
+    size_t rb = (size_t)g.B * (g.FD * g.Ch + g.FD) * 4;
+    const size_t cb = ((size_t)g.Ch * 520 + EEGC_MAX_SPLIT * 16) * 4;
+    if (rb < cb) rb = cb;
+    w.off_r = o;   o += bx_align_up(rb, 256);
+  }
+  {   // also the collapsed front end's statistic partials (forward) and correlation partials [Ch][split][16][64] (backward)
+    size_t wb = (size_t)rows * g.F1 * g.K1 * 4;
+    const size_t sb = bx_eegc_stat_floats() * 4, cb = (size_t)g.Ch * EEGC_MAX_SPLIT * 1024 * 4;
+    if (wb < sb) wb = sb;
+    if (wb < cb) wb = cb;
+    w.off_w1p = o; o += bx_align_up(wb, 256);
+  }
   w.off_sepp = o; o += bx_align_up((size_t)g.B * 4 * g.F2 * g.FD * g.K2 * 4, 256);
   w.off_coef = o; o += bx_align_up((size_t)3 * 3 * EEG_MAXF * 4 + 256, 256);
   w.total = o;
@@ -367,6 +399,16 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
                        p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, g.F2, st.sc3, st.sh3, st.mean3, st.inv3, d->eps);
     BX_CHECK_LAUNCH("eeg eval stats");
   }
+  if (eeg_collapsed(d)) {
+    // conv1 -> BatchNorm1 -> electrode mix without the [B,8,Chans,T] tensor (eeg_collapse.hip): statistics, finalize, forward
+    int rows2 = 0;
+    const int rc = bx_eegc_forward(x, p->conv1_w, p->dw_w, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, p->bn1_nbt, d->momentum, d->eps, st.mean1, st.inv1,
+                                   st.sc1, st.sh1, (double*)c1, (float*)((char*)workspace + w.off_w1p), dmap, part, &rows2, g.B, g.Ch, g.T, s);
+    BX_REQUIRE(rc == 0, "bx_eeg_features_fwd: collapsed front end failed (code %d)", rc);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.FD)), dim3(1024), 0, s, part, rows2, (double)g.B * g.T, g.FD, tr, p->bn2_w, p->bn2_b,
+                       p->bn2_rm, p->bn2_rv, p->bn2_nbt, d->momentum, d->eps, st.sc2, st.sh2, st.mean2, st.inv2);
+    BX_CHECK_LAUNCH("eeg bn2 (collapsed front end)");
+  } else {
   // bf16 storage with the reference's 64-tap kernel: the temporal convolution runs on the matrix cores (eeg_mfma.hip)
   const bool no_mfma = getenv("BX_EEG_NO_MFMA") != nullptr;          // read per call: tests flip it to compare both paths
   if (d->dtype == BX_BF16 && g.K1 == 64 && !no_mfma && bx_eeg_conv1_mfma_lds(g.T) <= 150 * 1024) {
@@ -391,6 +433,7 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
     hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.FD)), dim3(1024), 0, s, part, (int)(gdw.x * gdw.y), (double)g.B * g.T, g.FD, tr, p->bn2_w, p->bn2_b,
                      p->bn2_rm, p->bn2_rv, p->bn2_nbt, d->momentum, d->eps, st.sc2, st.sh2, st.mean2, st.inv2);
   BX_CHECK_LAUNCH("eeg bn2");
+  }
   {
     const long long n = (long long)g.B * g.FD * g.T1;
     hipLaunchKernelGGL(k_eeg_bn_elu_pool, dim3(bx_ceil_div(n, 256)), dim3(256), 0, s, dmap, st.sc2, st.sh2, p1, g.B, g.FD, g.T, g.T1, g.P1,
@@ -956,6 +999,20 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
     hipLaunchKernelGGL(k_eeg_bn_bwd_apply, dim3(bx_ceil_div(n, 256) > 4096 ? 4096 : bx_ceil_div(n, 256)), dim3(256), 0, s, du2, dmap, st.mean2, st.inv2,
                        coef2, g.FD, g.T, n);
     BX_CHECK_LAUNCH("eeg bn2 bwd apply");
+  }
+  if (eeg_collapsed(d)) {
+    // gradients of conv1 / BatchNorm1 / depthwise from C = g (*) x, G = sum g and the saved (R, S): eeg_collapse.hip
+    BX_REQUIRE(!dx, "bx_eeg_features_bwd: the collapsed front end (bxEegDesc.collapse) has no input gradient; clear the flag when x needs one");
+    const int nsplit = g.B < EEGC_MAX_SPLIT ? g.B : EEGC_MAX_SPLIT;
+    float* cpart = w1part;
+    float* ep = rpart;
+    float* gpart = rpart + (size_t)g.Ch * 520;
+    int rc = bx_eegc_corr_launch(du2, x, cpart, gpart, g.B, g.Ch, g.T, nsplit, s);
+    BX_REQUIRE(rc == 0, "bx_eeg_features_bwd: correlation launch failed (code %d)", rc);
+    rc = bx_eegc_grads(cpart, gpart, nsplit, p->conv1_w, p->dw_w, st.mean1, st.inv1, st.sc1, st.sh1, (const double*)c1, ep, gr->dw_w, gr->bn1_w, gr->bn1_b,
+                       gr->conv1_w, g.B, g.Ch, g.T, s);
+    BX_REQUIRE(rc == 0, "bx_eeg_features_bwd: collapsed gradient launch failed (code %d)", rc);
+    return BX_OK;
   }
   // depthwise + BN1
   BX_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((k_eeg_dw_bwd_a<T>), dim3(g.B, (g.F1 * g.Ch + g.FD + 3) / 4), dim3(256), 0, s, (const T*)c1, du2, rpart, g));

@@ -345,6 +345,8 @@ WGRAD_CARRY = _os.environ.get("BX_WGRAD_CARRY", "1") == "1"
 TAIL_IN_LAUNCH = _os.environ.get("BX_TAIL_IN_LAUNCH", "1") == "1"
 # conv3 of a Block pools and sums the batch statistics in its epilogue (bx_block_conv3_tail_fwd); 0 = conv3, then the pooling kernel
 FUSE_POOL = _os.environ.get("BX_FUSE_POOL", "1") == "1"
+# EEGNet front end without the conv1 output tensor (bxEegDesc.collapse); 0 = conv1, BatchNorm1 and the electrode mix layer by layer
+EEG_COLLAPSE = _os.environ.get("BX_EEG_COLLAPSE", "1") == "1"
 _WG_CHAIN = {}
 
 
@@ -700,8 +702,10 @@ class EegFeaturesFn(torch.autograd.Function):
         _require_gpu(x, "eeg input")
         B, _, Ch, T = x.shape
         x = x.contiguous().float()
+        # collapsed front end (no conv1 output tensor): only when nobody can ask for the input's gradient
+        collapse = 1 if (EEG_COLLAPSE and cfg.training and not ctx.needs_input_grad[0]) else 0
         desc = L.EegDesc(B, Ch, T, cfg.F1, cfg.D, cfg.F2, cfg.K1, cfg.K2, cfg.P1, cfg.P2, 1 if cfg.training else 0, cfg.eps, cfg.momentum,
-                         float(cfg.dropout_p), cfg.salt, bx_dtype(cfg.dtype))
+                         float(cfg.dropout_p), cfg.salt, bx_dtype(cfg.dtype), collapse)
         nsaved = lib.bx_eeg_saved_bytes(C.byref(desc))
         if nsaved == 0:
             raise RuntimeError("brainxai: unsupported EEGNet geometry (needs F1=8, D=2, F2=16, kernLength<=64, Chans<=64)")

@@ -700,12 +700,15 @@ def test_eegnet_bf16_mfma_temporal_conv(chans, samples):
         mine.zero_grad(set_to_none=True)
         out = mine(xb.to(DEV)); brainxai.KLDivLoss()(out, labels.to(DEV)).backward()
         return out.detach().float().cpu(), {n: p.grad.detach().float().cpu().clone() for n, p in mine.named_parameters()}
+    keep = ops.EEG_COLLAPSE
     try:
+        ops.EEG_COLLAPSE = False                    # this test is about the layer-by-layer front end's two conv1 kernels
         os.environ["BX_EEG_NO_MFMA"] = "1"
         out_v, g_v = run()
         del os.environ["BX_EEG_NO_MFMA"]
         out_m, g_m = run()
     finally:
+        ops.EEG_COLLAPSE = keep
         os.environ.pop("BX_EEG_NO_MFMA", None)
         ops.clear_grad_views()
     assert float((out_m - out_v).abs().max()) < 2e-3 * float(out_v.abs().max()), "MFMA vs VALU forward (same bf16 operands)"
@@ -715,6 +718,60 @@ def test_eegnet_bf16_mfma_temporal_conv(chans, samples):
             continue                                # exactly zero in train mode: pure rounding noise
         cos = F.cosine_similarity(g_m[n].flatten().double(), g_v[n].flatten().double(), dim=0)
         assert float(cos) > 0.995, ("mfma vs valu", n, float(cos))
+
+
+@pytest.mark.parametrize("chans,samples,batch", [(19, 2000, 8), (37, 3000, 4), (5, 104, 3), (19, 2000, 64)])
+def test_eegnet_collapsed_front_end(chans, samples, batch):
+    """bf16 storage, training: the collapsed front end (electrodes mixed first, BatchNorm1 statistics from the input's
+    autocorrelation, conv1 / bn1 / depthwise gradients from one correlation of dL/du with the input; no [B,8,Chans,T] tensor)
+    against (a) the fp32 oracle and (b) the layer-by-layer kernels of the same storage type.  It rounds less than they do (no bf16
+    conv1 output), so it must be at least as close to the oracle; running statistics and every gradient are compared."""
+    ref, mine = _pair(lambda: O.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0),
+                      lambda: brainxai.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0), 41)
+    brainxai.set_compute_dtype(mine, torch.bfloat16)
+    x = O.seeded((batch, 1, chans, samples), 42, "randn") + 0.25          # a non-zero mean exercises the mean / variance split
+    labels = torch.softmax(O.seeded((batch, 6), 43, "randn"), 1)
+    ref.train(); mine.train()
+    state0 = {k: v.clone() for k, v in mine.state_dict().items()}
+    out_r = ref(x); O.kl_div(out_r, labels).backward()
+    g_r = {n: p.grad.detach().clone() for n, p in ref.named_parameters()}
+
+    def run(collapse):
+        keep = ops.EEG_COLLAPSE
+        ops.EEG_COLLAPSE = collapse
+        try:
+            mine.load_state_dict(state0)
+            mine.zero_grad(set_to_none=True)
+            out = mine(x.to(DEV)); brainxai.KLDivLoss()(out, labels.to(DEV)).backward()
+            torch.cuda.synchronize()
+            return (out.detach().float().cpu(), {n: p.grad.detach().float().cpu().clone() for n, p in mine.named_parameters()},
+                    {k: v.detach().float().cpu().clone() for k, v in mine.state_dict().items() if "running" in k})
+        finally:
+            ops.EEG_COLLAPSE = keep
+    try:
+        out_c, g_c, rs_c = run(True)
+        out_l, g_l, rs_l = run(False)
+    finally:
+        ops.clear_grad_views()
+    ref_rs = {k: v.detach().float() for k, v in ref.state_dict().items() if "running" in k}
+    for k in rs_c:                                                      # BatchNorm1's running statistics come from (R, S) in fp64
+        assert _sync_err(rs_c[k], ref_rs[k]) < (2e-5 if "batchnorm1" in k else 2e-2), ("running stat", k)
+    e_c, e_l = _sync_err(out_c, out_r.detach()), _sync_err(out_l, out_r.detach())
+    print(f"[parity] collapsed EEG front end {chans}x{samples} B={batch}: log-probabilities vs fp32 oracle {e_c:.2e} (layer by layer: {e_l:.2e})")
+    assert e_c < 2e-2 and e_c < 2.0 * e_l + 1e-3
+    for n in g_c:
+        if n.startswith("batchnorm1."):
+            # mathematically zero (BatchNorm2 removes any scale / shift of its input rows): noise of the size of the other path's
+            scale = float(g_r["conv1.weight"].abs().max())
+            assert float(g_c[n].abs().max()) < 0.05 * scale + 10 * float(g_l[n].abs().max()), (n, float(g_c[n].abs().max()))
+            continue
+        want = g_r[n].float()
+        cos_c = float(F.cosine_similarity(g_c[n].flatten().double(), want.flatten().double(), dim=0))
+        cos_l = float(F.cosine_similarity(g_l[n].flatten().double(), want.flatten().double(), dim=0))
+        rel_c = float((g_c[n].double() - want.double()).norm() / want.double().norm())
+        rel_l = float((g_l[n].double() - want.double()).norm() / want.double().norm())
+        print(f"[parity]    {n:28s} rel L2 {rel_c:.2e} (layer by layer {rel_l:.2e})  cosine {cos_c:.5f}")
+        assert cos_c > 0.995 and rel_c < 2.0 * rel_l + 2e-2, (n, cos_c, rel_c, rel_l)
 
 
 @pytest.mark.parametrize("arch", ["EEGNet", "EEGNetAttentionDeep"])
