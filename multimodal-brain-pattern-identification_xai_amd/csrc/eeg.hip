@@ -26,7 +26,8 @@ size_t bx_eegc_stat_floats();
 int bx_eegc_forward(const float* x, const float* w1, const float* wd, const float* gamma, const float* beta, float* rmean, float* rvar, int64_t* nbt,
                     float momentum, float eps, float* mean1, float* inv1, float* sc1, float* sh1, double* RS, float* stat_ws, float* u,
                     float* bn2_partials, int* bn2_rows, int B, int Ch, int T, hipStream_t s);
-int bx_eegc_corr_launch(const float* gmap, const float* x, float* cpart, float* gpart, int B, int Ch, int T, int nsplit, hipStream_t s);
+int bx_eegc_corr_launch(const void* g16, const float* x, float* cpart, float* gpart, int B, int Ch, int T, int nsplit, hipStream_t s);
+int bx_eegc_corr_max_T();
 int bx_eegc_grads(const float* cpart, const float* gpart, int nsplit, const float* w1, const float* wd, const float* mean1, const float* inv1,
                   const float* sc1, const float* sh1, const double* RS, float* ep, float* d_wd, float* d_gamma, float* d_beta, float* d_w1,
                   int B, int Ch, int T, hipStream_t s);
@@ -35,7 +36,8 @@ int bx_eegc_grads(const float* cpart, const float* gpart, int nsplit, const floa
 // The collapsed front end applies to: training mode, bf16 storage (its backward rounds the MFMA operands to bf16, which the fp32
 // parity path must not), the reference's 64-tap kernel, rows long enough for the edge terms, T % 8 == 0, no input gradient.
 static bool eeg_collapsed(const bxEegDesc* d) {
-  return d->collapse && d->training && d->dtype == BX_BF16 && d->K1 == 64 && d->T >= 96 && d->T % 8 == 0;
+  return d->collapse && d->training && d->dtype == BX_BF16 && d->K1 == 64 && d->T >= 96 && d->T % 8 == 0 && d->T <= bx_eegc_corr_max_T()
+         && d->F2 == d->F1 * d->D && d->P1 == 4;       // (the bf16 gradient map reuses the du3 | dp1 regions: 2 x B*16*(T/4)*4 bytes)
 }
 
 struct EegGeom {
@@ -544,6 +546,23 @@ __global__ void k_eeg_bn_bwd_apply(float* __restrict__ du, const float* __restri
   }
 }
 
+// the same for the collapsed front end: the result goes out as bf16 (the MFMA operand of k_eegc_corr), 8 elements per thread
+__global__ __launch_bounds__(256) void k_eeg_bn_bwd_apply16(const float* __restrict__ du, const float* __restrict__ pre, const float* __restrict__ mean,
+                                                             const float* __restrict__ inv, const float* __restrict__ coef, bf16_t* __restrict__ out,
+                                                             int F, int Tin, long long n8) {
+  for (long long i8 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i8 < n8; i8 += (long long)gridDim.x * blockDim.x) {
+    const long long i = i8 * 8;
+    const int f = (int)(((unsigned)i / (unsigned)Tin) % (unsigned)F);          // Tin % 8 == 0: the 8 elements share a row
+    const float a = coef[f], k1 = coef[EEG_MAXF + f], k2 = coef[2 * EEG_MAXF + f] * inv[f], mu = mean[f];
+    const float4 d0 = *reinterpret_cast<const float4*>(du + i), d1 = *reinterpret_cast<const float4*>(du + i + 4);
+    const float4 p0 = *reinterpret_cast<const float4*>(pre + i), p1 = *reinterpret_cast<const float4*>(pre + i + 4);
+    const float o[8] = {a * (d0.x - k1 - (p0.x - mu) * k2), a * (d0.y - k1 - (p0.y - mu) * k2), a * (d0.z - k1 - (p0.z - mu) * k2),
+                        a * (d0.w - k1 - (p0.w - mu) * k2), a * (d1.x - k1 - (p1.x - mu) * k2), a * (d1.y - k1 - (p1.y - mu) * k2),
+                        a * (d1.z - k1 - (p1.z - mu) * k2), a * (d1.w - k1 - (p1.w - mu) * k2)};
+    *reinterpret_cast<uint4*>(out + i) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+  }
+}
+
 // sepconv backward: grid (B, 4); LDS holds the sample's ds[16][.] and p1[16][.] rows (zero halo) and the weights.
 // (a) dp1[fd][t] = sum_{o,k} ws[o][fd][k] ds[o][t-k+padl]: wave w of quarter q owns map fd = 4q+w, a lane 8 consecutive
 //     time steps; per output map o it reads the 23-value window as 6 aligned float4s and 16 weights as 4 broadcast
@@ -994,7 +1013,12 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
                        gr->bn2_b, (const float*)sepp, gr->sep_w, g.B * 4, 4096, S2);
   }
   BX_CHECK_LAUNCH("eeg bn2 bwd finalize");
-  {
+  void* g16 = W + w.off_du3;                              // collapsed front end: dL/du as bf16 over the (dead by now) du3 | dp1 regions
+  if (eeg_collapsed(d)) {
+    const long long n8 = (long long)g.B * g.FD * g.T / 8;
+    hipLaunchKernelGGL(k_eeg_bn_bwd_apply16, dim3(bx_ceil_div(n8, 256)), dim3(256), 0, s, du2, dmap, st.mean2, st.inv2, coef2, (bf16_t*)g16, g.FD, g.T, n8);
+    BX_CHECK_LAUNCH("eeg bn2 bwd apply (bf16)");
+  } else {
     const long long n = (long long)g.B * g.FD * g.T;
     hipLaunchKernelGGL(k_eeg_bn_bwd_apply, dim3(bx_ceil_div(n, 256) > 4096 ? 4096 : bx_ceil_div(n, 256)), dim3(256), 0, s, du2, dmap, st.mean2, st.inv2,
                        coef2, g.FD, g.T, n);
@@ -1003,11 +1027,13 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
   if (eeg_collapsed(d)) {
     // gradients of conv1 / BatchNorm1 / depthwise from C = g (*) x, G = sum g and the saved (R, S): eeg_collapse.hip
     BX_REQUIRE(!dx, "bx_eeg_features_bwd: the collapsed front end (bxEegDesc.collapse) has no input gradient; clear the flag when x needs one");
-    const int nsplit = g.B < EEGC_MAX_SPLIT ? g.B : EEGC_MAX_SPLIT;
+    static const int want_split = getenv("BX_EEGC_NSPLIT") ? atoi(getenv("BX_EEGC_NSPLIT")) : EEGC_MAX_SPLIT;
+    int nsplit = want_split < 1 ? 1 : want_split > EEGC_MAX_SPLIT ? EEGC_MAX_SPLIT : want_split;
+    if (nsplit > g.B) nsplit = g.B;
     float* cpart = w1part;
     float* ep = rpart;
     float* gpart = rpart + (size_t)g.Ch * 520;
-    int rc = bx_eegc_corr_launch(du2, x, cpart, gpart, g.B, g.Ch, g.T, nsplit, s);
+    int rc = bx_eegc_corr_launch(g16, x, cpart, gpart, g.B, g.Ch, g.T, nsplit, s);
     BX_REQUIRE(rc == 0, "bx_eeg_features_bwd: correlation launch failed (code %d)", rc);
     rc = bx_eegc_grads(cpart, gpart, nsplit, p->conv1_w, p->dw_w, st.mean1, st.inv1, st.sc1, st.sh1, (const double*)c1, ep, gr->dw_w, gr->bn1_w, gr->bn1_b,
                        gr->conv1_w, g.B, g.Ch, g.T, s);

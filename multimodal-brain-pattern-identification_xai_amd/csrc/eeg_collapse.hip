@@ -19,7 +19,7 @@
 #define EC_PADL 31
 #define EC_EDGE 96                 // samples of a row's head / tail that the edge terms touch (31 + 63 + 1, rounded up)
 #define EC_NR 608                  // workgroups of the lag-sum role (two rows each at the benchmark shape: several resident per CU hide the row loads)
-#define EC_NE 16                   // workgroups of the edge role
+#define EC_NE 32                   // workgroups of the edge role
 #define EC_RCOLS 65                // r[0..63], sum x
 #define EC_ECOLS (66 * EC_EDGE)    // E_head[32][96], E_tail[32][96] (products of edge samples), column sums of head and tail [96] each
 
@@ -145,33 +145,37 @@ __global__ __launch_bounds__(1024) void k_eegc_finalize1(const float* __restrict
   __shared__ float tot_e[EC_ECOLS];
   double (*slice)[EC_RCOLS] = reinterpret_cast<double (*)[EC_RCOLS]>(sR);      // [15][65]: consumed (-> tot_r) before R is assembled in sR
   __shared__ double qf[8][2][2];
+  __shared__ double Hh[64][33], Ht[64][33], hx[33], tx[33];
+  __shared__ float sw[8 * EC_K];
   const int tid = threadIdx.x;
   {                                                     // lag sums: 15 slices of the partial rows, combined in slice order
     const int col = tid % EC_RCOLS, sl = tid / EC_RCOLS;
     constexpr int PER = (EC_NR + 14) / 15;
     if (sl < 15) {
       double a = 0.0;
-      for (int r0 = 0; r0 < PER; r0 += 8) {             // eight independent loads per trip
-        float v[8];
+      for (int r0 = 0; r0 < PER; r0 += 16) {            // sixteen independent loads per trip
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
           const int r = sl * PER + r0 + u;
           v[u] = rpart[(size_t)(r < EC_NR ? r : EC_NR - 1) * EC_RCOLS + col];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a += (r0 + u < PER && sl * PER + r0 + u < EC_NR) ? (double)v[u] : 0.0;
+        for (int u = 0; u < 16; ++u) a += (r0 + u < PER && sl * PER + r0 + u < EC_NR) ? (double)v[u] : 0.0;
       }
       slice[sl][col] = a;
     }
   }
-  for (int i = tid; i < EC_ECOLS; i += 1024) {          // edge sums (float is enough: a few thousand products per entry, ~2 % of R)
-    float v[EC_NE];
+  for (int i = tid; i < EC_ECOLS; i += 2048) {          // edge sums, two columns (2 x EC_NE loads) per trip; float is enough (~2 % of R)
+    float v[2][EC_NE];
+    const int i1 = i + 1024 < EC_ECOLS ? i + 1024 : i;
 #pragma unroll
-    for (int r = 0; r < EC_NE; ++r) v[r] = epart[(size_t)r * EC_ECOLS + i];
-    double a = 0.0;
+    for (int r = 0; r < EC_NE; ++r) { v[0][r] = epart[(size_t)r * EC_ECOLS + i]; v[1][r] = epart[(size_t)r * EC_ECOLS + i1]; }
+    double a = 0.0, b = 0.0;
 #pragma unroll
-    for (int r = 0; r < EC_NE; ++r) a += (double)v[r];
+    for (int r = 0; r < EC_NE; ++r) { a += (double)v[0][r]; b += (double)v[1][r]; }
     tot_e[i] = (float)a;
+    if (i + 1024 < EC_ECOLS) tot_e[i + 1024] = (float)b;
   }
   __syncthreads();
   if (tid < EC_RCOLS) {
@@ -180,30 +184,50 @@ __global__ __launch_bounds__(1024) void k_eegc_finalize1(const float* __restrict
     tot_r[tid] = a;
   }
   __syncthreads();
+  // prefix sums along the diagonals of E (one thread per lag and end): Hh[d][m] = sum_{s<m} x[s] x[s+d],  Ht[d][j] = the last j
+  // products of lag d; hx / tx likewise from the column sums.  (Summed per entry of R instead, a thread walked up to 62 dependent
+  // LDS reads for each of its four entries.)
   const float* Eh = tot_e;                              // E_head[s][c] = sum_rows x[s] x[c]
   const float* Et = tot_e + 32 * EC_EDGE;               // E_tail[i][c] = sum_rows x[T-1-i] x[T-1-c]
-  for (int i = tid; i < 64 * 64; i += 1024) {           // R[k][k'] = r[d] - [m > 0] sum_{s<m} x[s]x[s+d] - [m' < 0] (last -m' products of lag d)
+  if (tid < 128) {
+    const int d = tid & 63;
+    const float* E = tid < 64 ? Eh : Et;
+    double* P = tid < 64 ? Hh[d] : Ht[d];
+    double run = 0.0;
+    P[0] = 0.0;
+#pragma unroll 8
+    for (int s_ = 0; s_ < 32; ++s_) { run += (double)E[s_ * EC_EDGE + s_ + d]; P[s_ + 1] = run; }
+  } else if (tid < 130) {
+    const float* cs = tot_e + (64 + (tid - 128)) * EC_EDGE;
+    double* P = tid == 128 ? hx : tx;
+    double run = 0.0;
+    P[0] = 0.0;
+    for (int s_ = 0; s_ < 32; ++s_) { run += (double)cs[s_]; P[s_ + 1] = run; }
+  }
+  for (int i = tid; i < 8 * EC_K; i += 1024) sw[i] = w1[i];
+  __syncthreads();
+  for (int i = tid; i < 64 * 64; i += 1024) {           // R[k][k'] = r[d] - [m > 0] Hh[d][m] - [m' < 0] Ht[d][-m']   (k <= k', d = k' - k)
     int k = i >> 6, k2 = i & 63;
     if (k > k2) { const int t_ = k; k = k2; k2 = t_; }
     const int m = k - EC_PADL, m2 = k2 - EC_PADL, d = k2 - k;
     double v = tot_r[d];
-    for (int s_ = 0; s_ < m; ++s_) v -= (double)Eh[s_ * EC_EDGE + s_ + d];
-    for (int j = 0; j < -m2; ++j) v -= (double)Et[j * EC_EDGE + j + d];
+    if (m > 0) v -= Hh[d][m];
+    if (m2 < 0) v -= Ht[d][-m2];
     sR[i] = v;
     RS[i] = v;
   }
   if (tid < 64) {                                       // S[k] = sum x - [m > 0] sum_{s<m} x[s] - [m < 0] sum_{s >= T+m} x[s]
     const int m = tid - EC_PADL;
     double v = tot_r[64];
-    for (int s_ = 0; s_ < m; ++s_) v -= (double)tot_e[64 * EC_EDGE + s_];
-    for (int j = 0; j < -m; ++j) v -= (double)tot_e[65 * EC_EDGE + j];
+    if (m > 0) v -= hx[m];
+    if (m < 0) v -= tx[-m];
     sS[tid] = v;
     RS[4096 + tid] = v;
   }
   __syncthreads();
   {                                                     // per filter: w.S and w^T R w, 128 threads each
     const int f = tid >> 7, t = tid & 127;
-    const float* w = w1 + f * EC_K;
+    const float* w = sw + f * EC_K;
     double q = 0.0, l = 0.0;
     for (int i = t; i < 64 * 64; i += 128) q += (double)w[i >> 6] * (double)w[i & 63] * sR[i];
     if (t < 64) l = (double)w[t] * sS[t];

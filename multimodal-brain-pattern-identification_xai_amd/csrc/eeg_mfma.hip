@@ -303,18 +303,20 @@ int bx_eeg_conv1_wgrad_mfma_launch(const void* c1, const float* dd, const float*
 
 // ---- collapsed front end (eeg_collapse.hip), backward: C[fd][ch][k] = sum_{b,t} g[b][fd][t] x~[b][ch][t + k - 31] ---------------------
 // One workgroup per (electrode, split): it walks the samples b = split, split + nsplit, ... of its electrode.  Per sample the row's
-// two shifted bf16 copies are rebuilt in LDS (em_build_copies) and D[fd][k] += A[fd][t] B[t][k] runs as 16x16x32 MFMAs with time as
-// the reduction dimension: A = g rows (ALL 16 rows are real here; the per-filter kernel above fills 4 of 16), read straight from
-// global memory as fp32 and rounded to bf16 in registers (the 19 electrode workgroups of a sample share them through L2),
-// B = shifted x windows, 4 tap tiles of 16.  The four waves split the K-steps and keep their accumulators across samples; one
-// fixed-order sum through LDS at the end.  Partials [ch][split][16][64]; the electrode-0 workgroups also leave sum_t g (fp32).
-__global__ __launch_bounds__(256) void k_eegc_corr(const float* __restrict__ gmap, const float* __restrict__ x, float* __restrict__ cpart,
+// two shifted bf16 copies are rebuilt in LDS and D[fd][k] += A[fd][t] B[t][k] runs as 16x16x32 MFMAs with time as the reduction
+// dimension: A = g rows (ALL 16 rows are real here; the per-filter kernel above fills 4 of 16), B = shifted x windows, 4 tap tiles.
+// g arrives as bf16 [B][16][T] (written by the BatchNorm2 backward apply): a lane's A operand of a K-step is ONE 16-byte load, so a
+// wave's share of a WHOLE sample (NJ K-steps) fits 4 NJ registers and the NEXT sample's share -- and the next row's samples -- are
+// requested before the current sample is multiplied (with fp32 g each K-step group was an exposed round trip: 39 -> see DESIGN).
+// The four waves split the K-steps and keep their accumulators across samples; one fixed-order sum through LDS at the end.
+// Partials [ch][split][16][64]; the electrode-0 workgroups also leave sum_t g.
+template <int NJ>
+__global__ __launch_bounds__(256) void k_eegc_corr(const bf16_t* __restrict__ g16, const float* __restrict__ x, float* __restrict__ cpart,
                                                    float* __restrict__ gpart, EmGeom g, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) bf16_t lds_ec[];
   bf16_t* xs = lds_ec;                                  // [2][NP]
-  // Workgroups are dealt to the 8 XCDs round-robin by id.  The 19 electrode workgroups of a split read the same samples' gradient
-  // rows (128 KB per sample): they must share ONE XCD's L2, or every XCD fetches every sample (19 x 8 MB through the L2s, measured
-  // as the kernel's bound).  With nsplit % 8 == 0: XCD k = id % 8 takes the splits k, k + 8, ...; otherwise the plain order.
+  // Workgroups are dealt to the 8 XCDs round-robin by id: the electrode workgroups of a split read the same samples' gradient
+  // rows and should share ONE XCD's L2.  With nsplit % 8 == 0: XCD k = id % 8 takes the splits k, k + 8, ...
   int ch, split;
   if (nsplit % 8 == 0) {
     const int xk = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3, per = nsplit >> 3;
@@ -328,64 +330,58 @@ __global__ __launch_bounds__(256) void k_eegc_corr(const float* __restrict__ gma
 #pragma unroll
   for (int n = 0; n < 4; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float gs = 0.f;
-  // A wave's K-steps are ks = wave + 4 j.  Their A operands (two 16-byte loads per lane and K-step) are requested eight K-steps
-  // at a time into one of two register buffers, the next eight while the current eight are multiplied; the first eight of a
-  // sample are requested before the row's LDS copies are built (loaded inside the K-step loop each was an exposed round trip).
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
-  const int nj = (nk - wave + 3) / 4;                   // K-steps of this wave
+  const int nj = (nk - wave + 3) / 4;                   // K-steps of this wave: ks = wave + 4 j  (nj <= NJ, checked by the launcher)
   const int e0 = 8 * gq + li + (EM_OFF - EM_PADL);
+  // B[t][k]: lane (col k = 16 n + li, time 32 ks + 8 gq + j) -> xpad[e], e = 32 ks + 16 n + e0: the copy (parity of e) and the aligned
+  // start are per-lane constants, so a window is wbase + a uniform offset + an immediate
   const uint32_t* wbase = reinterpret_cast<const uint32_t*>(xs + (size_t)(e0 & 1) * g.NP + (e0 & ~1));
-  const bool pre = g.NP / 8 <= 512;                     // rows short enough for the two-item register prefetch
+  typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+  auto request = [&](int b, u32x4_ (&dst)[NJ]) {
+    const __amdgpu_buffer_rsrc_t gres = bx_rsrc(g16 + (size_t)b * 16 * Tn, (uint32_t)(16 * Tn) * 2u);        // wave-uniform: the sample's 16 rows
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int t0 = 32 * (wave + 4 * j) + 8 * gq;
+      // T % 8 == 0: a group of 8 is inside the row or past it; K-steps past this wave's share read zeros as well
+      const uint32_t off = (j < nj && t0 < Tn) ? (uint32_t)(li * Tn + t0) * 2u : 0x80000000u;
+      dst[j] = __builtin_amdgcn_raw_buffer_load_b128(gres, off, 0, 0);
+    }
+  };
+  auto multiply = [&](const u32x4_ (&src)[NJ]) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (j >= nj) break;                               // wave-uniform
+      const u32x4_ a = src[j];
+      if (ch == 0) {                                    // workgroup-uniform: sum_t g
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gs += __uint_as_float(a[q] << 16) + __uint_as_float(a[q] & 0xffff0000u);
+      }
+      const uint32_t* pw = wbase + 16 * (wave + 4 * j);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const u32x4_ d = {pw[8 * n], pw[8 * n + 1], pw[8 * n + 2], pw[8 * n + 3]};
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, d), acc[n], 0, 0, 0);
+      }
+    }
+  };
   EmRow row;
-  if (pre && split < g.B) em_row_request(x + ((size_t)split * g.Ch + ch) * Tn, Tn, g.NP, row);
-  for (int b = split; b < g.B; b += nsplit) {
-    const __amdgpu_buffer_rsrc_t gres = bx_rsrc(gmap + (size_t)b * 16 * Tn, (uint32_t)(16 * Tn) * 4u);      // wave-uniform: the sample's 16 rows
-    f4 bufA[2][8][2];
-    auto request = [&](int j0, f4 (&dst)[8][2]) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int t0 = 32 * (wave + 4 * (j0 + u)) + 8 * gq;
-        // T % 8 == 0: a group of 8 is inside the row or past it; K-steps past this wave's share read zeros as well
-        const uint32_t off = (j0 + u < nj && t0 < Tn) ? (uint32_t)(li * Tn + t0) * 4u : 0x80000000u;
-        dst[u][0] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(gres, off, 0, 0));
-        dst[u][1] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(gres, off + 16u, 0, 0));
-      }
-    };
-    auto multiply = [&](int j0, const f4 (&src)[8][2]) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (j0 + u >= nj) break;                        // wave-uniform
-        const int ks = wave + 4 * (j0 + u);
-        const f4 a0 = src[u][0], a1 = src[u][1];
-        if (ch == 0) gs += ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a1[0] + a1[1]) + (a1[2] + a1[3]));      // workgroup-uniform
-        const u32x4_ pk = {pack2bf(a0[0], a0[1]), pack2bf(a0[2], a0[3]), pack2bf(a1[0], a1[1]), pack2bf(a1[2], a1[3])};
-        const bf16x8 afr = __builtin_bit_cast(bf16x8, pk);
-        // B[t][k]: lane (col k = 16 n + li, time 32 ks + 8 gq + j) -> x[t + k - 31] = xpad[e], e = 32 ks + 16 n + (8 gq + li + 1): the
-        // copy (parity of e) and the aligned start are per-lane constants, so a window is wbase + a uniform offset + an immediate
-        const uint32_t* pw = wbase + 16 * ks;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          const u32x4_ d = {pw[8 * n], pw[8 * n + 1], pw[8 * n + 2], pw[8 * n + 3]};
-          acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, __builtin_bit_cast(bf16x8, d), acc[n], 0, 0, 0);
-        }
-      }
-    };
-    request(0, bufA[0]);
+  u32x4_ A0[NJ], A1[NJ];
+  if (split < g.B) {
+    em_row_request(x + ((size_t)split * g.Ch + ch) * Tn, Tn, g.NP, row);
+    request(split, A0);
+  }
+  auto sample = [&](int b, const u32x4_ (&cur)[NJ], u32x4_ (&nxt)[NJ]) {
     __syncthreads();                                    // the previous sample's window reads are done
-    if (pre) {
-      em_row_store(xs, g.NP, row);                      // requested while the previous sample was multiplied
-      __syncthreads();
-      if (b + nsplit < g.B) em_row_request(x + ((size_t)(b + nsplit) * g.Ch + ch) * Tn, Tn, g.NP, row);
-    } else {
-      em_build_copies(x + ((size_t)b * g.Ch + ch) * Tn, xs, Tn, g.NP);        // ends with a barrier
+    em_row_store(xs, g.NP, row);                        // requested while the previous sample was multiplied
+    __syncthreads();
+    if (b + nsplit < g.B) {
+      em_row_request(x + ((size_t)(b + nsplit) * g.Ch + ch) * Tn, Tn, g.NP, row);
+      request(b + nsplit, nxt);
     }
-    for (int j0 = 0; j0 < nj; j0 += 16) {
-      request(j0 + 8, bufA[1]);
-      multiply(j0, bufA[0]);
-      request(j0 + 16, bufA[0]);
-      multiply(j0 + 8, bufA[1]);
-    }
+    multiply(cur);
+  };
+  for (int b = split; b < g.B; b += 2 * nsplit) {
+    sample(b, A0, A1);
+    if (b + nsplit < g.B) sample(b + nsplit, A1, A0);
   }
   // D: lane (col k = 16 n + li, rows fd = 4 gq + r).  Sum the four waves in wave order.
   __syncthreads();
@@ -405,13 +401,21 @@ __global__ __launch_bounds__(256) void k_eegc_corr(const float* __restrict__ gma
     if (threadIdx.x < 16) gpart[split * 16 + threadIdx.x] = (red[threadIdx.x] + red[16 + threadIdx.x]) + (red[32 + threadIdx.x] + red[48 + threadIdx.x]);
   }
 }
-int bx_eegc_corr_launch(const float* gmap, const float* x, float* cpart, float* gpart, int B, int Ch, int T, int nsplit, hipStream_t s) {
+int bx_eegc_corr_max_T() { return 3072; }               // 24 K-steps per wave: two sample buffers of 96 registers
+int bx_eegc_corr_launch(const void* g16, const float* x, float* cpart, float* gpart, int B, int Ch, int T, int nsplit, hipStream_t s) {
   EmGeom g;
   g.B = B; g.Ch = Ch; g.T = T; g.NP = em_np(T);
+  if (g.NP / 8 > 512 || T > bx_eegc_corr_max_T() || T % 8) return -3;
   size_t lds = (size_t)2 * g.NP * sizeof(bf16_t);
   if (lds < 16384) lds = 16384;
   if (lds > 150 * 1024) return -1;
-  if (hipFuncSetAttribute((const void*)k_eegc_corr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-  hipLaunchKernelGGL(k_eegc_corr, dim3(Ch * nsplit), dim3(256), lds, s, gmap, x, cpart, gpart, g, nsplit);
+  const int njmax = ((T + 31) / 32 + 3) / 4;
+  if (njmax <= 16) {
+    if (hipFuncSetAttribute((const void*)k_eegc_corr<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+    hipLaunchKernelGGL(k_eegc_corr<16>, dim3(Ch * nsplit), dim3(256), lds, s, (const bf16_t*)g16, x, cpart, gpart, g, nsplit);
+  } else {
+    if (hipFuncSetAttribute((const void*)k_eegc_corr<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+    hipLaunchKernelGGL(k_eegc_corr<24>, dim3(Ch * nsplit), dim3(256), lds, s, (const bf16_t*)g16, x, cpart, gpart, g, nsplit);
+  }
   return 0;
 }
