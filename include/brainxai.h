@@ -74,6 +74,12 @@ int bx_conv3x3_pack_many(const bxPackJob* jobs_device, int njobs, int total_bloc
  * the two are independent and both sit at the start of every training step). */
 int bx_conv3x3_pack_many_layout(const bxPackJob* jobs_device, int njobs, int total_blocks, const float* src_nchw,
                                 void* dst_nhwc_bf16, int B, int C, int H, int W, int Cp, bxStream stream);
+/* The launch that opens a training step of the multimodal model (reference forward NB:1095-1105 with nn.Dropout in both
+ * branches): packing, the optional layout conversion (src_nchw / dst_nhwc_bf16 both NULL: none) and bx_seed_next2's work
+ * (both branches' dropout counters advance, out_a / out_b receive the seeds of this forward pass) in one launch. */
+int bx_conv3x3_pack_many_step(const bxPackJob* jobs_device, int njobs, int total_blocks, const float* src_nchw,
+                              void* dst_nhwc_bf16, int B, int C, int H, int W, int Cp, uint64_t* state_a, uint64_t* out_a,
+                              uint64_t* state_b, uint64_t* out_b, bxStream stream);
 /* y = epi(conv3x3(x, Wp) + bias);  x [B,H,W,Ci] -> y [B,H,W,Co], both `dtype`.
  *   bias (fp32 [Co]) may be NULL; flags & BX_EPI_RELU applies max(.,0);
  *   relu_mask_src (dtype [B,H,W,Co], may be NULL): y *= (relu_mask_src > 0)  -- the ReLU backward
@@ -384,8 +390,12 @@ int bx_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float 
  * l2_lambda, unused} (a captured hipGraph follows a learning-rate schedule without re-capture), and with the DDP loop's manual
  * L2 penalty fused in (root/src/training/training_distributed.py:52-57: total_loss = loss + l2_lambda * sum p^2): 2*l2_lambda*p
  * is added to the scaled gradient before the moment updates; when sumsq_partials (fp32[bx_adamw_partials(n)]) and l2_value
- * (fp32[1]) are given, l2_value[0] = l2_lambda * sum p^2 over the parameters BEFORE this update (fixed-order sum). */
+ * (fp32[1]) are given, l2_value[0] = l2_lambda * sum p^2 over the parameters BEFORE this update (fixed-order sum).
+ * step_count here is a device buffer of bx_adamw_step_words(n) 32-bit words: [0] the step count (float, incremented by this
+ * call in the update launch itself and then used as t), the rest ticket counters the launch uses to find its last workgroup --
+ * zero on entry, zero again on completion; concurrent launches must not share the buffer. */
 size_t bx_adamw_partials(size_t n);
+size_t bx_adamw_step_words(size_t n);
 int bx_adamw_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, float* step_count,
                       float* sumsq_partials, float* l2_value, bxStream stream);
 /* sum of squares of a flat fp32 arena -> out[1] (DDP loop's manual L2 term, DDP:52-53). */

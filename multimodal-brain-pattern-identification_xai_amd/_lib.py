@@ -75,6 +75,7 @@ SIGNATURES = {
     "bx_conv3x3_packed_mfma_bytes": (sz, [i32, i32]),
     "bx_conv3x3_pack_many": (i32, [vp, i32, i32, vp]),
     "bx_conv3x3_pack_many_layout": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "bx_conv3x3_pack_many_step": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "bx_scale_dev": (i32, [vp, vp, vp, sz, vp]),
     "bx_abs": (i32, [vp, vp, sz, vp]),
     "bx_conv3x3": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
@@ -129,6 +130,7 @@ SIGNATURES = {
     "bx_spec_regions": (i32, [vp, vp, vp] + [i32] * 7 + [P(C.c_double), i32, P(C.c_double), i32, f32, vp, sz, vp]),
     "bx_adamw_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, f32, vp, vp]),
     "bx_adamw_partials": (sz, [sz]),
+    "bx_adamw_step_words": (sz, [sz]),
     "bx_adamw_step_dev": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
     "bx_sumsq": (i32, [vp, sz, vp, vp]),
     "bx_u8_to_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),

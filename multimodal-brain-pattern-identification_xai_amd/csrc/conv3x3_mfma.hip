@@ -67,8 +67,16 @@ void bx_conv3x3_mfma_pack_launch(const float* w_oihw, void* packed, int Cout, in
 // table lives in device memory and is built once by the host (parameter pointers are stable under FlatAdamW).
 // Optional second role (workgroups >= npack): the batch's fp32 NCHW -> bf16 NHWC(Cp) conversion, which is independent of
 // the packing and otherwise a launch of its own at the start of every step (lsrc == nullptr: no such workgroups).
+// Optional third role (round 2): the dropout counters of the two branches advance here (thread 0 / 1 of workgroup 0; sa == nullptr:
+// not wanted) -- this launch opens the training step, every consumer of the seeds is a later launch.
 __global__ __launch_bounds__(256) void k_pack_mfma_many(const bxPackJob* __restrict__ jobs, int njobs, int npack, const float* __restrict__ lsrc,
-                                                        bf16_t* __restrict__ ldst, int C, int Cp, int HW, int nbx) {
+                                                        bf16_t* __restrict__ ldst, int C, int Cp, int HW, int nbx,
+                                                        uint64_t* sa, uint64_t* oa, uint64_t* sb, uint64_t* ob) {
+  if (sa && blockIdx.x == 0 && threadIdx.x < 2) {
+    uint64_t* st = threadIdx.x ? sb : sa;
+    uint64_t* ou = threadIdx.x ? ob : oa;
+    const uint64_t v = st[0] + 1; st[0] = v; ou[0] = v;
+  }
   if ((int)blockIdx.x >= npack) {
     const int lb = (int)blockIdx.x - npack, b = lb / nbx, r = (lb - b * nbx) * 256 + (int)threadIdx.x;
     if (r >= HW) return;
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256) void k_pack_mfma_many(const bxPackJob* __restr
 extern "C" int bx_conv3x3_pack_many(const bxPackJob* jobs_device, int njobs, int total_blocks, bxStream stream) {
   BX_REQUIRE(jobs_device && njobs > 0 && total_blocks > 0, "bx_conv3x3_pack_many: bad arguments");
   hipLaunchKernelGGL(k_pack_mfma_many, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs, total_blocks,
-                     (const float*)nullptr, (bf16_t*)nullptr, 0, 0, 0, 1);
+                     (const float*)nullptr, (bf16_t*)nullptr, 0, 0, 0, 1, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr);
   BX_CHECK_LAUNCH("bx_conv3x3_pack_many");
   return BX_OK;
 }
@@ -143,8 +151,28 @@ extern "C" int bx_conv3x3_pack_many_layout(const bxPackJob* jobs_device, int njo
   const long long nbx = (HW + 255) / 256;
   BX_REQUIRE(HW < (1ll << 31) && nbx * B + total_blocks < (1ll << 31), "bx_conv3x3_pack_many_layout: input too large");
   hipLaunchKernelGGL(k_pack_mfma_many, dim3((unsigned)(total_blocks + nbx * B)), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs,
-                     total_blocks, src_nchw, (bf16_t*)dst_nhwc_bf16, C, Cp, (int)HW, (int)nbx);
+                     total_blocks, src_nchw, (bf16_t*)dst_nhwc_bf16, C, Cp, (int)HW, (int)nbx, (uint64_t*)nullptr, (uint64_t*)nullptr,
+                     (uint64_t*)nullptr, (uint64_t*)nullptr);
   BX_CHECK_LAUNCH("bx_conv3x3_pack_many_layout");
+  return BX_OK;
+}
+extern "C" int bx_conv3x3_pack_many_step(const bxPackJob* jobs_device, int njobs, int total_blocks, const float* src_nchw, void* dst_nhwc_bf16,
+                                         int B, int C, int H, int W, int Cp, uint64_t* state_a, uint64_t* out_a, uint64_t* state_b,
+                                         uint64_t* out_b, bxStream stream) {
+  BX_REQUIRE(jobs_device && njobs > 0 && total_blocks > 0, "bx_conv3x3_pack_many_step: bad arguments");
+  BX_REQUIRE((src_nchw == nullptr) == (dst_nhwc_bf16 == nullptr), "bx_conv3x3_pack_many_step: src and dst go together");
+  BX_REQUIRE(state_a && out_a && state_b && out_b && state_a != state_b, "bx_conv3x3_pack_many_step: four seed pointers, two distinct states");
+  long long HW = 0, nbx = 1, extra = 0;
+  if (src_nchw) {
+    BX_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Cp % 8 == 0 && C <= Cp, "bx_conv3x3_pack_many_step: Cp must be a multiple of 8 and >= C");
+    HW = (long long)H * W;
+    nbx = (HW + 255) / 256;
+    extra = nbx * B;
+    BX_REQUIRE(HW < (1ll << 31) && extra + total_blocks < (1ll << 31), "bx_conv3x3_pack_many_step: input too large");
+  }
+  hipLaunchKernelGGL(k_pack_mfma_many, dim3((unsigned)(total_blocks + extra)), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs,
+                     total_blocks, src_nchw, (bf16_t*)dst_nhwc_bf16, C, Cp, (int)HW, (int)nbx, state_a, out_a, state_b, out_b);
+  BX_CHECK_LAUNCH("bx_conv3x3_pack_many_step");
   return BX_OK;
 }
 

@@ -397,9 +397,13 @@ __global__ __launch_bounds__(256) void k_eegc_grads_ch(const float* __restrict__
       sC[tid + 256 * q] = a;
     }
   }
-  if (tid < 16) {
+  if (tid < 16) {                                       // nsplit <= EEGC_MAXS loads in flight together, summed in split order
+    float v[EEGC_MAXS];
+#pragma unroll
+    for (int sp = 0; sp < EEGC_MAXS; ++sp) v[sp] = gpart[(sp < nsplit ? sp : nsplit - 1) * 16 + tid];
     float a = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) a += gpart[sp * 16 + tid];
+#pragma unroll
+    for (int sp = 0; sp < EEGC_MAXS; ++sp) a += sp < nsplit ? v[sp] : 0.f;
     sG[tid] = a;
   }
   __syncthreads();
@@ -431,31 +435,41 @@ __global__ __launch_bounds__(512) void k_eegc_grads_final(const float* __restric
   __shared__ double sQ[8], sk1[8], sk2[8];
   __shared__ float sG[16];
   const int tid = threadIdx.x;
-  for (int i = tid; i < 64 * 64 + 64; i += 512) sRS[i] = RS[i];
-  sw[tid] = w1[tid];
-  // sum over the electrodes: this thread's column of ep (8 + 512 columns, thread tid -> column 8 + tid), loads batched by 8
-  double dyx = 0.0;
-  for (int c0 = 0; c0 < Ch; c0 += 8) {
-    float v[8];
+  {                                                     // all nine of a thread's R / S loads in flight together (a rolled copy loop is
+    double rs[9];                                       // nine serial round trips in a one-workgroup kernel: nothing else hides them)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) v[c] = ep[(size_t)(c0 + c < Ch ? c0 + c : Ch - 1) * 520 + 8 + tid];
+    for (int q = 0; q < 9; ++q) { const int i = tid + 512 * q; rs[q] = RS[i < 64 * 64 + 64 ? i : 64 * 64 + 63]; }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) dyx += c0 + c < Ch ? (double)v[c] : 0.0;
+    for (int q = 0; q < 9; ++q) { const int i = tid + 512 * q; if (i < 64 * 64 + 64) sRS[i] = rs[q]; }
   }
-  if (tid < 16) {
+  sw[tid] = w1[tid];
+  // sum over the electrodes: this thread's column of ep (8 + 512 columns, thread tid -> column 8 + tid), loads batched by 32
+  double dyx = 0.0;
+  for (int c0 = 0; c0 < Ch; c0 += 32) {
+    float v[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) v[c] = ep[(size_t)(c0 + c < Ch ? c0 + c : Ch - 1) * 520 + 8 + tid];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) dyx += c0 + c < Ch ? (double)v[c] : 0.0;
+  }
+  if (tid < 16) {                                       // nsplit <= EEGC_MAXS loads in flight together, summed in split order
+    float v[EEGC_MAXS];
+#pragma unroll
+    for (int sp = 0; sp < EEGC_MAXS; ++sp) v[sp] = gpart[(sp < nsplit ? sp : nsplit - 1) * 16 + tid];
     float a = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) a += gpart[sp * 16 + tid];
+#pragma unroll
+    for (int sp = 0; sp < EEGC_MAXS; ++sp) a += sp < nsplit ? v[sp] : 0.f;
     sG[tid] = a;
   }
   if (tid >= 64 && tid < 72) {                          // Q[f]: the electrodes' contributions, loads batched by 8
     const int f = tid - 64;
     double a = 0.0;
-    for (int c0 = 0; c0 < Ch; c0 += 8) {
-      float v[8];
+    for (int c0 = 0; c0 < Ch; c0 += 32) {
+      float v[32];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) v[c] = ep[(size_t)(c0 + c < Ch ? c0 + c : Ch - 1) * 520 + f];
+      for (int c = 0; c < 32; ++c) v[c] = ep[(size_t)(c0 + c < Ch ? c0 + c : Ch - 1) * 520 + f];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) a += c0 + c < Ch ? (double)v[c] : 0.0;
+      for (int c = 0; c < 32; ++c) a += c0 + c < Ch ? (double)v[c] : 0.0;
     }
     sQ[f] = a;
   }

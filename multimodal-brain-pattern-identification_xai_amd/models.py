@@ -99,14 +99,16 @@ class Spectrogram_Model(nn.Module):
         self.log_softmax = nn.LogSoftmax(dim=1)
         self.compute_dtype = torch.float32
 
-    def _pack_all(self, x=None):
+    def _pack_all(self, x=None, seed_pair=False):
         """bf16 MFMA path: ONE launch packs the forward and data-gradient operands of all 15 convolutions -- and, when the raw
-        batch ``x`` (fp32 NCHW, no gradient wanted) is given, converts it to the internal layout as well (returned, else None)."""
+        batch ``x`` (fp32 NCHW, no gradient wanted) is given, converts it to the internal layout as well (returned, else None).
+        ``seed_pair=True`` (MultimodalModel's training forward): the same launch advances both branches' dropout counters and the
+        return value is (xi, spectrogram seed, EEG seed); without the MFMA path the seeds come from their own launch."""
         blocks = [getattr(self, f"block{i}") for i in range(1, 6)]
         for blk in blocks:
             blk._prepacked = None
         if self.compute_dtype != torch.bfloat16 or ops.CONV_ALGO == ops.L.BX_ALGO_DIRECT or not self.fc.weight.is_cuda:
-            return None
+            return (None,) + tuple(ops.next_seed_pair(x.device)) if seed_pair else None
         weights = [getattr(b, f"conv{k}").weight for b in blocks for k in (1, 2, 3)]
         plan = getattr(self, "_pack_plan", None)
         if plan is None or plan.key != tuple(w.data_ptr() for w in weights):
@@ -114,16 +116,22 @@ class Spectrogram_Model(nn.Module):
             self._pack_plan = plan
         raw = (x is not None and x.is_cuda and x.dim() == 4 and x.shape[1] == blocks[0].in_channels and not x.requires_grad
                and not _is_internal(x, torch.bfloat16) and blocks[0].compute_dtype == torch.bfloat16)
-        xi = plan.run(x if raw else None)
+        if seed_pair and plan.njobs:
+            res = plan.run_step(x if raw else None)
+        elif seed_pair:
+            res = (plan.run(x if raw else None),) + tuple(ops.next_seed_pair(x.device))
+        else:
+            res = plan.run(x if raw else None)
         for bi, blk in enumerate(blocks):
             blk._prepacked, blk._pack_base = plan, 3 * bi
-        return xi
+        return res
 
-    def features(self, x, seed=None, cut=None):
+    def features(self, x, seed=None, cut=None, packed=None):
         """``cut = (k, fn)``: the activation leaving stage k is handed to ``fn`` and its return value feeds stage k+1 -- the
         data-parallel step uses it to cut autograd there (fn detaches), so that the gradients of the late stages (88 % of the
-        parameter bytes, finished first) can be all-reduced while the early stages' backward still runs."""
-        xi = self._pack_all(x)
+        parameter bytes, finished first) can be all-reduced while the early stages' backward still runs.
+        ``packed``: the caller already ran ``_pack_all`` for this forward pass and hands over its result (a 1-tuple)."""
+        xi = packed[0] if packed is not None else self._pack_all(x)
         if xi is not None:
             x = xi                                          # already in the internal layout (same launch as the weight packing)
         blocks = [getattr(self, f"block{i}") for i in range(1, 6)]
@@ -301,11 +309,12 @@ class MultimodalModel(nn.Module):
             if not self._fusable():
                 raise RuntimeError("brainxai MultimodalModel: cut= needs the un-hooked reference architecture (fused head path)")
             em, sm = self.eeg_model, self.spectrogram_model
-            ss = se = None
+            ss = se = packed = None
             if self.training and em.dropout.p > 0 and any(getattr(sm, f"block{i}").dropout.p > 0 for i in range(1, 6)):
-                ss, se = ops.next_seed_pair(eeg_data.device)
+                xi, ss, se = sm._pack_all(spectrogram_data, seed_pair=True)
+                packed = (xi,)
             ef = em.features(eeg_data, seed=se)
-            sf = sm.features(spectrogram_data, seed=ss, cut=cut)
+            sf = sm.features(spectrogram_data, seed=ss, cut=cut, packed=packed)
             return ops.MultimodalHeadFn.apply(sf.permute(0, 2, 3, 1), ef, sm.fc.weight, sm.fc.bias, em.dense.weight, em.dense.bias,
                                               self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
         if ops.OVERLAP and eeg_data.is_cuda and ops.CONV_PROFILE is None:
@@ -322,11 +331,13 @@ class MultimodalModel(nn.Module):
         elif self._fusable():
             # one launch for GAP+fc, dense and the fusion head (same arithmetic as the three separate ops below)
             em, sm = self.eeg_model, self.spectrogram_model
-            ss = se = None
+            ss = se = packed = None
             if self.training and em.dropout.p > 0 and any(getattr(sm, f"block{i}").dropout.p > 0 for i in range(1, 6)):
-                ss, se = ops.next_seed_pair(eeg_data.device)    # both branches' dropout seeds from one launch
+                # both branches' dropout seeds ride in the weight-packing launch, which therefore opens the step
+                xi, ss, se = sm._pack_all(spectrogram_data, seed_pair=True)
+                packed = (xi,)
             ef = em.features(eeg_data, seed=se)
-            sf = sm.features(spectrogram_data, seed=ss)
+            sf = sm.features(spectrogram_data, seed=ss, packed=packed)
             if ef.shape[1] != em.dense.in_features:
                 raise RuntimeError(f"EEGNet: {ef.shape[1]} features but dense expects {em.dense.in_features} (Samples mismatch)")
             return ops.MultimodalHeadFn.apply(sf.permute(0, 2, 3, 1), ef, sm.fc.weight, sm.fc.bias, em.dense.weight, em.dense.bias,

@@ -296,6 +296,22 @@ class PackPlan:
         raw = bytes(memoryview(jobs)) if entries else b"\0" * 8
         self.jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
 
+    def run_step(self, x_nchw=None):
+        """run() + next_seed_pair() in ONE launch (the launch that opens a multimodal training step): returns
+        (batch in the internal layout or None, spectrogram-lane seed, EEG-lane seed)."""
+        dev = self.buf.device
+        seeds = torch.empty(2, dtype=torch.int64, device=dev)
+        out, src, dims = None, None, (0, 0, 0, 0, 8)
+        if x_nchw is not None:
+            B, Cc, H, W = x_nchw.shape
+            src = x_nchw.detach().to(torch.float32).contiguous()
+            out = torch.empty(B, H, W, pad8(Cc), dtype=torch.bfloat16, device=dev)
+            dims = (B, Cc, H, W, pad8(Cc))
+        L.check(L.load().bx_conv3x3_pack_many_step(_p(self.jobs_dev), self.njobs, self.nblocks, _p(src), _p(out), *dims,
+                                                   _p(seed_state(dev, "spec")), seeds.data_ptr(), _p(seed_state(dev, "eeg")),
+                                                   seeds.data_ptr() + 8, _stream()), "bx_conv3x3_pack_many_step")
+        return (None if out is None else out.permute(0, 3, 1, 2)), seeds[0:1], seeds[1:2]
+
     def run(self, x_nchw=None):
         """Pack every operand; with ``x_nchw`` (fp32 NCHW, no gradient needed) the same launch also produces the batch in the
         internal bf16 channels-last layout and returns it as a logical-NCHW view."""

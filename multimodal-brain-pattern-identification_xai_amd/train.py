@@ -69,7 +69,9 @@ class FlatAdamW(torch.optim.Optimizer):
         self._grad_key = ops.register_grad_views(self.params, self.flat_g)
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
-        self.step_t = torch.zeros(1, dtype=torch.float32, device=dev)
+        # [step count | ticket counters of bx_adamw_step_dev]
+        self._step_buf = torch.zeros(int(L.load().bx_adamw_step_words(self.n)) if dev.type == "cuda" else 1, dtype=torch.float32, device=dev)
+        self.step_t = self._step_buf[:1]
         self.grad_scale = 1.0
         self.l2_lambda = 0.0
         self.is_cuda = dev.type == "cuda"

@@ -15,6 +15,7 @@ f=$(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1)
 echo "stats done: $f" >> $R/gpurun_out/${tag}_log.txt
 rocprofv3 --kernel-trace -d /tmp/prof_steps -- python3 $R/tools/step_profile.py --steps 50 > /tmp/prof_steps.out 2>&1
 python3 $R/tools/step_profile.py --summarize /tmp/prof_steps --steps 50 > $R/gpurun_out/${tag}_step_breakdown.txt 2>> $R/gpurun_out/${tag}_log.txt
+python3 $R/tools/step_profile.py --timeline /tmp/prof_steps --steps 50 > $R/gpurun_out/${tag}_step_timeline.txt 2>> $R/gpurun_out/${tag}_log.txt
 echo "breakdown done" >> $R/gpurun_out/${tag}_log.txt
 BX_GRAPH_LOOPS=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_fetch -- python3 $R/tools/step_profile.py --steps 4 > /tmp/prof_fetch.out 2>&1
 BX_GRAPH_LOOPS=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_write -- python3 $R/tools/step_profile.py --steps 4 > /tmp/prof_write.out 2>&1

@@ -43,6 +43,29 @@ def run(steps):
     print(f"steps {steps}  ms/step {e0.elapsed_time(e1) / steps:.4f}  loss {float(loss):.5f}")
 
 
+def run_gradcam(steps):
+    """`steps` replayed Grad-CAM sweep batches (eval mode, B=64, all classes, maps upsampled): the other half of the metric."""
+    import torch
+    import brainxai
+    dev = torch.device("cuda", 0)
+    B = 64
+    g = torch.Generator().manual_seed(42)
+    spec = torch.rand(B, 4, 128, 256, generator=g).to(dev)
+    eeg = torch.randn(B, 1, 19, 2000, generator=g).to(dev)
+    model = brainxai.build_multimodal(19, 2000, 4, dropout=0.5, compute_dtype=torch.bfloat16).to(dev).eval()
+    sweep = brainxai.GradCamSweep(model, eeg, spec, class_idx="all")
+    for _ in range(3):
+        sweep(eeg, spec)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        out = sweep(eeg, spec)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"batches {steps}  ms/batch {e0.elapsed_time(e1) / steps:.4f}  checksum {float(out.sum()):.6g}")
+
+
 def summarize(out_dir, steps):
     db = sorted(glob.glob(os.path.join(out_dir, "**", "*.db"), recursive=True))[-1]
     con = sqlite3.connect(db)
@@ -67,6 +90,44 @@ def summarize(out_dir, steps):
     print(f"{'kernel':60s} {'launches/step':>13s} {'avg us':>9s} {'us/step':>9s} {'share':>7s}")
     for k, (cnt, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"{k[:60]:60s} {cnt / steps:13.2f} {tot / cnt / 1e3:9.2f} {tot / steps / 1e3:9.1f} {100.0 * tot / busy:6.1f}%")
+
+
+def timeline(out_dir, steps, delim="k_adamw"):
+    """One line per launch of a step, in launch order: duration averaged over the replayed steps (every step is the same
+    sequence), start offset inside the step, grid and workgroup size -- tells the stages of a shared kernel apart."""
+    db = sorted(glob.glob(os.path.join(out_dir, "**", "*.db"), recursive=True))[-1]
+    con = sqlite3.connect(db)
+    cols = [r[1] for r in con.execute("pragma table_info(rocpd_kernel_dispatch)")]
+    gcol = "d.grid_size_x, d.grid_size_y, d.workgroup_size_x" if "grid_size_x" in cols else "0, 0, 0"
+    rows = list(con.execute(f"select s.kernel_name, d.start, d.end, {gcol} from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
+                            "on d.kernel_id = s.id order by d.start"))
+    names = sorted({r[0] for r in rows})
+    dem = subprocess.run(["c++filt"], input="\n".join(n.replace(".kd", "") for n in names), capture_output=True, text=True).stdout.split("\n")
+    short = {n: re.sub(r"\(.*", "", d).replace("void ", "") for n, d in zip(names, dem)}
+    ends = [i for i, r in enumerate(rows) if short[r[0]].startswith(delim)]
+    per = ends[-1] - ends[-2]
+    acc = [[0.0, 0.0, 0.0] for _ in range(per)]
+    used = 0
+    for k in range(steps):
+        hi = ends[-1 - k]
+        lo = hi - per + 1
+        if lo < 0 or ends[-2 - k] != lo - 1:
+            continue
+        used += 1
+        t0 = rows[lo][1]
+        for j in range(per):
+            r = rows[lo + j]
+            acc[j][0] += r[2] - r[1]
+            acc[j][1] += r[1] - t0
+            acc[j][2] += (rows[lo + j + 1][1] - r[2]) if j + 1 < per else 0.0
+    print(f"# launch timeline of one training step, averaged over {used} hipGraph-replayed steps: {per} launches")
+    print(f"{'#':>3s} {'start us':>9s} {'dur us':>8s} {'gap us':>7s} {'grid':>12s} {'wg':>5s}  kernel")
+    lo = ends[-1] - per + 1
+    for j in range(per):
+        r = rows[lo + j]
+        wg = max(int(r[5]), 1)
+        print(f"{j:3d} {acc[j][1] / used / 1e3:9.1f} {acc[j][0] / used / 1e3:8.2f} {acc[j][2] / used / 1e3:7.2f} "
+              f"{int(r[3]) // wg:6d}x{int(r[4]):<5d} {wg:5d}  {short[r[0]][:70]}")
 
 
 def pmc_summarize(fetch_dir, write_dir, steps):
@@ -137,12 +198,19 @@ if __name__ == "__main__":
     ap.add_argument("--summarize", default=None)
     ap.add_argument("--pmc", nargs=2, default=None, metavar=("FETCH_DIR", "WRITE_DIR"))
     ap.add_argument("--sq", default=None, metavar="DIR")
+    ap.add_argument("--timeline", default=None, metavar="DIR")
+    ap.add_argument("--delim", default="k_adamw", help="kernel-name prefix of the launch that closes a step (timeline mode)")
+    ap.add_argument("--gradcam", action="store_true", help="run the configs[3] Grad-CAM sweep batches instead of training steps")
     a = ap.parse_args()
-    if a.sq:
+    if a.timeline:
+        timeline(a.timeline, a.steps, a.delim)
+    elif a.sq:
         sq_summarize(a.sq, a.steps)
     elif a.pmc:
         pmc_summarize(a.pmc[0], a.pmc[1], a.steps)
     elif a.summarize:
         summarize(a.summarize, a.steps)
+    elif a.gradcam:
+        run_gradcam(a.steps)
     else:
         run(a.steps)
