@@ -96,11 +96,14 @@ __global__ __launch_bounds__(256) void k_gradcam_head(const T* __restrict__ A, c
     float* part = ds + N;                                     // [slots][C] scratch behind the small vectors
     const int cg = tid % ncg, slot = tid / ncg;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int p = slot; p < HW; p += slots) {
-      float v[8];
-      ld8(a, (size_t)p * C + cg * 8, v);
+    for (int p0 = slot; p0 < HW; p0 += 8 * slots) {         // eight 16-byte loads in flight per trip (clamped index, masked add)
+      float v[8][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+      for (int u = 0; u < 8; ++u) { const int p = p0 + u * slots; ld8(a, (size_t)(p < HW ? p : HW - 1) * C + cg * 8, v[u]); }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += p0 + u * slots < HW ? v[u][j] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) part[slot * C + cg * 8 + j] = acc[j];
@@ -116,7 +119,13 @@ __global__ __launch_bounds__(256) void k_gradcam_head(const T* __restrict__ A, c
   // ---- fc + LogSoftmax (spectrogram branch head)
   for (int n = wave; n < N; n += 4) {
     float acc = 0.f;
-    for (int k = lane; k < C; k += 64) acc = fmaf(fcw[(size_t)n * C + k], gap[k], acc);
+    for (int k0 = lane; k0 < C; k0 += 256) {
+      float wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wv[u] = fcw[(size_t)n * C + (k0 + 64 * u < C ? k0 + 64 * u : 0)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = k0 + 64 * u < C ? fmaf(wv[u], gap[k0 + 64 * u], acc) : acc;
+    }
     acc = wave_sum(acc);
     if (lane == 0) ds[n] = acc + fcb[n];             // logits parked in ds
   }
@@ -131,9 +140,15 @@ __global__ __launch_bounds__(256) void k_gradcam_head(const T* __restrict__ A, c
   }
   __syncthreads();
   // ---- fusion head forward
-  for (int j = tid; j < Hd; j += 256) {
-    float acc = b1[j];
-    for (int i = 0; i < 2 * N; ++i) acc = fmaf(w1[(size_t)j * 2 * N + i], cat[i], acc);
+  for (int j = tid; j < Hd; j += 256) {                 // (rows of small matrices: all of a batch's loads before the first FMA -- a rolled
+    float acc = b1[j];                                  //  loop is one L2 round trip per element, and nothing else runs in this workgroup)
+    for (int i0 = 0; i0 < 2 * N; i0 += 16) {
+      float wv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) wv[u] = w1[(size_t)j * 2 * N + (i0 + u < 2 * N ? i0 + u : 2 * N - 1)];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = i0 + u < 2 * N ? fmaf(wv[u], cat[i0 + u], acc) : acc;
+    }
     hid[j] = fmaxf(acc, 0.f);
   }
   __syncthreads();
@@ -150,7 +165,7 @@ __global__ __launch_bounds__(256) void k_gradcam_head(const T* __restrict__ A, c
     float se = 0.f;
     for (int n = 0; n < N; ++n) se += expf(dz[n] - mx);
     const float lse = mx + logf(se);
-    for (int n = 0; n < N; ++n) { lp[n] = dz[n] - lse; if (out_lp) out_lp[(size_t)b * N + n] = lp[n]; }
+    for (int n = 0; n < N; ++n) { lp[n] = dz[n] - lse; if (out_lp && blockIdx.y == 0) out_lp[(size_t)b * N + n] = lp[n]; }
   }
   __syncthreads();
   int first = class_mode, nm = 1;
@@ -159,7 +174,11 @@ __global__ __launch_bounds__(256) void k_gradcam_head(const T* __restrict__ A, c
     first = 0;
     for (int n = 1; n < N; ++n) if (lp[n] > lp[first]) first = n;
   }
-  for (int ci = 0; ci < nm; ++ci) {
+  // all classes: the launcher gives every (sample, class) its own workgroup (grid.y = N; the forward part above is recomputed, the
+  // stage output comes from L2 for all but the first of a sample's workgroups) -- one workgroup per sample walked the classes
+  // serially on a quarter of the chip (64 workgroups, 66 us per batch of 64)
+  const int ci_lo = gridDim.y > 1 ? (int)blockIdx.y : 0, ci_hi = gridDim.y > 1 ? (int)blockIdx.y + 1 : nm;
+  for (int ci = ci_lo; ci < ci_hi; ++ci) {
     const int c = first + ci;
     // ---- backward of the fused head for the score y_c = lp[c]:  d logits = onehot(c) - softmax
     if (tid < N) {                                       // (1 - p_c) as the sum of the other probabilities: no cancellation when p_c -> 1
@@ -170,7 +189,13 @@ __global__ __launch_bounds__(256) void k_gradcam_head(const T* __restrict__ A, c
     __syncthreads();
     for (int j = tid; j < Hd; j += 256) {
       float acc = 0.f;
-      for (int n = 0; n < N; ++n) acc = fmaf(w2[(size_t)n * Hd + j], dz[n], acc);
+      for (int n0 = 0; n0 < N; n0 += 8) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = w2[(size_t)(n0 + u < N ? n0 + u : N - 1) * Hd + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = n0 + u < N ? fmaf(wv[u], dz[n0 + u], acc) : acc;
+      }
       dhid[j] = hid[j] > 0.f ? acc : 0.f;
     }
     __syncthreads();
@@ -186,25 +211,67 @@ __global__ __launch_bounds__(256) void k_gradcam_head(const T* __restrict__ A, c
     float* wdst = wout ? wout + ((size_t)b * nm + ci) * C : nullptr;
     for (int k = tid; k < C; k += 256) {                 // through fc and the mean over positions: w = W_fc^T dz_s / HW
       float acc = 0.f;
-      for (int i = 0; i < N; ++i) acc = fmaf(fcw[(size_t)i * C + k], dz[i], acc);
+      for (int n0 = 0; n0 < N; n0 += 8) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = fcw[(size_t)(n0 + u < N ? n0 + u : N - 1) * C + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = n0 + u < N ? fmaf(wv[u], dz[n0 + u], acc) : acc;
+      }
       acc *= inv_hw;
       w[k] = acc;
       if (wdst) wdst[k] = acc;
     }
     __syncthreads();
     const size_t mbase = ((size_t)b * nm + ci) * HW;
-    for (int p = wave; p < HW; p += 4) {
-      float acc = 0.f;
-      for (int k0 = lane * 8; k0 < C; k0 += 512) {
-        float v[8];
-        ld8(a, (size_t)p * C + k0, v);
+    if (C <= 512) {
+      // a position's channels sit on C/8 neighbouring lanes (one 16-byte load each), 64 / (C/8) positions per wave at a time, eight
+      // such groups in flight per trip; the channel weights of a lane are loop-invariant registers; segmented butterfly sum
+      const int lpp = C / 8, ppw = 64 / lpp, sub = lane / lpp, cg = lane - sub * lpp;
+      float wr[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc = fmaf(w[k0 + j], v[j], acc);
+      for (int j = 0; j < 8; ++j) wr[j] = w[cg * 8 + j];
+      const int ngrp = (HW + ppw - 1) / ppw;                 // position groups of the map; wave takes groups wave, wave + 4, ...
+      for (int g0 = wave; g0 < ngrp; g0 += 4 * 8) {
+        float v[8][8], acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int p = (g0 + 4 * u) * ppw + sub;
+          ld8(a, (size_t)(p < HW ? p : HW - 1) * C + cg * 8, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          float t = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t = fmaf(wr[j], v[u][j], t);
+          for (int o = lpp >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+          acc[u] = t;
+        }
+        if (cg == 0) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int p = (g0 + 4 * u) * ppw + sub;
+            if (g0 + 4 * u < ngrp && p < HW) {
+              cam[mbase + p] = relu ? fmaxf(acc[u], 0.f) : acc[u];
+              if (raw) raw[mbase + p] = acc[u];
+            }
+          }
+        }
       }
-      acc = wave_sum(acc);
-      if (lane == 0) {
-        cam[mbase + p] = relu ? fmaxf(acc, 0.f) : acc;
-        if (raw) raw[mbase + p] = acc;
+    } else {
+      for (int p = wave; p < HW; p += 4) {
+        float acc = 0.f;
+        for (int k0 = lane * 8; k0 < C; k0 += 512) {
+          float v[8];
+          ld8(a, (size_t)p * C + k0, v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc = fmaf(w[k0 + j], v[j], acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+          cam[mbase + p] = relu ? fmaxf(acc, 0.f) : acc;
+          if (raw) raw[mbase + p] = acc;
+        }
       }
     }
     __syncthreads();
@@ -221,7 +288,7 @@ extern "C" int bx_gradcam_head(const void* A, const float* eeg_logp, const float
   BX_REQUIRE(class_mode >= -2 && class_mode < N, "bx_gradcam_head: class %d out of range", class_mode);
   const size_t lds = ((size_t)2 * C + 2 * Hd + 5 * N + (size_t)(256 / (C / 8)) * C) * sizeof(float);
   BX_DISPATCH_DTYPE(dtype, T,
-    hipLaunchKernelGGL((k_gradcam_head<T>), dim3(B), dim3(256), lds, (hipStream_t)stream, (const T*)A, eeg_logp, fc_w, fc_b, w1, b1, w2, b2,
+    hipLaunchKernelGGL((k_gradcam_head<T>), dim3(B, class_mode == -2 ? N : 1), dim3(256), lds, (hipStream_t)stream, (const T*)A, eeg_logp, fc_w, fc_b, w1, b1, w2, b2,
                        out_logp, cam, raw, weights_out, HW, C, N, Hd, class_mode, relu));
   BX_CHECK_LAUNCH("bx_gradcam_head");
   return BX_OK;

@@ -28,12 +28,15 @@ static inline int mfma_ks(int ck) { return (9 * ck + 31) / 32; }
 int bx_conv3x3_mfma_supported(int Ci, int Co, int dtype) {
   if (dtype != BX_BF16) return 0;
   if (!(Ci == 8 || Ci == 16 || Ci == 32 || (Ci >= 64 && Ci % 64 == 0))) return 0;
-  return Co >= 16 && Co % 16 == 0;
+  // Co == 8: the data gradient of a stage's first convolution when the network input has <= 8 (padded) channels -- only saliency /
+  // integrated gradients ask for it.  The operand is packed with 16 rows (8 of them zero), the kernels store the 8 real channels.
+  return (Co >= 16 && Co % 16 == 0) || (Co == 8 && Ci >= 16);
 }
+static inline int mfma_ow(int O_p) { return O_p < 16 ? 16 : O_p; }        // weight rows per K-step of the packed operand
 extern "C" size_t bx_conv3x3_packed_mfma_bytes(int I_p, int O_p) {
   if (!bx_conv3x3_mfma_supported(I_p, O_p, BX_BF16)) return 0;
   const int ck = mfma_ck(I_p);
-  return (size_t)(I_p / ck) * mfma_ks(ck) * O_p * 32 * sizeof(bf16_t);
+  return (size_t)(I_p / ck) * mfma_ks(ck) * mfma_ow(O_p) * 32 * sizeof(bf16_t);
 }
 
 // Wp[chunk][s][o][kk]:  q = s*32+kk, tap = q / CK, i = chunk*CK + q % CK
@@ -60,7 +63,7 @@ void bx_conv3x3_mfma_pack_launch(const float* w_oihw, void* packed, int Cout, in
   const size_t n = bytes / sizeof(bf16_t);
   const int ck = mfma_ck(I_p);
   const int grid = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
-  hipLaunchKernelGGL(k_pack_mfma, dim3(grid), dim3(256), 0, s, w_oihw, (bf16_t*)packed, Cout, Cin, I_p, O_p, tf, ck, mfma_ks(ck), n);
+  hipLaunchKernelGGL(k_pack_mfma, dim3(grid), dim3(256), 0, s, w_oihw, (bf16_t*)packed, Cout, Cin, I_p, mfma_ow(O_p), tf, ck, mfma_ks(ck), n);
 }
 
 // Many pack jobs in ONE launch (all 3x3 convolutions of the model, forward and data-gradient operands): the job
@@ -105,7 +108,8 @@ __global__ __launch_bounds__(256) void k_pack_mfma_many(const bxPackJob* __restr
   const int j = sj;
   const bxPackJob jb = jobs[j];
   const int ck = jb.I_p < 64 ? jb.I_p : 64, ks = (9 * ck + 31) / 32;
-  const size_t n = (size_t)(jb.I_p / ck) * ks * jb.O_p * 32;
+  const int Ow = jb.O_p < 16 ? 16 : jb.O_p;               // mfma_ow
+  const size_t n = (size_t)(jb.I_p / ck) * ks * Ow * 32;
   const float* __restrict__ w = (const float*)jb.w_oihw;
   bf16_t* __restrict__ wp = (bf16_t*)jb.packed_mfma;
   const int nblk = (j + 1 < njobs ? jobs[j + 1].block_begin : npack) - jb.block_begin;
@@ -118,8 +122,8 @@ __global__ __launch_bounds__(256) void k_pack_mfma_many(const bxPackJob* __restr
       if (idx < n) {
         const unsigned i32 = (unsigned)idx, row = i32 >> 5;          // n < 2^31: 32-bit divisions (64-bit ones cost ~70 instructions each)
         const int kk = (int)(i32 & 31);
-        const unsigned so = row / (unsigned)jb.O_p;
-        const int o = (int)(row - so * (unsigned)jb.O_p);
+        const unsigned so = row / (unsigned)Ow;
+        const int o = (int)(row - so * (unsigned)Ow);
         const int chunk = (int)(so / (unsigned)ks);
         const int s = (int)(so - (unsigned)chunk * (unsigned)ks);
         const int q = s * 32 + kk, tap = q / ck, i = chunk * ck + q % ck;
@@ -307,6 +311,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
     for (int n = 0; n < NC; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nchunk = Ci / CK;
+  const int Cw = Co < 16 ? 16 : Co;         // rows of the packed operand (Co == 8: rows 8..15 are zero and their results are not stored)
   // staging: every thread issues ALL of its 16-byte global loads before the first LDS write (a rolled
   // load->wait->write loop serialises one HBM round trip per iteration)
   constexpr int NU = IMGS * HH * HWID * NCH, NR = (NU + 255) / 256;
@@ -331,13 +336,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
       rv[k] = make_uint4(v.x, v.y, v.z, v.w);
       hoff[k] += (uint32_t)(CK * 2);                          // next chunk of input channels (an invalid lane stays >= 2^31)
     }
-    const bf16_t* wchunk = wp + (size_t)chunk * KS * Co * 32;
+    const bf16_t* wchunk = wp + (size_t)chunk * KS * Cw * 32;
     // weight fragments run two K-steps ahead of the MFMAs that consume them (L2 latency >> one K-step)
     bf16x8 a[3][NC];
     auto load_a = [&](int s, bf16x8 (&dst)[NC]) {
 #pragma unroll
       for (int n = 0; n < NC; ++n)
-        dst[n] = *reinterpret_cast<const bf16x8*>(wchunk + ((size_t)s * Co + co_base + n * 16 + li) * 32 + 8 * g);
+        dst[n] = *reinterpret_cast<const bf16x8*>(wchunk + ((size_t)s * Cw + co_base + n * 16 + li) * 32 + 8 * g);
     };
     load_a(0, a[0]);
     if (KS > 1) load_a(1, a[1]);
@@ -381,10 +386,11 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src ? mask_src : y), 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend : y), 0, y_bytes, 0x00020000);
+  const bool ch_ok = co_base + 4 * g < Co;        // false only for the zero rows of an 8-channel output
   float4 bz[NC];
 #pragma unroll
   for (int n = 0; n < NC; ++n)
-    bz[n] = bias ? *reinterpret_cast<const float4*>(bias + co_base + n * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bz[n] = bias && ch_ok ? *reinterpret_cast<const float4*>(bias + co_base + n * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
   const uint32_t lane_off = (uint32_t)((((b * H + y0) * W + x0 + li) * Co + co_base + 4 * g) * 2);
   // Epilogue operands (ReLU mask of the data gradient, residual addend): ALL of a thread's loads are issued before the first
   // one is consumed.  Loaded inside the store loop each of the MP*NC iterations was its own memory round trip (the ISA had
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   for (int i = 0; i < MP; ++i) {
     const int t = wave * MP + i, img = t / TPI, tl = t % TPI;
     const int oy = y0 + tl / TPR, ox = x0 + (tl % TPR) * 16 + li;
-    const bool inb = oy < H && ox < W;
+    const bool inb = oy < H && ox < W && ch_ok;
     const uint32_t orow = lane_off + (uint32_t)((((img * H + tl / TPR) * W + (tl % TPR) * 16) * Co) * 2);
 #pragma unroll
     for (int n = 0; n < NC; ++n) offs[i][n] = inb ? orow + (uint32_t)(n * 32) : 0x80000000u;
@@ -755,10 +761,12 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
   const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src ? mask_src : y), 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend : y), 0, y_bytes, 0x00020000);
   const uint32_t lane_rel = (uint32_t)((li * Co + co_base + 4 * g) * 2);
+  const int Cw = Co < 16 ? 16 : Co;               // rows of the packed operand (see k_conv_mfma)
+  const bool ch_ok = co_base + 4 * g < Co;
   float4 bz[NC];
 #pragma unroll
   for (int n = 0; n < NC; ++n)
-    bz[n] = bias ? *reinterpret_cast<const float4*>(bias + co_base + n * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bz[n] = bias && ch_ok ? *reinterpret_cast<const float4*>(bias + co_base + n * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
   if (first_tile < ntiles) fetch(first_tile);
   // pooled form: statistics accumulate over the workgroup's tiles in registers; one reduction-tree row per workgroup at the end
   float st[2][NC][4];
@@ -794,7 +802,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
     auto load_a = [&](int s, bf16x8 (&dst)[NC]) {
 #pragma unroll
       for (int n = 0; n < NC; ++n)
-        dst[n] = *reinterpret_cast<const bf16x8*>(wp + ((size_t)s * Co + co_base + n * 16 + li) * 32 + 8 * g);
+        dst[n] = *reinterpret_cast<const bf16x8*>(wp + ((size_t)s * Cw + co_base + n * 16 + li) * 32 + 8 * g);
     };
     load_a(0, a[0]);
     if (KS > 1) load_a(1, a[1]);
@@ -826,7 +834,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
     for (int i = 0; i < MP; ++i) {
       const int t = wave * MP + i;
       const int oy = y0 + t / TPR, ox = x0 + (t % TPR) * 16 + li;
-      const bool inb = oy < H && ox < W;
+      const bool inb = oy < H && ox < W && ch_ok;
       const uint32_t orow = tile_o + (uint32_t)((((t / TPR) * W + (t % TPR) * 16) * Co) * 2);
 #pragma unroll
       for (int n = 0; n < NC; ++n) offs[i][n] = inb ? orow + (uint32_t)(n * 32) : 0x80000000u;
@@ -1047,7 +1055,7 @@ static int launch_conv(const void* x, const void* wp, const float* bias, const v
     if (lds < need) lds = need;
   }
   if constexpr (CK <= 32) if (Ci == CK) {
-    const int ntiles = tiles_x * tiles_y * B, ygroups = Co / (16 * NC);
+    const int ntiles = tiles_x * tiles_y * B, ygroups = Co < 16 ? 1 : Co / (16 * NC);
     int gx = 2048 / ygroups;                       // ~8 workgroups per CU in total, each walking ntiles/gx tiles
     if (gx > ntiles) gx = ntiles;
     if (ntiles >= 4 * gx && (size_t)B * H * W * CK * 2 < ((size_t)1 << 31)) {       // 32-bit byte offsets in the halo fetch
@@ -1104,7 +1112,7 @@ static int launch_conv(const void* x, const void* wp, const float* bias, const v
       return BX_OK;
     }
   }
-  dim3 grid((unsigned)(tiles_x * tiles_y * B + nred), (unsigned)(Co / (16 * NC)));
+  dim3 grid((unsigned)(tiles_x * tiles_y * B + nred), (unsigned)(Co < 16 ? 1 : Co / (16 * NC)));
   if (pe) {
     if constexpr (CK >= 16) {
       const int rc = pool_tree_shape<NC>(pe, (int)grid.x, (int)grid.y, Co);

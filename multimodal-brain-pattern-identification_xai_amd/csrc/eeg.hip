@@ -28,6 +28,9 @@ int bx_eegc_forward(const float* x, const float* w1, const float* wd, const floa
                     float* bn2_partials, int* bn2_rows, int B, int Ch, int T, hipStream_t s);
 int bx_eegc_corr_launch(const void* g16, const float* x, float* cpart, float* gpart, int B, int Ch, int T, int nsplit, hipStream_t s);
 int bx_eegc_corr_max_T();
+int bx_eegc_forward_eval(const float* x, const float* w1, const float* wd, const float* sc1, const float* sh1, float* u, int B, int Ch, int T,
+                         hipStream_t s);
+int bx_eegc_dx_launch(const float* g, const float* w1, const float* wd, const float* sc1, float* dx, int B, int Ch, int T, hipStream_t s);
 int bx_eegc_grads(const float* cpart, const float* gpart, int nsplit, const float* w1, const float* wd, const float* mean1, const float* inv1,
                   const float* sc1, const float* sh1, const double* RS, float* ep, float* d_wd, float* d_gamma, float* d_beta, float* d_w1,
                   int B, int Ch, int T, hipStream_t s);
@@ -39,6 +42,11 @@ static bool eeg_collapsed(const bxEegDesc* d) {
   return d->collapse && d->training && d->dtype == BX_BF16 && d->K1 == 64 && d->T >= 96 && d->T % 8 == 0 && d->T <= bx_eegc_corr_max_T()
          && d->F2 == d->F1 * d->D && d->P1 == 4;       // (the bf16 gradient map reuses the du3 | dp1 regions: 2 x B*16*(T/4)*4 bytes)
 }
+
+// Evaluation mode (inference, Grad-CAM sweeps, attribution passes) with no parameter gradient wanted: BatchNorm1 is a fixed affine
+// map, so the forward is k_eegc_fwd alone (any storage type: it computes in fp32 and never forms the conv1 tensor) and the input
+// gradient, if asked for, k_eegc_dx.  The caller (ops.py) sets `collapse` only when no parameter needs a gradient.
+static bool eeg_collapsed_eval(const bxEegDesc* d) { return d->collapse && !d->training && d->K1 == 64; }
 
 struct EegGeom {
   int B, Ch, T, F1, D, FD, F2, K1, K2, P1, P2, T1, T2, padl1, padl2;
@@ -401,7 +409,10 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
                        p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, g.F2, st.sc3, st.sh3, st.mean3, st.inv3, d->eps);
     BX_CHECK_LAUNCH("eeg eval stats");
   }
-  if (eeg_collapsed(d)) {
+  if (eeg_collapsed_eval(d)) {
+    const int rc = bx_eegc_forward_eval(x, p->conv1_w, p->dw_w, st.sc1, st.sh1, dmap, g.B, g.Ch, g.T, s);
+    BX_REQUIRE(rc == 0, "bx_eeg_features_fwd: collapsed evaluation-mode front end failed (code %d)", rc);
+  } else if (eeg_collapsed(d)) {
     // conv1 -> BatchNorm1 -> electrode mix without the [B,8,Chans,T] tensor (eeg_collapse.hip): statistics, finalize, forward
     int rows2 = 0;
     const int rc = bx_eegc_forward(x, p->conv1_w, p->dw_w, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, p->bn1_nbt, d->momentum, d->eps, st.mean1, st.inv1,
@@ -1038,6 +1049,22 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
     rc = bx_eegc_grads(cpart, gpart, nsplit, p->conv1_w, p->dw_w, st.mean1, st.inv1, st.sc1, st.sh1, (const double*)c1, ep, gr->dw_w, gr->bn1_w, gr->bn1_b,
                        gr->conv1_w, g.B, g.Ch, g.T, s);
     BX_REQUIRE(rc == 0, "bx_eeg_features_bwd: collapsed gradient launch failed (code %d)", rc);
+    return BX_OK;
+  }
+  const bool front_params = gr->conv1_w || gr->dw_w || gr->bn1_w || gr->bn1_b;
+  if (eeg_collapsed_eval(d)) {
+    BX_REQUIRE(!front_params, "bx_eeg_features_bwd: the forward pass ran the collapsed evaluation-mode front end (bxEegDesc.collapse), which keeps no "
+                              "conv1 output; clear the flag when conv1 / batchnorm1 / depthwise gradients are wanted");
+    if (dx) {
+      const int rc = bx_eegc_dx_launch(du2, p->conv1_w, p->dw_w, st.sc1, dx, g.B, g.Ch, g.T, s);
+      BX_REQUIRE(rc == 0, "bx_eeg_features_bwd: collapsed input-gradient launch failed (code %d)", rc);
+    }
+    return BX_OK;
+  }
+  if (dx && !tr && !front_params && g.K1 == 64 && !getenv("BX_EEG_DX_LAYERED")) {
+    // attribution pass (evaluation mode, only the input gradient wanted): the front end's adjoint in collapsed form, eeg_collapse.hip
+    const int rc = bx_eegc_dx_launch(du2, p->conv1_w, p->dw_w, st.sc1, dx, g.B, g.Ch, g.T, s);
+    BX_REQUIRE(rc == 0, "bx_eeg_features_bwd: collapsed input-gradient launch failed (code %d)", rc);
     return BX_OK;
   }
   // depthwise + BN1

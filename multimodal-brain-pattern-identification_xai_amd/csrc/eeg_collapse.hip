@@ -498,6 +498,91 @@ __global__ __launch_bounds__(512) void k_eegc_grads_final(const float* __restric
   }
 }
 
+// ---- input gradient in evaluation mode (attribution passes: saliency, integrated gradients, SHAP-style estimators) -------------
+// With BatchNorm1 on its running statistics, conv1 -> BatchNorm1 -> depthwise is the fixed linear map of the header comment, and its
+// adjoint is    dx[b,ch,t] = sum_fd wd[fd,ch] e[b,fd,t],      e[b,fd,t] = a_f sum_k w1[f,k] g[b,fd,t-k+31]       (g = dL/du, a_f = sc1[f])
+// -- a 64-tap filter over 16 rows per sample and a 16 -> Chans mix, where the layer-by-layer kernel (k_eeg_conv1_bwd) rebuilds
+// dL/dconv1 [8][T] per (sample, electrode) row and runs 8 x 64 taps on each: Chans / 2 times the arithmetic and the conv1 tensor re-read.
+// grid (ceil(T / 256), B); phases as k_eegc_fwd run backwards: stage g with its halo, filter (wave = four rows, lane = four
+// consecutive time steps, taps and window in registers), mix (thread = time step, all electrodes).
+__global__ __launch_bounds__(256) void k_eegc_dx(const float* __restrict__ g, const float* __restrict__ w1, const float* __restrict__ wd,
+    const float* __restrict__ sc1, float* __restrict__ dx, int Ch, int T) {
+  __shared__ __attribute__((aligned(16))) float sg[16 * EC_VP];          // column i <-> time t0 - 32 + i
+  __shared__ __attribute__((aligned(16))) float se[16 * EC_TC];
+  __shared__ __attribute__((aligned(16))) float swt[EEG_MAXCH_C * 16];   // [ch][fd]
+  __shared__ __attribute__((aligned(16))) float sw1[8 * EC_K];           // taps reversed: the adjoint of a correlation is a convolution
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.y, t0 = blockIdx.x * EC_TC;
+  for (int i = tid; i < 16 * Ch; i += 256) { const int fd = i / Ch, ch = i - fd * Ch; swt[ch * 16 + fd] = wd[i]; }
+  for (int i = tid; i < 8 * EC_K; i += 256) sw1[i] = w1[(i & ~(EC_K - 1)) + (EC_K - 1 - (i & (EC_K - 1)))];
+  {
+    constexpr int NQ = 16 * EC_VP / 256;                // 20 loads per thread, all in flight before the first LDS write
+    const float* gb = g + (size_t)b * 16 * T;
+    float gv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int i = tid + 256 * q, fd = i / EC_VP, col = i - fd * EC_VP;
+      const int t = t0 - (EC_K - 1 - EC_PADL) + col;
+      const bool ok = t >= 0 && t < T;
+      gv[q] = gb[(size_t)fd * T + (ok ? t : 0)];
+      if (!ok) gv[q] = 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) sg[tid + 256 * q] = gv[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int f = 2 * wave + half;
+    float w[64];
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+      const float4 v = *reinterpret_cast<const float4*>(sw1 + f * EC_K + 4 * k4);
+      w[4 * k4] = v.x; w[4 * k4 + 1] = v.y; w[4 * k4 + 2] = v.z; w[4 * k4 + 3] = v.w;
+    }
+    const float a = sc1[f];
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) {
+      const int fd = 2 * f + dd;
+      float win[68];
+#pragma unroll
+      for (int q = 0; q < 17; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(sg + fd * EC_VP + 4 * lane + 4 * q);
+        win[4 * q] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
+      }
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 64; ++k) {
+        o[0] = fmaf(w[k], win[k], o[0]); o[1] = fmaf(w[k], win[k + 1], o[1]);
+        o[2] = fmaf(w[k], win[k + 2], o[2]); o[3] = fmaf(w[k], win[k + 3], o[3]);
+      }
+      *reinterpret_cast<float4*>(se + fd * EC_TC + 4 * lane) = make_float4(a * o[0], a * o[1], a * o[2], a * o[3]);
+    }
+  }
+  __syncthreads();
+  float ev[16];
+#pragma unroll
+  for (int fd = 0; fd < 16; ++fd) ev[fd] = se[fd * EC_TC + tid];
+  const int t = t0 + tid;
+  if (t >= T) return;
+  float* dst = dx + (size_t)b * Ch * T + t;
+  for (int ch = 0; ch < Ch; ++ch) {
+    float acc = 0.f;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float4 v = *reinterpret_cast<const float4*>(swt + ch * 16 + 4 * q4);
+      acc = fmaf(v.x, ev[4 * q4], acc); acc = fmaf(v.y, ev[4 * q4 + 1], acc); acc = fmaf(v.z, ev[4 * q4 + 2], acc); acc = fmaf(v.w, ev[4 * q4 + 3], acc);
+    }
+    dst[(size_t)ch * T] = acc;
+  }
+}
+int bx_eegc_dx_launch(const float* g, const float* w1, const float* wd, const float* sc1, float* dx, int B, int Ch, int T, hipStream_t s) {
+  if (Ch > EEG_MAXCH_C) return -2;
+  dim3 grid((unsigned)((T + EC_TC - 1) / EC_TC), (unsigned)B);
+  hipLaunchKernelGGL(k_eegc_dx, grid, dim3(256), 0, s, g, w1, wd, sc1, dx, Ch, T);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ---- launchers (called from eeg.hip) ---------------------------------------------------------------------------------------
 size_t bx_eegc_stat_floats() { return (size_t)EC_NR * EC_RCOLS + (size_t)EC_NE * EC_ECOLS; }
 int bx_eegc_forward(const float* x, const float* w1, const float* wd, const float* gamma, const float* beta, float* rmean, float* rvar, int64_t* nbt,
@@ -527,6 +612,13 @@ int bx_eegc_forward(const float* x, const float* w1, const float* wd, const floa
   hipLaunchKernelGGL(k_eegc_fwd, grid, dim3(256), 0, s, x, w1, wd, sc1, sh1, u, bn2_partials, Ch, T, 1);
   *bn2_rows = (int)(grid.x * grid.y);
   return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int bx_eegc_forward_eval(const float* x, const float* w1, const float* wd, const float* sc1, const float* sh1, float* u, int B, int Ch, int T,
+                         hipStream_t s) {
+  if (Ch > EEG_MAXCH_C) return -2;
+  dim3 grid((unsigned)((T + EC_TC - 1) / EC_TC), (unsigned)B);
+  hipLaunchKernelGGL(k_eegc_fwd, grid, dim3(256), 0, s, x, w1, wd, sc1, sh1, u, (float*)nullptr, Ch, T, 0);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int bx_eegc_grads(const float* cpart, const float* gpart, int nsplit, const float* w1, const float* wd, const float* mean1, const float* inv1,
                   const float* sc1, const float* sh1, const double* RS, float* ep, float* d_wd, float* d_gamma, float* d_beta, float* d_w1,

@@ -188,7 +188,8 @@ class EEGNet(nn.Module):
         bn1, bn2, bn3 = self.batchnorm1, self.batchnorm2, self.batchnorm3
         cfg = SimpleNamespace(F1=g.F1, D=g.D, F2=g.F2, K1=g.K1, K2=g.K2, P1=g.P1, P2=g.P2, training=self.training,
                               eps=bn1.eps, momentum=0.1 if bn1.momentum is None else bn1.momentum,
-                              dropout_p=self.dropout.p if self.training else 0.0, salt=self.salt, dtype=self.compute_dtype, seed=seed)
+                              dropout_p=self.dropout.p if self.training else 0.0, salt=self.salt, dtype=self.compute_dtype, seed=seed,
+                              grad_mode=torch.is_grad_enabled())      # (inside an autograd Function's forward grad mode always reads False)
         bufs = (bn1.running_mean, bn1.running_var, bn1.num_batches_tracked, bn2.running_mean, bn2.running_var,
                 bn2.num_batches_tracked, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked)
         return ops.EegFeaturesFn.apply(x, self.conv1.weight, bn1.weight, bn1.bias, self.depthwiseConv.weight, bn2.weight, bn2.bias,
@@ -267,7 +268,8 @@ class EEGNetAttentionDeep(nn.Module):
         bn1, bn2, bn3 = self.batchnorm1, self.batchnorm2, self.batchnorm3
         cfg = SimpleNamespace(F1=g.F1, D=g.D, F2=g.F2, K1=g.K1, K2=g.K2, P1=g.P1, P2=g.P2, training=self.training,
                               eps=bn1.eps, momentum=0.1 if bn1.momentum is None else bn1.momentum,
-                              dropout_p=self.dropout1.p if self.training else 0.0, salt=self.salt, dtype=self.compute_dtype)
+                              dropout_p=self.dropout1.p if self.training else 0.0, salt=self.salt, dtype=self.compute_dtype,
+                              grad_mode=torch.is_grad_enabled())
         bufs = (bn1.running_mean, bn1.running_var, bn1.num_batches_tracked, bn2.running_mean, bn2.running_var,
                 bn2.num_batches_tracked, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked)
         return ops.EegFeaturesFn.apply(x, self.conv1.weight, bn1.weight, bn1.bias, self.depthwiseConv.weight, bn2.weight, bn2.bias,

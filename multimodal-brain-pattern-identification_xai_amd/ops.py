@@ -718,8 +718,12 @@ class EegFeaturesFn(torch.autograd.Function):
         _require_gpu(x, "eeg input")
         B, _, Ch, T = x.shape
         x = x.contiguous().float()
-        # collapsed front end (no conv1 output tensor): only when nobody can ask for the input's gradient
-        collapse = 1 if (EEG_COLLAPSE and cfg.training and not ctx.needs_input_grad[0]) else 0
+        # collapsed front end (no conv1 output tensor).  Training: only when nobody can ask for the input's gradient.  Evaluation
+        # mode (BatchNorm1 a fixed affine map): whenever no PARAMETER needs a gradient -- inference, Grad-CAM sweeps, saliency /
+        # integrated-gradients passes (the input gradient has a collapsed form too)
+        params_need_grad = getattr(cfg, "grad_mode", True) and any(ctx.needs_input_grad[1:10])      # under no_grad nobody does
+        collapse = 1 if EEG_COLLAPSE and ((cfg.training and not ctx.needs_input_grad[0]) or
+                                          (not cfg.training and not params_need_grad)) else 0
         desc = L.EegDesc(B, Ch, T, cfg.F1, cfg.D, cfg.F2, cfg.K1, cfg.K2, cfg.P1, cfg.P2, 1 if cfg.training else 0, cfg.eps, cfg.momentum,
                          float(cfg.dropout_p), cfg.salt, bx_dtype(cfg.dtype), collapse)
         nsaved = lib.bx_eeg_saved_bytes(C.byref(desc))

@@ -98,6 +98,34 @@ def test_conv_mfma_data_gradient_epilogue(cin, cout, h, w):
     assert rel_err(outs["mfma"], outs["direct"]) < 8e-3
 
 
+@pytest.mark.parametrize("co_layer,batch,h,w", [(16, 2, 12, 20), (32, 3, 9, 33), (16, 64, 128, 256)])
+def test_conv_mfma_data_gradient_to_8_padded_channels(co_layer, batch, h, w):
+    """the data gradient of a stage-1 conv1 (4 input planes padded to 8; only saliency / integrated gradients ask for it): the MFMA
+    operand has 16 rows, 8 of them zero, and the kernels store the 8 real channels -- one-shot kernel at the small sizes, persistent
+    kernel at the benchmark's batch; must equal the direct kernel and the fp32 reference, and the 4 padding channels must be 0 + addend"""
+    torch.manual_seed(11 + co_layer + h)
+    ci_layer = 4
+    wt = _bf(torch.randn(co_layer, ci_layer, 3, 3) / (3 * ci_layer ** 0.5))
+    dz = _bf(torch.randn(batch, co_layer, h, w))
+    add = _bf(torch.randn(batch, ci_layer, h, w))
+    want = F.conv_transpose2d(dz, wt, padding=1) + add
+    packed = ops._pack(wt.to(DEV), True)
+    assert packed[1] is not None and packed[3] == 8, "MFMA operand must exist for an 8-channel data gradient"
+    dzn, an = (ops.to_nhwc(t.to(DEV), torch.bfloat16) for t in (dz, add))
+    assert an.shape[3] == 8
+    lib = L.load()
+    outs = {}
+    for name, algo in (("direct", L.BX_ALGO_DIRECT), ("mfma", L.BX_ALGO_MFMA)):
+        y = torch.full((batch, h, w, 8), 7.0, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.bx_conv3x3(dzn.data_ptr(), packed[0].data_ptr(), packed[1].data_ptr(), None, None, an.data_ptr(), y.data_ptr(),
+                               batch, h, w, co_layer, 8, L.BX_BF16, 0, algo, torch.cuda.current_stream().cuda_stream), name)
+        torch.cuda.synchronize()
+        assert float(y[..., 4:].float().abs().max()) == 0.0, name       # padding channels: zero weights + zero addend
+        outs[name] = ops.to_nchw_f32(y, ci_layer).cpu()
+    assert rel_err(outs["mfma"], want) < 8e-3
+    assert rel_err(outs["mfma"], outs["direct"]) < 8e-3
+
+
 def test_block_bf16_mfma_matches_direct_path():
     """whole Block forward+backward in bf16: MFMA kernels vs direct kernels (same storage rounding points)"""
     torch.manual_seed(11)

@@ -191,6 +191,53 @@ def test_eegnet_fwd_bwd(tag, chans, samples):
         check(fix, f"after.{k}.running_var", getattr(mine, k).running_var.cpu(), tol=TOL)
 
 
+@pytest.mark.parametrize("chans,samples,b", [(19, 2000, 3), (37, 3000, 2), (19, 2100, 2), (5, 300, 1)])
+def test_eeg_input_gradient_of_an_attribution_pass(chans, samples, b):
+    """Evaluation mode, frozen parameters, only dL/dx wanted (saliency / integrated gradients / SHAP-style estimators): the EEG front
+    end's adjoint runs in collapsed form (k_eegc_dx: 64-tap filter over the 16 mixed rows, then the 16 -> Chans mix).  Against
+    autograd through the oracle, and against the layer-by-layer kernels (BX_EEG_DX_LAYERED=1) it replaces."""
+    import os
+    ref, mine = _pair(lambda: O.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0),
+                      lambda: brainxai.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0), 33)
+    for m in (ref.batchnorm1, ref.batchnorm2, ref.batchnorm3):          # non-trivial running statistics
+        m.running_mean.copy_(O.seeded(tuple(m.running_mean.shape), 5, "randn") * 0.1)
+        m.running_var.copy_(O.seeded(tuple(m.running_var.shape), 6, "rand") + 0.5)
+    mine.load_state_dict(ref.state_dict())
+    ref.eval(); mine.eval()
+    for q in list(ref.parameters()) + list(mine.parameters()):
+        q.requires_grad_(False)
+    x = O.seeded((b, 1, chans, samples), 34, "randn")
+    r = O.seeded((b, 6), 35, "randn")
+    xr = x.clone().double().requires_grad_(True)
+    (ref.double()(xr) * r.double()).sum().backward()
+    got = {}
+    collapse_was = ops.EEG_COLLAPSE
+    for storage in (torch.float32, torch.bfloat16):
+        mine.compute_dtype = storage
+        for route in ("collapsed", "collapsed-dx", "layered"):
+            # collapsed: forward AND input gradient in collapsed form (what an attribution pass runs); collapsed-dx: layer-by-layer
+            # forward, collapsed input gradient; layered: round 1's kernels for both
+            ops.EEG_COLLAPSE = route == "collapsed"
+            if route == "layered":
+                os.environ["BX_EEG_DX_LAYERED"] = "1"
+            try:
+                xm = x.clone().to(DEV).requires_grad_(True)
+                (mine(xm) * r.to(DEV)).sum().backward()
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("BX_EEG_DX_LAYERED", None)
+                ops.EEG_COLLAPSE = collapse_was
+            got[(storage, route)] = xm.grad.cpu()
+    scale = float(xr.grad.abs().max())
+    err = lambda k: float((got[k].double() - xr.grad).abs().max()) / scale
+    for route in ("collapsed", "collapsed-dx", "layered"):
+        assert err((torch.float32, route)) < 2e-5, (route, err((torch.float32, route)))
+    # bf16 storage only rounds the conv1 output tensor, which the collapsed forward never forms: that route stays at fp32 accuracy
+    assert err((torch.bfloat16, "collapsed")) < 2e-5
+    assert float((got[(torch.bfloat16, "collapsed-dx")] - got[(torch.bfloat16, "layered")]).abs().max()) / scale < 2e-5
+    assert err((torch.bfloat16, "layered")) < 2e-2
+
+
 @pytest.mark.parametrize("tag,chans,samples,b", [("eegdeep19x2000", 19, 2000, 3), ("eegdeep37x3000", 37, 3000, 2)])
 def test_eegnet_attention_deep_fwd_bwd(tag, chans, samples, b):
     """Row C' (models.py:109-235): third block + attention + two dense layers, against the oracle and the reference's fixtures."""

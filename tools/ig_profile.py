@@ -16,6 +16,7 @@ def main():
     import torch
     import brainxai
     dev = torch.device("cuda", 0)
+    torch.manual_seed(42)
     B = int(os.environ.get("IG_B", "64"))
     g = torch.Generator().manual_seed(42)
     spec = torch.rand(B, 4, 128, 256, generator=g).to(dev)
