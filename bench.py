@@ -358,7 +358,7 @@ def main():
             gradcam["ig50_samples_per_sec"] = round(B / ig_dt, 2)
             gradcam["integrated_gradients"] = {"samples_per_sec": round(B / ig_dt, 2), "ms": round(ig_dt * 1e3, 2),
                                                "workload": "configs[4]: 50 steps x B=64 (3200 forward + input-gradient passes), samples sharded "
-                                                           "over %d rank(s), interpolants batched %d per pass" % (world, 256)}
+                                                           "over %d rank(s), interpolants batched %d per pass" % (world, 1024)}
         model.train()
 
     # ---- measured device-to-device copy rate (quote the box's own streaming rate next to the 8 TB/s spec)

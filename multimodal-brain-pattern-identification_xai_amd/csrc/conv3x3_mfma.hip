@@ -30,7 +30,7 @@ int bx_conv3x3_mfma_supported(int Ci, int Co, int dtype) {
   if (!(Ci == 8 || Ci == 16 || Ci == 32 || (Ci >= 64 && Ci % 64 == 0))) return 0;
   // Co == 8: the data gradient of a stage's first convolution when the network input has <= 8 (padded) channels -- only saliency /
   // integrated gradients ask for it.  The operand is packed with 16 rows (8 of them zero), the kernels store the 8 real channels.
-  return (Co >= 16 && Co % 16 == 0) || (Co == 8 && Ci >= 16);
+  return (Co >= 16 && Co % 16 == 0) || (Co == 8 && (Ci == 16 || Ci == 32));
 }
 static inline int mfma_ow(int O_p) { return O_p < 16 ? 16 : O_p; }        // weight rows per K-step of the packed operand
 extern "C" size_t bx_conv3x3_packed_mfma_bytes(int I_p, int O_p) {
@@ -284,7 +284,9 @@ __device__ __forceinline__ void conv_pool_transpose_w1x1(const BxConvPoolEpi& pe
 // IMGS (round 2): a workgroup's pixel tile may span the SAME 8 x TW window of IMGS consecutive images (their halo tiles sit one
 // after the other in LDS).  The weight fragments a wave fetches per K-step then feed IMGS times as many MFMAs: the late stages
 // (8x16 and 16x32 maps, 64-channel chunks) ran 4-8 MFMAs per K-step per wave and spent 470-830 cycles on each (in-kernel stamps).
-template <int CK, int NC, int TW, int IMGS = 1, bool POOL = false>
+// C8 (round 2): the output tensor has 8 channels while the packed operand has 16 rows (see bx_conv3x3_mfma_supported); a template
+// flag, so that the ordinary instantiations keep their register allocation (as a run-time test it cost <32,2,32> one wave of occupancy)
+template <int CK, int NC, int TW, int IMGS = 1, bool POOL = false, bool C8 = false>
 __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const bf16_t* __restrict__ mask_src, const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
     int H, int W, int Ci, int Co, int relu, int tiles_x, int tiles_y, uint32_t x_bytes, BxConvPoolEpi pe, WgradRedJob red, int nred) {
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
     for (int n = 0; n < NC; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nchunk = Ci / CK;
-  const int Cw = Co < 16 ? 16 : Co;         // rows of the packed operand (Co == 8: rows 8..15 are zero and their results are not stored)
+  const int Cw = C8 ? 16 : Co;              // rows of the packed operand (C8: rows 8..15 are zero and their results are not stored)
   // staging: every thread issues ALL of its 16-byte global loads before the first LDS write (a rolled
   // load->wait->write loop serialises one HBM round trip per iteration)
   constexpr int NU = IMGS * HH * HWID * NCH, NR = (NU + 255) / 256;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src ? mask_src : y), 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend : y), 0, y_bytes, 0x00020000);
-  const bool ch_ok = co_base + 4 * g < Co;        // false only for the zero rows of an 8-channel output
+  const bool ch_ok = C8 ? g < 2 : true;           // false only for the zero rows of an 8-channel output
   float4 bz[NC];
 #pragma unroll
   for (int n = 0; n < NC; ++n)
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_c(const bf16_t* __restrict__ 
 // blockIdx.x, blockIdx.x + gridDim.x, ...; the NEXT tile's halo is fetched into registers before the current tile's
 // MFMAs and epilogue, so every CU always has input loads in flight (the one-shot kernel exposes one HBM round trip per
 // workgroup and relies on occupancy alone to hide it).
-template <int CK, int NC, int TW, bool POOL = false>
+template <int CK, int NC, int TW, bool POOL = false, bool C8 = false>
 __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const bf16_t* __restrict__ mask_src, const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
     int H, int W, int Co, int relu, int tiles_x, int tiles_y, int ntiles, uint32_t x_bytes, BxConvPoolEpi pe, WgradRedJob red, int nred) {
@@ -761,8 +763,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const bf16_t* __restrict__ 
   const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src ? mask_src : y), 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend : y), 0, y_bytes, 0x00020000);
   const uint32_t lane_rel = (uint32_t)((li * Co + co_base + 4 * g) * 2);
-  const int Cw = Co < 16 ? 16 : Co;               // rows of the packed operand (see k_conv_mfma)
-  const bool ch_ok = co_base + 4 * g < Co;
+  const int Cw = C8 ? 16 : Co;                    // rows of the packed operand (see k_conv_mfma)
+  const bool ch_ok = C8 ? g < 2 : true;
   float4 bz[NC];
 #pragma unroll
   for (int n = 0; n < NC; ++n)
@@ -1054,8 +1056,28 @@ static int launch_conv(const void* x, const void* wp, const float* bias, const v
     const size_t need = BX_STAT_TREE_LDS(2) + (size_t)4 * 2 * NC * 16 * sizeof(float);       // conv_pool_finish reuses the halo tile's LDS
     if (lds < need) lds = need;
   }
+  if (Co < 16) {                                   // 8-channel output (bx_conv3x3_mfma_supported: Ci 16 or 32, so NC == 1 and one chunk)
+    if constexpr (NC == 1 && (CK == 16 || CK == 32)) {
+      BX_REQUIRE(Co == 8 && Ci == CK && !pe && !bias, "bx_conv3x3(mfma): the 8-channel output form is a plain data gradient (Ci=%d Co=%d)", Ci, Co);
+      const int ntiles = tiles_x * tiles_y * B;
+      const int gx = ntiles < 2048 ? ntiles : 2048;
+      if (ntiles >= 4 * gx && (size_t)B * H * W * CK * 2 < ((size_t)1 << 31)) {
+        hipLaunchKernelGGL((k_conv_mfma_p<CK, 1, TW, false, true>), dim3((unsigned)(gx + nred), 1u), dim3(256), lds, s, (const bf16_t*)x,
+                           (const bf16_t*)wp, bias, (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Co, relu, tiles_x, tiles_y, ntiles,
+                           (uint32_t)((size_t)B * H * W * CK * 2), none, rj, nred);
+        BX_CHECK_LAUNCH("bx_conv3x3(mfma persistent, 8 output channels)");
+        return BX_OK;
+      }
+      hipLaunchKernelGGL((k_conv_mfma<CK, 1, TW, 1, false, true>), dim3((unsigned)(ntiles + nred), 1u), dim3(256), lds, s, (const bf16_t*)x,
+                         (const bf16_t*)wp, bias, (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y,
+                         (uint32_t)((size_t)B * H * W * Ci * 2), none, rj, nred);
+      BX_CHECK_LAUNCH("bx_conv3x3(mfma, 8 output channels)");
+      return BX_OK;
+    }
+    BX_FAIL(BX_EUNSUPPORTED, "bx_conv3x3(mfma): %d output channels with Ci=%d", Co, Ci);
+  }
   if constexpr (CK <= 32) if (Ci == CK) {
-    const int ntiles = tiles_x * tiles_y * B, ygroups = Co < 16 ? 1 : Co / (16 * NC);
+    const int ntiles = tiles_x * tiles_y * B, ygroups = Co / (16 * NC);
     int gx = 2048 / ygroups;                       // ~8 workgroups per CU in total, each walking ntiles/gx tiles
     if (gx > ntiles) gx = ntiles;
     if (ntiles >= 4 * gx && (size_t)B * H * W * CK * 2 < ((size_t)1 << 31)) {       // 32-bit byte offsets in the halo fetch
@@ -1112,7 +1134,7 @@ static int launch_conv(const void* x, const void* wp, const float* bias, const v
       return BX_OK;
     }
   }
-  dim3 grid((unsigned)(tiles_x * tiles_y * B + nred), (unsigned)(Co < 16 ? 1 : Co / (16 * NC)));
+  dim3 grid((unsigned)(tiles_x * tiles_y * B + nred), (unsigned)(Co / (16 * NC)));
   if (pe) {
     if constexpr (CK >= 16) {
       const int rc = pool_tree_shape<NC>(pe, (int)grid.x, (int)grid.y, Co);
