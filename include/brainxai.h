@@ -319,6 +319,13 @@ int bx_gradcam_reduce(const void* A, const void* G, float* cam, float* weights_o
 int bx_gradcam_head(const void* A, const float* eeg_logp, const float* fc_w, const float* fc_b, const float* w1, const float* b1,
                     const float* w2, const float* b2, float* out_logp, float* cam, float* raw, float* weights_out, int B, int HW,
                     int C, int N, int Hd, int class_mode, int relu, int dtype, bxStream stream);
+/* The same for sweeps over many batches: the EEG branch's own head (EEGNet.dense + LogSoftmax, models.py:287-289: eeg_feat fp32
+ * [B,Fe], dense_w [N,Fe], dense_b [N]) and the bilinear up-sampling of the finished maps to H x W (W % 4 == 0) run in the same
+ * launch; A is [B,h*w,C].  maps fp32 [B*nm,H,W]. */
+int bx_gradcam_head_sweep(const void* A, const float* eeg_feat, const float* dense_w, const float* dense_b, int Fe, const float* fc_w,
+                          const float* fc_b, const float* w1, const float* b1, const float* w2, const float* b2, float* out_logp,
+                          float* maps, int B, int h, int w, int C, int N, int Hd, int H, int W, int class_mode, int relu, int dtype,
+                          bxStream stream);
 /* Bilinear resize (align_corners=False) of fp32 maps [N,h,w] -> [N,H,W]  (F.interpolate). */
 int bx_resize_bilinear(const float* src, float* dst, int N, int h, int w, int H, int W, bxStream stream);
 /* Saliency reduce (NB:3121-3129): out[b,p] = scale * max_c |g[b,p,c]|, g NHWC `dtype` (first C of Cs). */

@@ -113,6 +113,7 @@ SIGNATURES = {
     "bx_attention_bwd": (i32, [vp] * 16 + [sz, i32, i32, i32, vp]),
     "bx_gradcam_reduce": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "bx_gradcam_head": (i32, [vp] * 12 + [i32] * 8 + [vp]),
+    "bx_gradcam_head_sweep": (i32, [vp] * 4 + [i32] + [vp] * 8 + [i32] * 11 + [vp]),
     "bx_resize_bilinear": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "bx_saliency_reduce": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "bx_axpby": (i32, [vp, vp, sz, f32, f32, vp]),

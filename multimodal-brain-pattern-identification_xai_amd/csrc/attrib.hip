@@ -71,12 +71,15 @@ extern "C" int bx_gradcam_reduce(const void* A, const void* G, float* cam, float
 // runs the two heads forward, their backward for every requested class (class_mode -2: all N classes, -1: the sample's arg-max
 // class, >= 0: that class), and the channel reduce cam[p] = sum_k w[k] A[p][k] -- what used to be 4 library launches plus 7
 // framework launches (argmax, scatter, four repeat_interleave, ...) and a materialised gradient tensor [B*N, HW, C].
+// Sweep form (bx_gradcam_head_sweep; GcExtra.ef / .up non-null): the EEG branch's dense layer + LogSoftmax (a launch of its own per
+// batch otherwise) and the bilinear up-sampling of the finished map (a second launch and a round trip of the small maps) run here too.
+struct GcExtra { const float* ef; const float* dw; const float* db; int Fe; float* up; int h, w, H, W; };
 template <typename T>
 __global__ __launch_bounds__(256) void k_gradcam_head(const T* __restrict__ A, const float* __restrict__ e_lp, const float* __restrict__ fcw,
                                                        const float* __restrict__ fcb, const float* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ out_lp,
                                                        float* __restrict__ cam, float* __restrict__ raw, float* __restrict__ wout,
-                                                       int HW, int C, int N, int Hd, int class_mode, int relu) {
+                                                       int HW, int C, int N, int Hd, int class_mode, int relu, GcExtra ex) {
   extern __shared__ float sm[];
   float* gap = sm;                 // [C]
   float* w = gap + C;              // [C]
@@ -87,6 +90,7 @@ __global__ __launch_bounds__(256) void k_gradcam_head(const T* __restrict__ A, c
   float* dz = lp + N;              // [N]
   float* ds = dz + N;              // [N]
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float* scam = ds + N + (size_t)(256 / (C / 8)) * C;       // [HW] the finished map, for the in-kernel up-sampling (sweep form only)
   const T* a = A + (size_t)b * HW * C;
   const float inv_hw = 1.f / (float)HW;
   // ---- forward: GAP.  C/8 channel groups x (256 / (C/8)) position slots run in parallel (16-byte loads, coalesced along C),
@@ -114,7 +118,30 @@ __global__ __launch_bounds__(256) void k_gradcam_head(const T* __restrict__ A, c
       gap[k] = t * inv_hw;
     }
   }
-  if (tid < N) cat[tid] = e_lp[(size_t)b * N + tid];
+  if (ex.ef) {                                             // EEG head: dense over the branch's features, then LogSoftmax
+    const float* f = ex.ef + (size_t)b * ex.Fe;
+    for (int n = wave; n < N; n += 4) {
+      float acc = 0.f;
+      for (int k0 = lane; k0 < ex.Fe; k0 += 256) {
+        float wv[4], fv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int k = k0 + 64 * u < ex.Fe ? k0 + 64 * u : 0; wv[u] = ex.dw[(size_t)n * ex.Fe + k]; fv[u] = f[k]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = k0 + 64 * u < ex.Fe ? fmaf(wv[u], fv[u], acc) : acc;
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) dz[n] = acc + ex.db[n];              // logits parked in dz
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float mx = -INFINITY;
+      for (int n = 0; n < N; ++n) mx = fmaxf(mx, dz[n]);
+      float se = 0.f;
+      for (int n = 0; n < N; ++n) se += expf(dz[n] - mx);
+      const float lse = mx + logf(se);
+      for (int n = 0; n < N; ++n) cat[n] = dz[n] - lse;
+    }
+  } else if (tid < N) cat[tid] = e_lp[(size_t)b * N + tid];
   __syncthreads();
   // ---- fc + LogSoftmax (spectrogram branch head)
   for (int n = wave; n < N; n += 4) {
@@ -252,8 +279,10 @@ __global__ __launch_bounds__(256) void k_gradcam_head(const T* __restrict__ A, c
           for (int u = 0; u < 8; ++u) {
             const int p = (g0 + 4 * u) * ppw + sub;
             if (g0 + 4 * u < ngrp && p < HW) {
-              cam[mbase + p] = relu ? fmaxf(acc[u], 0.f) : acc[u];
+              const float cv = relu ? fmaxf(acc[u], 0.f) : acc[u];
+              if (cam) cam[mbase + p] = cv;
               if (raw) raw[mbase + p] = acc[u];
+              if (ex.up) scam[p] = cv;
             }
           }
         }
@@ -269,12 +298,51 @@ __global__ __launch_bounds__(256) void k_gradcam_head(const T* __restrict__ A, c
         }
         acc = wave_sum(acc);
         if (lane == 0) {
-          cam[mbase + p] = relu ? fmaxf(acc, 0.f) : acc;
+          const float cv = relu ? fmaxf(acc, 0.f) : acc;
+          if (cam) cam[mbase + p] = cv;
           if (raw) raw[mbase + p] = acc;
+          if (ex.up) scam[p] = cv;
         }
       }
     }
     __syncthreads();
+    if (ex.up) {                                         // F.interpolate(bilinear, align_corners=False) of this map: four columns per thread
+      const int W4 = ex.W / 4;
+      const float sy = (float)ex.h / (float)ex.H, sx = (float)ex.w / (float)ex.W;
+      float4* dst = reinterpret_cast<float4*>(ex.up + ((size_t)b * nm + ci) * ex.H * ex.W);
+      if (256 % W4 == 0) {                               // a thread keeps its four columns: the column interpolation is loop-invariant
+        const int X4 = tid % W4, rows_per_trip = 256 / W4;
+        int x0[4], x1[4]; float lx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bilinear_src(X4 * 4 + j, sx, ex.w, x0[j], x1[j], lx[j]);
+        for (int Y = tid / W4; Y < ex.H; Y += rows_per_trip) {
+          int y0, y1; float ly;
+          bilinear_src(Y, sy, ex.h, y0, y1, ly);
+          const float* r0 = scam + y0 * ex.w;
+          const float* r1 = scam + y1 * ex.w;
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            o[j] = (1.f - ly) * ((1.f - lx[j]) * r0[x0[j]] + lx[j] * r0[x1[j]]) + ly * ((1.f - lx[j]) * r1[x0[j]] + lx[j] * r1[x1[j]]);
+          dst[Y * W4 + X4] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      } else {
+        for (int i = tid; i < ex.H * W4; i += 256) {
+          const int X4 = i % W4, Y = i / W4;
+          int y0, y1; float ly;
+          bilinear_src(Y, sy, ex.h, y0, y1, ly);
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            int x0, x1; float lx;
+            bilinear_src(X4 * 4 + j, sx, ex.w, x0, x1, lx);
+            o[j] = (1.f - ly) * ((1.f - lx) * scam[y0 * ex.w + x0] + lx * scam[y0 * ex.w + x1]) + ly * ((1.f - lx) * scam[y1 * ex.w + x0] + lx * scam[y1 * ex.w + x1]);
+          }
+          dst[i] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -287,10 +355,31 @@ extern "C" int bx_gradcam_head(const void* A, const float* eeg_logp, const float
              "bx_gradcam_head: unsupported sizes (C=%d must be 8*2^k <= 2048, N=%d <= 64, Hd=%d <= 4096)", C, N, Hd);
   BX_REQUIRE(class_mode >= -2 && class_mode < N, "bx_gradcam_head: class %d out of range", class_mode);
   const size_t lds = ((size_t)2 * C + 2 * Hd + 5 * N + (size_t)(256 / (C / 8)) * C) * sizeof(float);
+  const GcExtra none = {nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0, 0};
   BX_DISPATCH_DTYPE(dtype, T,
     hipLaunchKernelGGL((k_gradcam_head<T>), dim3(B, class_mode == -2 ? N : 1), dim3(256), lds, (hipStream_t)stream, (const T*)A, eeg_logp, fc_w, fc_b, w1, b1, w2, b2,
-                       out_logp, cam, raw, weights_out, HW, C, N, Hd, class_mode, relu));
+                       out_logp, cam, raw, weights_out, HW, C, N, Hd, class_mode, relu, none));
   BX_CHECK_LAUNCH("bx_gradcam_head");
+  return BX_OK;
+}
+extern "C" int bx_gradcam_head_sweep(const void* A, const float* eeg_feat, const float* dense_w, const float* dense_b, int Fe, const float* fc_w,
+                                     const float* fc_b, const float* w1, const float* b1, const float* w2, const float* b2, float* out_logp,
+                                     float* maps, int B, int h, int w, int C, int N, int Hd, int H, int W, int class_mode, int relu, int dtype,
+                                     bxStream stream) {
+  BX_DTYPE_OK(dtype);
+  BX_REQUIRE(A && eeg_feat && dense_w && dense_b && fc_w && fc_b && w1 && b1 && w2 && b2 && maps, "bx_gradcam_head_sweep: null pointer");
+  const int HW = h * w;
+  BX_REQUIRE(B > 0 && h > 0 && w > 0 && C % 8 == 0 && C >= 8 && C <= 2048 && 256 % (C / 8) == 0 && N > 0 && N <= 64 && Hd > 0 && Hd <= 4096 && Fe > 0,
+             "bx_gradcam_head_sweep: unsupported sizes (C=%d must be 8*2^k <= 2048, N=%d <= 64, Hd=%d <= 4096)", C, N, Hd);
+  BX_REQUIRE(H > 0 && W > 0 && W % 4 == 0 && ((uintptr_t)maps & 15) == 0, "bx_gradcam_head_sweep: W must be a multiple of 4 and maps 16-byte aligned");
+  BX_REQUIRE(class_mode >= -2 && class_mode < N, "bx_gradcam_head_sweep: class %d out of range", class_mode);
+  const size_t lds = ((size_t)2 * C + 2 * Hd + 5 * N + (size_t)(256 / (C / 8)) * C + HW) * sizeof(float);
+  BX_REQUIRE(lds <= 64 * 1024, "bx_gradcam_head_sweep: stage output of %d positions x %d channels does not fit the workgroup's LDS", HW, C);
+  const GcExtra ex = {eeg_feat, dense_w, dense_b, Fe, maps, h, w, H, W};
+  BX_DISPATCH_DTYPE(dtype, T,
+    hipLaunchKernelGGL((k_gradcam_head<T>), dim3(B, class_mode == -2 ? N : 1), dim3(256), lds, (hipStream_t)stream, (const T*)A, (const float*)nullptr, fc_w,
+                       fc_b, w1, b1, w2, b2, out_logp, (float*)nullptr, (float*)nullptr, (float*)nullptr, HW, C, N, Hd, class_mode, relu, ex));
+  BX_CHECK_LAUNCH("bx_gradcam_head_sweep");
   return BX_OK;
 }
 

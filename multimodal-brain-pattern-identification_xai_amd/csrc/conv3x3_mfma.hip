@@ -1216,7 +1216,8 @@ static int launch_conv_tw(const void* x, const void* wp, const float* bias, cons
                           int B, int H, int W, int Ci, int Co, int relu, hipStream_t s, BxConvPoolEpi* pe = nullptr, const WgradRedJob* red = nullptr) {
   // 8x32 tiles wherever the map is wide enough: a workgroup re-reads its whole weight slab from L2 per pixel tile, so
   // twice the pixels per tile halves the dominant L2 traffic of the late stages (measured: 16x32 maps 22.4 -> 17.3 us)
-  if (W <= 16) return launch_conv<CK, NC, 16>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe, red);
+  static const int tw16_ck = getenv("BX_CONV_TW16_CK") ? atoi(getenv("BX_CONV_TW16_CK")) : 0;     // sweep knob: 8 x 16 tiles for layers with this chunk size
+  if (W <= 16 || (tw16_ck && (tw16_ck & CK))) return launch_conv<CK, NC, 16>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe, red);
   return launch_conv<CK, NC, 32>(x, wp, bias, mask, addend, y, B, H, W, Ci, Co, relu, s, pe, red);
 }
 template <int CK>

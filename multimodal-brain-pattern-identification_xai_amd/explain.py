@@ -92,8 +92,29 @@ def _grad_cam_last_stage(model, eeg, spec, class_idx, upsample, relu, return_par
     else:
         mode = int(class_idx)
     with torch.no_grad():
-        e = model.eeg_model(eeg).contiguous()
-        A = sm.features(spec).permute(0, 2, 3, 1).contiguous()
+        em = model.eeg_model
+        H, W = spec.shape[-2:]
+        if upsample and not return_parts and W % 4 == 0 and hasattr(model, "_fusable") and model._fusable():
+            # sweep form: the EEG branch's dense + LogSoftmax and the up-sampling ride in the head launch (two launches fewer per batch)
+            ef = em.features(eeg).contiguous()
+            A = sm.features(spec).permute(0, 2, 3, 1).contiguous()
+            B, h, w, C = A.shape
+            N, Hd = model.fc2.out_features, model.fc1.out_features
+            nm = N if mode == -2 else 1
+            if ef.shape[1] != em.dense.in_features:
+                raise RuntimeError(f"EEGNet: {ef.shape[1]} features but dense expects {em.dense.in_features} (Samples mismatch)")
+            lds_floats = 2 * C + 2 * Hd + 5 * N + (256 // (C // 8)) * C + h * w
+            if lds_floats * 4 <= 64 * 1024:
+                maps = torch.empty(B * nm, H, W, dtype=torch.float32, device=A.device)
+                L.check(lib.bx_gradcam_head_sweep(_p(A), _p(ef), _p(em.dense.weight), _p(em.dense.bias), ef.shape[1], _p(sm.fc.weight),
+                                                  _p(sm.fc.bias), _p(model.fc1.weight), _p(model.fc1.bias), _p(model.fc2.weight),
+                                                  _p(model.fc2.bias), None, _p(maps), B, h, w, C, N, Hd, H, W, mode, 1 if relu else 0,
+                                                  ops.bx_dtype(A.dtype), _stream()), "bx_gradcam_head_sweep")
+                return maps.reshape(B, nm, H, W) if isinstance(class_idx, str) else maps
+            e = ops.LinearLsmFn.apply(ef, em.dense.weight, em.dense.bias).contiguous()
+        else:
+            e = em(eeg).contiguous()
+            A = sm.features(spec).permute(0, 2, 3, 1).contiguous()
         B, h, w, C = A.shape
         N, Hd = model.fc2.out_features, model.fc1.out_features
         nm = N if mode == -2 else 1

@@ -486,6 +486,11 @@ def test_gradcam_targets():
     rs = float(np.abs(fix["block5.raw"]).max())
     up = brainxai.grad_cam(mine, e, s, class_idx="all")
     assert up.shape == (2, 6, 64, 128)
+    # the sweep form (EEG head + up-sampling inside the head launch) against the three-launch form it replaces
+    from brainxai.explain import resize_bilinear
+    small = brainxai.grad_cam(mine, e, s, class_idx="all", upsample=False)
+    up3 = resize_bilinear(small.reshape(-1, *small.shape[-2:]), (64, 128)).reshape(up.shape)
+    assert float((up - up3).abs().max()) <= 1e-6 * float(up3.abs().max()) + 1e-12
     # ReLU'd maps are compared on the scale of the raw maps (a map can be ~all zero after ReLU)
     check(fix, "up.block5", up.cpu(), tol=TOL, floor=rs, digest=False)
     assert rel_err(up.cpu(), O.grad_cam(ref, eeg, spec, class_idx="all"), floor=rs) < TOL
