@@ -80,6 +80,13 @@ int bx_conv3x3_pack_many_layout(const bxPackJob* jobs_device, int njobs, int tot
 int bx_conv3x3_pack_many_step(const bxPackJob* jobs_device, int njobs, int total_blocks, const float* src_nchw,
                               void* dst_nhwc_bf16, int B, int C, int H, int W, int Cp, uint64_t* state_a, uint64_t* out_a,
                               uint64_t* state_b, uint64_t* out_b, bxStream stream);
+/* conv1 + ReLU and conv2 + ReLU of a stage-1 Block (models.py:64-65) in ONE launch: conv1's output tile stays in LDS and is
+ * written to y1 only when y1 != NULL (a backward pass will read it; evaluation-mode passes hand NULL).  Built for bf16 storage and
+ * 8 (padded) -> 16 -> 16 channels (bx_conv3x3_pair_supported); results are bit-identical to two bx_conv3x3 calls with BX_EPI_RELU.
+ * x [B,H,W,8], y1 / y2 [B,H,W,16]; packed*_mfma from bx_conv3x3_pack / _pack_many (forward operands). */
+int bx_conv3x3_pair_supported(int C0_p, int C1, int C2, int dtype);
+int bx_conv3x3_pair(const void* x, const void* packed1_mfma, const float* bias1, const void* packed2_mfma, const float* bias2,
+                    void* y1, void* y2, int B, int H, int W, int C0_p, int C1, int C2, int dtype, bxStream stream);
 /* y = epi(conv3x3(x, Wp) + bias);  x [B,H,W,Ci] -> y [B,H,W,Co], both `dtype`.
  *   bias (fp32 [Co]) may be NULL; flags & BX_EPI_RELU applies max(.,0);
  *   relu_mask_src (dtype [B,H,W,Co], may be NULL): y *= (relu_mask_src > 0)  -- the ReLU backward

@@ -75,6 +75,8 @@ SIGNATURES = {
     "bx_conv3x3_packed_mfma_bytes": (sz, [i32, i32]),
     "bx_conv3x3_pack_many": (i32, [vp, i32, i32, vp]),
     "bx_conv3x3_pack_many_layout": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "bx_conv3x3_pair_supported": (i32, [i32, i32, i32, i32]),
+    "bx_conv3x3_pair": (i32, [vp] * 7 + [i32] * 7 + [vp]),
     "bx_conv3x3_pack_many_step": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "bx_scale_dev": (i32, [vp, vp, vp, sz, vp]),
     "bx_abs": (i32, [vp, vp, sz, vp]),

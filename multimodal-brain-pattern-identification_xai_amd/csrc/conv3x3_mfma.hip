@@ -901,6 +901,157 @@ __global__ __launch_bounds__(256, (CK == 16 && NC == 1 && TW == 32 && !POOL) ? 4
   if constexpr (POOL) conv_pool_finish<NC>(st, pe, co_base, lds);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stage 1 of the spectrogram CNN: conv1 (8 padded input channels -> 16) and conv2 (16 -> 16) in ONE launch (round 2).
+// Both layers are HBM-bound (153 FLOP/B ridge vs 9 / 72 FLOP/B here), and conv2's only input is conv1's output: the workgroup
+// that owns an 8 x 32 tile of conv2 recomputes conv1 on the tile's (8+2) x (32+2) halo from the (8+4) x (32+4) input halo --
+// 1.33 x of conv1's (negligible) MFMA work -- and keeps that result in LDS in exactly the layout k_conv_mfma_p stages its halo in,
+// so conv2's main loop is the one above.  conv1's output makes no round trip through HBM: it is written once when the backward
+// pass will need it (STORE1; interior pixels only, every pixel belongs to one tile) and not at all in evaluation-mode passes
+// without gradients (Grad-CAM sweeps, inference).  Per image 67 MB (bf16, B=64) less to read, another 67 MB less to write when
+// STORE1 is off.  Arithmetic is operation-for-operation that of the two separate launches: results are bit-identical.
+template <bool STORE1>
+__global__ __launch_bounds__(256, 4) void k_conv12_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp1, const float* __restrict__ bias1,
+    const bf16_t* __restrict__ wp2, const float* __restrict__ bias2, bf16_t* __restrict__ y1, bf16_t* __restrict__ y2,
+    int H, int W, int tiles_x, int tiles_y, int ntiles, uint32_t x_bytes) {
+  constexpr int TH = 8, TW = 32, XW = TW + 4, XH = TH + 4, YW = TW + 2, YH = TH + 2, NX = XH * XW, NY = YH * YW;
+  constexpr int NR = (NX + 255) / 256, NT1 = (NY + 15) / 16, MP = TH * TW / 64, TPR = TW / 16, KS1 = 3, KS2 = 5;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* xs = lds;                           // [NX] pixels x 16 bytes (8 channels)
+  char* y1s = lds + NX * 16;                // [NY] pixels x 32 bytes (16 channels): conv2's halo tile
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
+  int hpy[NR], hpx[NR];
+  uint32_t hrel[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int u = threadIdx.x + k * 256;
+    hpy[k] = u < NX ? u / XW - 2 : -100000;
+    hpx[k] = u % XW - 2;
+    hrel[k] = (uint32_t)(((u / XW - 2) * W + (u % XW - 2)) * 8) * 2u;
+  }
+  uint4 rv[NR];
+  auto fetch = [&](int tile) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    const uint32_t tbase = (uint32_t)(((b * H + y0) * W + x0) * 8) * 2u;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const bool ok = (unsigned)(y0 + hpy[k]) < (unsigned)H && (unsigned)(x0 + hpx[k]) < (unsigned)W;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? tbase + hrel[k] : 0x80000000u, 0, 0);
+      rv[k] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  };
+  const uint32_t y_bytes = (uint32_t)((size_t)(ntiles / (tiles_x * tiles_y)) * H * W * 16 * 2);
+  const __amdgpu_buffer_rsrc_t y1res = __builtin_amdgcn_make_buffer_rsrc((void*)(STORE1 ? y1 : y2), 0, y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t y2res = __builtin_amdgcn_make_buffer_rsrc((void*)y2, 0, y_bytes, 0x00020000);
+  // both layers' weight fragments are loop-invariant: 3 + 5 K-steps x 16 bytes per lane
+  bf16x8 a1[KS1], a2[KS2];
+#pragma unroll
+  for (int s = 0; s < KS1; ++s) a1[s] = *reinterpret_cast<const bf16x8*>(wp1 + ((size_t)s * 16 + li) * 32 + 8 * g);
+#pragma unroll
+  for (int s = 0; s < KS2; ++s) a2[s] = *reinterpret_cast<const bf16x8*>(wp2 + ((size_t)s * 16 + li) * 32 + 8 * g);
+  const float4 b1z = *reinterpret_cast<const float4*>(bias1 + 4 * g), b2z = *reinterpret_cast<const float4*>(bias2 + 4 * g);
+  const int first_tile = (int)blockIdx.x, tile_stride = (int)gridDim.x;
+  if (first_tile < ntiles) fetch(first_tile);
+  for (int tile = first_tile; tile < ntiles; tile += tile_stride) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    __syncthreads();                          // previous tile's fragment reads (both phases) are done
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int u = threadIdx.x + k * 256;
+      if (u < NX) *reinterpret_cast<uint4*>(xs + u * 16) = rv[k];
+    }
+    __syncthreads();
+    if (tile + tile_stride < ntiles) fetch(tile + tile_stride);
+    // ---- conv1 on the (8+2) x (32+2) halo: 16-pixel tiles of the FLATTENED halo, tile t to wave t % 4
+#pragma unroll 2
+    for (int it = 0; it < (NT1 + 3) / 4; ++it) {         // two rounds at a time: their LDS reads and MFMA chains interleave (all six: spills)
+      const int t = wave + 4 * it;
+      if (t >= NT1) break;
+      const int p = 16 * t + li, pc = p < NY ? p : NY - 1;
+      const int r = pc / YW, c = pc - r * YW;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS1; ++s) {
+        int tap = 4 * s + g;                   // K index 8g + j of K-step s = (tap 4s + g, channel j)
+        const bool valid = tap < 9;
+        if (!valid) tap = 0;
+        const int dy = tap / 3, dx = tap - 3 * dy;
+        bf16x8 bv = *reinterpret_cast<const bf16x8*>(xs + ((r + dy) * XW + c + dx) * 16);
+        if (!valid) bv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[s], bv, acc, 0, 0, 0);
+      }
+      const int iy = y0 - 1 + r, ix = x0 - 1 + c;
+      const bool inside = p < NY && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;   // outside the image: conv2's zero padding
+      const float v0 = inside ? fmaxf(acc[0] + b1z.x, 0.f) : 0.f, v1 = inside ? fmaxf(acc[1] + b1z.y, 0.f) : 0.f;
+      const float v2 = inside ? fmaxf(acc[2] + b1z.z, 0.f) : 0.f, v3 = inside ? fmaxf(acc[3] + b1z.w, 0.f) : 0.f;
+      const u32x2 out = {pack2bf(v0, v1), pack2bf(v2, v3)};
+      if (p < NY) *reinterpret_cast<u32x2*>(y1s + p * 32 + 8 * g) = out;
+      if constexpr (STORE1) {
+        const bool own = inside && r >= 1 && r <= TH && c >= 1 && c <= TW;
+        const uint32_t off = own ? (uint32_t)((((b * H + iy) * W + ix) * 16 + 4 * g) * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b64(out, y1res, off, 0, 0);
+      }
+    }
+    __syncthreads();
+    // ---- conv2 on the 8 x 32 tile: k_conv_mfma_p<16, 1, 32>'s loop over the LDS tile just written
+    f32x4 acc2[MP];
+#pragma unroll
+    for (int i = 0; i < MP; ++i) acc2[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS2; ++s) {
+      const int q0 = s * 32 + 8 * g;
+      int tap = q0 / 16;
+      const int c8 = (q0 % 16) / 8;
+      const bool valid = tap < 9;
+      if (!valid) tap = 0;
+      const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+      for (int i = 0; i < MP; ++i) {
+        const int t = wave * MP + i;
+        const int p = (t / TPR + dy) * YW + (t % TPR) * 16 + li + dx;
+        bf16x8 bv = *reinterpret_cast<const bf16x8*>(y1s + p * 32 + 16 * c8);
+        if (!valid) bv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[s], bv, acc2[i], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MP; ++i) {
+      const int t = wave * MP + i;
+      const int oy = y0 + t / TPR, ox = x0 + (t % TPR) * 16 + li;
+      const bool inb = oy < H && ox < W;
+      const uint32_t off = inb ? (uint32_t)((((b * H + oy) * W + ox) * 16 + 4 * g) * 2) : 0x80000000u;
+      const u32x2 out = {pack2bf(fmaxf(acc2[i][0] + b2z.x, 0.f), fmaxf(acc2[i][1] + b2z.y, 0.f)),
+                         pack2bf(fmaxf(acc2[i][2] + b2z.z, 0.f), fmaxf(acc2[i][3] + b2z.w, 0.f))};
+      __builtin_amdgcn_raw_buffer_store_b64(out, y2res, off, 0, 0);
+    }
+  }
+}
+extern "C" int bx_conv3x3_pair_supported(int C0_p, int C1, int C2, int dtype) { return dtype == BX_BF16 && C0_p == 8 && C1 == 16 && C2 == 16; }
+extern "C" int bx_conv3x3_pair(const void* x, const void* packed1_mfma, const float* bias1, const void* packed2_mfma, const float* bias2,
+                               void* y1, void* y2, int B, int H, int W, int C0_p, int C1, int C2, int dtype, bxStream stream) {
+  BX_REQUIRE(x && packed1_mfma && bias1 && packed2_mfma && bias2 && y2 && B > 0 && H > 0 && W > 0, "bx_conv3x3_pair: bad arguments");
+  BX_REQUIRE(bx_conv3x3_pair_supported(C0_p, C1, C2, dtype), "bx_conv3x3_pair: built for bf16 storage, 8 (padded) -> 16 -> 16 channels (got %d -> %d -> %d)",
+             C0_p, C1, C2);
+  BX_REQUIRE((size_t)B * H * W * 16 * 2 < ((size_t)1 << 31), "bx_conv3x3_pair: an activation tensor of 2 GiB or more is not supported");
+  const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
+  const long long ntiles = (long long)tiles_x * tiles_y * B;
+  BX_REQUIRE(ntiles < (1ll << 31), "bx_conv3x3_pair: too many tiles");
+  const int gx = ntiles < 2048 ? (int)ntiles : 2048;
+  const size_t lds = (size_t)12 * 36 * 16 + (size_t)10 * 34 * 32;
+  const uint32_t xb = (uint32_t)((size_t)B * H * W * 8 * 2);
+  if (y1)
+    hipLaunchKernelGGL((k_conv12_mfma<true>), dim3((unsigned)gx), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)packed1_mfma, bias1,
+                       (const bf16_t*)packed2_mfma, bias2, (bf16_t*)y1, (bf16_t*)y2, H, W, tiles_x, tiles_y, (int)ntiles, xb);
+  else
+    hipLaunchKernelGGL((k_conv12_mfma<false>), dim3((unsigned)gx), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)packed1_mfma, bias1,
+                       (const bf16_t*)packed2_mfma, bias2, (bf16_t*)nullptr, (bf16_t*)y2, H, W, tiles_x, tiles_y, (int)ntiles, xb);
+  BX_CHECK_LAUNCH("bx_conv3x3_pair");
+  return BX_OK;
+}
+
 // K-split variant for Ci >= 64 (the MFMA-bound late stages, where maps are small and a workgroup-per-tile kernel is a
 // serial chain stage -> 18*nchunk K-steps -> epilogue on too few workgroups).  A workgroup owns 4 x 16 pixels x 64 output
 // channels; ALL input chunks of its (4+2) x (16+2) halo sit in LDS at once and wave w takes K-steps w, w+4, w+8, ...

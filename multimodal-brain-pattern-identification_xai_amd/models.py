@@ -75,7 +75,7 @@ class Block(nn.Module):
         cfg = ops.block_cfg(pool=self.pool_type, training=self.training, dropout_p=self.dropout.p if self.training else 0.0,
                             eps=bn.eps, momentum=0.1 if bn.momentum is None else bn.momentum, salt=self.salt,
                             preact=self._preact, capture=self._capture, prepacked=self._prepacked, pack_base=self._pack_base, seed=self._seed,
-                            keep=self._keep, sync=self._sync_words(xi.device))
+                            keep=self._keep, sync=self._sync_words(xi.device), grad_mode=torch.is_grad_enabled())
         out = ops.BlockFn.apply(xi, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.conv3.weight,
                                 self.conv3.bias, bn.weight, bn.bias, self.conv1x1.weight, self.conv1x1.bias,
                                 bn.running_mean, bn.running_var, bn.num_batches_tracked, cfg)

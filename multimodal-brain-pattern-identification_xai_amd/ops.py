@@ -361,6 +361,8 @@ WGRAD_CARRY = _os.environ.get("BX_WGRAD_CARRY", "1") == "1"
 TAIL_IN_LAUNCH = _os.environ.get("BX_TAIL_IN_LAUNCH", "1") == "1"
 # conv3 of a Block pools and sums the batch statistics in its epilogue (bx_block_conv3_tail_fwd); 0 = conv3, then the pooling kernel
 FUSE_POOL = _os.environ.get("BX_FUSE_POOL", "1") == "1"
+# stage 1's conv1 and conv2 in one launch (bx_conv3x3_pair); 0 = two bx_conv3x3 launches
+CONV_PAIR = _os.environ.get("BX_CONV_PAIR", "1") == "1"
 # EEGNet front end without the conv1 output tensor (bxEegDesc.collapse); 0 = conv1, BatchNorm1 and the electrode mix layer by layer
 EEG_COLLAPSE = _os.environ.get("BX_EEG_COLLAPSE", "1") == "1"
 _WG_CHAIN = {}
@@ -447,7 +449,25 @@ class BlockFn(torch.autograd.Function):
         # conv3 with the pool and the batch statistics in its epilogue (two launches for conv3 + tail instead of four)
         fused = FUSE_POOL and dt == torch.bfloat16 and CONV_ALGO != L.BX_ALGO_DIRECT and cfg.preact != 3 and Cc >= 16 and CONV_PROFILE is None
         packed3 = None
-        for k in range(3):
+        first = 0
+        # stage 1 (8 padded input channels -> 16 -> 16, bf16): conv1 and conv2 in one launch, conv1's output kept in LDS and written
+        # out only when a backward pass (or a debugging hook) will read it
+        if (CONV_PAIR and dt == torch.bfloat16 and CONV_ALGO != L.BX_ALGO_DIRECT and cfg.preact not in (1, 2) and CONV_PROFILE is None
+                and lib.bx_conv3x3_pair_supported(x.shape[3], w1.shape[0], w2.shape[0], bx_dtype(dt))):
+            pk = []
+            for k in range(2):
+                packed = cfg.prepacked.get(cfg.pack_base + k, False) if cfg.prepacked is not None else None
+                pk.append(packed if packed is not None else _pack(ws_[k], flip=False, dtype=dt))
+            if pk[0][1] is not None and pk[1][1] is not None:
+                need_y1 = cfg.keep is not None or (getattr(cfg, "grad_mode", True) and any(ctx.needs_input_grad[:11]))
+                y1 = torch.empty(B, H, W, w1.shape[0], dtype=dt, device=x.device) if need_y1 else None
+                y2 = torch.empty(B, H, W, w2.shape[0], dtype=dt, device=x.device)
+                with _Timed("fwd"):
+                    L.check(lib.bx_conv3x3_pair(_p(x), _p(pk[0][1]), _p(b1), _p(pk[1][1]), _p(b2), _p(y1), _p(y2), B, H, W, x.shape[3], w1.shape[0],
+                                                w2.shape[0], bx_dtype(dt), _stream()), "bx_conv3x3_pair")
+                acts += [y1 if y1 is not None else x.new_empty(0), y2]
+                first = 2
+        for k in range(first, 3):
             packed = cfg.prepacked.get(cfg.pack_base + k, False) if cfg.prepacked is not None else None
             if packed is None:
                 packed = _pack(ws_[k], flip=False, dtype=dt)
