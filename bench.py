@@ -457,7 +457,12 @@ def main():
         line.update(extra)
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():
-        dist.destroy_process_group()
+        # every rank is done and the result line is out: leave without tearing the communicator down (a destroy_process_group with
+        # captured graphs alive aborted once in the GPU test suite; an abort here would turn a finished measurement into a failed run)
+        dist.barrier()
+        torch.cuda.synchronize()
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -180,6 +180,8 @@ def setup(rank, world_size, backend=None):
 
 def cleanup():
     if dist.is_initialized():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()                      # nothing may still be queued on RCCL's stream when the communicator goes
         dist.destroy_process_group()
 
 
