@@ -126,40 +126,42 @@ def test_conv_mfma_data_gradient_to_8_padded_channels(co_layer, batch, h, w):
     assert rel_err(outs["mfma"], outs["direct"]) < 8e-3
 
 
-@pytest.mark.parametrize("batch,h,w", [(3, 20, 45), (2, 8, 32), (1, 9, 33), (64, 128, 256)])
-def test_conv_pair_is_bit_identical_to_two_launches(batch, h, w):
+@pytest.mark.parametrize("cin,c1,batch,h,w", [(4, 16, 3, 20, 45), (4, 16, 2, 8, 32), (4, 16, 1, 9, 33), (4, 16, 64, 128, 256),
+                                                (16, 32, 3, 20, 45), (16, 32, 2, 8, 32), (16, 32, 1, 9, 33), (16, 32, 64, 64, 128)])
+def test_conv_pair_is_bit_identical_to_two_launches(cin, c1, batch, h, w):
     """stage 1's conv1 + conv2 in one launch (conv1's tile recomputed on the halo and kept in LDS): the same MFMA sequence on the same
     operands as the two separate launches, so y1 and y2 must be EQUAL bit for bit -- with the conv1 output written out (training) and
     without (evaluation-mode passes); image edges, ragged tiles, and the benchmark's batch (several tiles per workgroup)"""
     torch.manual_seed(5 + h)
-    x = _bf(torch.rand(batch, 4, h, w))
-    w1 = _bf(torch.randn(16, 4, 3, 3) / 6.0)
-    w2 = _bf(torch.randn(16, 16, 3, 3) / 12.0)
-    b1, b2 = torch.randn(16) * 0.1, torch.randn(16) * 0.1
+    x = _bf(torch.rand(batch, cin, h, w))
+    w1 = _bf(torch.randn(c1, cin, 3, 3) / (3 * cin ** 0.5))
+    w2 = _bf(torch.randn(c1, c1, 3, 3) / (3 * c1 ** 0.5))
+    b1, b2 = torch.randn(c1) * 0.1, torch.randn(c1) * 0.1
+    cp = ops.pad8(cin)
     xn = ops.to_nhwc(x.to(DEV), torch.bfloat16)
     p1, p2 = ops._pack(w1.to(DEV), False, torch.bfloat16), ops._pack(w2.to(DEV), False, torch.bfloat16)
     lib = L.load()
     st = torch.cuda.current_stream().cuda_stream
     b1d, b2d = b1.to(DEV), b2.to(DEV)
-    y1 = torch.empty(batch, h, w, 16, dtype=torch.bfloat16, device=DEV)
+    y1 = torch.empty(batch, h, w, c1, dtype=torch.bfloat16, device=DEV)
     y2 = torch.empty_like(y1)
-    L.check(lib.bx_conv3x3(xn.data_ptr(), None, p1[1].data_ptr(), b1d.data_ptr(), None, None, y1.data_ptr(), batch, h, w, 8, 16, L.BX_BF16,
+    L.check(lib.bx_conv3x3(xn.data_ptr(), None, p1[1].data_ptr(), b1d.data_ptr(), None, None, y1.data_ptr(), batch, h, w, cp, c1, L.BX_BF16,
                            L.BX_EPI_RELU, L.BX_ALGO_MFMA, st), "conv1")
-    L.check(lib.bx_conv3x3(y1.data_ptr(), None, p2[1].data_ptr(), b2d.data_ptr(), None, None, y2.data_ptr(), batch, h, w, 16, 16, L.BX_BF16,
+    L.check(lib.bx_conv3x3(y1.data_ptr(), None, p2[1].data_ptr(), b2d.data_ptr(), None, None, y2.data_ptr(), batch, h, w, c1, c1, L.BX_BF16,
                            L.BX_EPI_RELU, L.BX_ALGO_MFMA, st), "conv2")
     z1 = torch.full_like(y1, 3.0)
     z2, z2b = torch.full_like(y1, 3.0), torch.full_like(y1, 3.0)
     L.check(lib.bx_conv3x3_pair(xn.data_ptr(), p1[1].data_ptr(), b1d.data_ptr(), p2[1].data_ptr(), b2d.data_ptr(), z1.data_ptr(), z2.data_ptr(),
-                                batch, h, w, 8, 16, 16, L.BX_BF16, st), "pair")
+                                batch, h, w, cp, c1, c1, L.BX_BF16, st), "pair")
     L.check(lib.bx_conv3x3_pair(xn.data_ptr(), p1[1].data_ptr(), b1d.data_ptr(), p2[1].data_ptr(), b2d.data_ptr(), None, z2b.data_ptr(),
-                                batch, h, w, 8, 16, 16, L.BX_BF16, st), "pair (no y1)")
+                                batch, h, w, cp, c1, c1, L.BX_BF16, st), "pair (no y1)")
     torch.cuda.synchronize()
     assert torch.equal(z1.view(torch.int16), y1.view(torch.int16))
     assert torch.equal(z2.view(torch.int16), y2.view(torch.int16))
     assert torch.equal(z2b.view(torch.int16), y2.view(torch.int16))
     if batch <= 3:                                         # and against the fp32 reference of the two layers
         want = F.relu(F.conv2d(_bf(F.relu(F.conv2d(x, w1, b1, padding=1))), w2, b2, padding=1))
-        assert rel_err(ops.to_nchw_f32(z2, 16).cpu(), want) < 8e-3
+        assert rel_err(ops.to_nchw_f32(z2, c1).cpu(), want) < 8e-3
 
 
 def test_block_bf16_mfma_matches_direct_path():

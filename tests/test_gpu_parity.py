@@ -1039,6 +1039,35 @@ def test_full_size_properties():
     assert float(resid) < 1e-3, float(resid)
 
 
+@pytest.mark.parametrize("n", [5, 1000, 1024 * 64 + 4, 1024 * 65 * 3 + 7])
+def test_adamw_step_counter_advances_inside_the_update_launch(n):
+    """bx_adamw_step_dev advances the step count in the update launch itself (every workgroup reads it, two-level tickets find the
+    last one): one, two and several ticket groups, arena sizes that are not multiples of 4; four steps against torch.optim.AdamW,
+    the count equal to the number of launches and every ticket word back at zero after each launch"""
+    lib = L.load()
+    gcpu = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=gcpu)
+    words = int(lib.bx_adamw_step_words(n))
+    assert words >= 32 and words == 16 * (2 + -(-max(1, -(-(n // 4) // 256)) // 64))
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    stepbuf = torch.zeros(words, dtype=torch.float32, device=DEV)
+    hyper = torch.tensor([1e-2, 0.9, 0.999, 1e-8, 1e-2, 1.0, 0.0, 0.0], dtype=torch.float32, device=DEV)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-2, weight_decay=1e-2)
+    for k in range(4):
+        g = torch.randn(n, generator=gcpu)
+        gd = g.to(DEV)
+        L.check(lib.bx_adamw_step_dev(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, hyper.data_ptr(), stepbuf.data_ptr(), None, None,
+                                      torch.cuda.current_stream().cuda_stream), "bx_adamw_step_dev")
+        ref.grad = g.clone()
+        opt.step()
+        torch.cuda.synchronize()
+        assert float(stepbuf[0]) == k + 1
+        assert int(stepbuf[1:].view(torch.int32).abs().max()) == 0, "ticket words must be zero between launches"
+        assert float((p.cpu() - ref.detach()).abs().max()) <= 2e-6 * float(ref.detach().abs().max())
+
+
 def test_zz_error_report():
     """Not a check: prints the worst deviations recorded by the tests above (kept in the GPU log)."""
     worst = sorted(REPORT, key=lambda r: -r[1])[:25]
