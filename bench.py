@@ -293,7 +293,9 @@ def main():
                     "arithmetic_intensity_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
                     "avg_launch_us": round(conv_time / max(n_launch, 1) * 1e6, 2),
                     "share_of_step": round(conv_time / (elapsed / args.steps), 3),
-                    "timing": "HIP events around each launch, %d eagerly launched steps right after the timed region" % prof_steps}
+                    "timing": "HIP events around each launch, %d eagerly launched steps right after the timed region; measured layer by layer: the "
+                              "timed region's fused launches (conv3 + pool + statistics, conv1 + conv2 of stages 1-2) run as their separate "
+                              "convolutions here" % prof_steps}
         extra["roofline_mfma"] = {"achieved": round(ach_tf, 2), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                                   "frac": round(ach_tf / MFMA_PEAK_TFLOPS[args.dtype], 5)}
         extra["conv_ms_per_step"] = {k_: round(sum(v) / prof_steps * 1e3, 3) for k_, v in kinds.items()}

@@ -38,7 +38,7 @@ enum { BX_OK = 0, BX_EINVAL = -1, BX_EDTYPE = -2, BX_EALIGN = -3, BX_EWORKSPACE 
 /* conv algorithm selector: 0 = library default, 1 = direct VALU (any dtype), 2 = MFMA implicit GEMM */
 enum { BX_ALGO_AUTO = 0, BX_ALGO_DIRECT = 1, BX_ALGO_MFMA = 2 };
 /* epilogue flags of bx_conv3x3 */
-enum { BX_EPI_RELU = 1 };
+enum { BX_EPI_RELU = 1, BX_EPI_MASK_BITS = 2 };   /* MASK_BITS: relu_mask_src is the bit form written by bx_conv3x3_pair (MFMA path, Ci <= 32) */
 
 typedef void* bxStream;
 
@@ -83,10 +83,14 @@ int bx_conv3x3_pack_many_step(const bxPackJob* jobs_device, int njobs, int total
 /* conv1 + ReLU and conv2 + ReLU of a stage-1 Block (models.py:64-65) in ONE launch: conv1's output tile stays in LDS and is
  * written to y1 only when y1 != NULL (a backward pass will read it; evaluation-mode passes hand NULL).  Built for bf16 storage and
  * 8 (padded) -> 16 -> 16 channels (bx_conv3x3_pair_supported); results are bit-identical to two bx_conv3x3 calls with BX_EPI_RELU.
- * x [B,H,W,8], y1 / y2 [B,H,W,16]; packed*_mfma from bx_conv3x3_pack / _pack_many (forward operands). */
+ * x [B,H,W,C0_p], y1 / y2 [B,H,W,C1]; packed*_mfma from bx_conv3x3_pack / _pack_many (forward operands).  Also built for
+ * 16 -> 32 -> 32.  mask1 / mask2 (nullable, only with y1): the ReLU decisions of y1 / y2 as bits, uint8 [B,H,W,C1/4], bit r of byte q =
+ * channel 4q + r is positive -- what the layers' data gradients read instead of the activations (bx_conv3x3 with BX_EPI_MASK_BITS:
+ * 1/8 of the bytes in the HBM-bound early stages). */
 int bx_conv3x3_pair_supported(int C0_p, int C1, int C2, int dtype);
 int bx_conv3x3_pair(const void* x, const void* packed1_mfma, const float* bias1, const void* packed2_mfma, const float* bias2,
-                    void* y1, void* y2, int B, int H, int W, int C0_p, int C1, int C2, int dtype, bxStream stream);
+                    void* y1, void* y2, unsigned char* mask1, unsigned char* mask2, int B, int H, int W, int C0_p, int C1, int C2,
+                    int dtype, bxStream stream);
 /* y = epi(conv3x3(x, Wp) + bias);  x [B,H,W,Ci] -> y [B,H,W,Co], both `dtype`.
  *   bias (fp32 [Co]) may be NULL; flags & BX_EPI_RELU applies max(.,0);
  *   relu_mask_src (dtype [B,H,W,Co], may be NULL): y *= (relu_mask_src > 0)  -- the ReLU backward

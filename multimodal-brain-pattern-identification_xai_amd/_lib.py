@@ -15,6 +15,7 @@ BX_F32, BX_BF16 = 0, 1
 BX_POOL_MAX, BX_POOL_AVG = 0, 1
 BX_ALGO_AUTO, BX_ALGO_DIRECT, BX_ALGO_MFMA = 0, 1, 2
 BX_EPI_RELU = 1
+BX_EPI_MASK_BITS = 2
 BX_TAIL_SYNC_WORDS = 8192
 
 vp, i32, i64, u32, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_float, C.c_size_t
@@ -76,7 +77,7 @@ SIGNATURES = {
     "bx_conv3x3_pack_many": (i32, [vp, i32, i32, vp]),
     "bx_conv3x3_pack_many_layout": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "bx_conv3x3_pair_supported": (i32, [i32, i32, i32, i32]),
-    "bx_conv3x3_pair": (i32, [vp] * 7 + [i32] * 7 + [vp]),
+    "bx_conv3x3_pair": (i32, [vp] * 9 + [i32] * 7 + [vp]),
     "bx_conv3x3_pack_many_step": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "bx_scale_dev": (i32, [vp, vp, vp, sz, vp]),
     "bx_abs": (i32, [vp, vp, sz, vp]),

@@ -146,6 +146,7 @@ static int conv3x3_impl(const void* x, const float* packed_f32, const void* pack
       BX_FAIL(BX_EUNSUPPORTED, "bx_conv3x3: MFMA path needs bf16 storage, packed_mfma and Ci%%8==0, Co%%16==0 (Ci=%d Co=%d dtype=%d)", Ci, Co, dtype);
     return bx_conv3x3_mfma_launch(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, flags, s, carry);
   }
+  BX_REQUIRE(!(flags & BX_EPI_MASK_BITS), "bx_conv3x3: BX_EPI_MASK_BITS needs the MFMA path");
   if (carry && carry->valid) {                                 // the direct kernels cannot carry a reduce: finish the chain first
     const int rc = bx_wgrad_mfma_finish(carry, s);
     if (rc) return rc;

@@ -194,6 +194,17 @@ __device__ __forceinline__ int lds_chunk(int c, int p) {
   return c;
 }
 
+// ReLU decisions as BITS (round 2): the data gradient of a layer multiplies by (y > 0) of the layer below, and reading the bf16
+// activation for that costs as many bytes as the gradient itself in the HBM-bound early stages.  The forward pair kernels also write
+// one byte per (pixel, group of 4 channels) -- bit r = channel 4q + r is positive -- and the data-gradient epilogues read that byte
+// instead of 8 bytes of activations (BX_EPI_MASK_BITS).  Byte offset = bf16 byte offset / 8.
+__device__ __forceinline__ unsigned char relu_bits(u32x2 v) {
+  const uint32_t h[4] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16};
+  unsigned b = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) b |= (h[r] != 0u && h[r] < 0x8000u) ? (1u << r) : 0u;
+  return (unsigned char)b;
+}
 // lane exchanges inside a row of 16 lanes as DPP modifiers (no LDS crossbar trip): quad_perm [1,0,3,2] / [2,3,0,1], row_ror:4 / :8
 template <int CTRL> __device__ __forceinline__ float dpp16(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
@@ -386,7 +397,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   // 32-bit byte offsets through buffer resources, out-of-image lanes point past the end (loads read 0, stores are dropped)
   const uint32_t y_bytes = (uint32_t)((size_t)gx / (tiles_x * tiles_y) * IMGS * H * W * Co * 2);
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, y_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src ? mask_src : y), 0, y_bytes, 0x00020000);
+  const bool mbits = CK <= 32 && (relu & 2);      // BX_EPI_MASK_BITS: mask_src is the byte-per-4-channels form (early stages only)
+  const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src ? mask_src : y), 0, mbits ? y_bytes / 8 : y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend : y), 0, y_bytes, 0x00020000);
   const bool ch_ok = C8 ? g < 2 : true;           // false only for the zero rows of an 8-channel output
   float4 bz[NC];
@@ -436,10 +448,17 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
     return;
   }
   if (mask_src) {
+    if (mbits) {
 #pragma unroll
-    for (int i = 0; i < MP; ++i)
+      for (int i = 0; i < MP; ++i)
 #pragma unroll
-      for (int n = 0; n < NC; ++n) mk[i][n] = __builtin_amdgcn_raw_buffer_load_b64(mres, offs[i][n], 0, 0);
+        for (int n = 0; n < NC; ++n) mk[i][n].x = __builtin_amdgcn_raw_buffer_load_b8(mres, offs[i][n] >> 3, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < MP; ++i)
+#pragma unroll
+        for (int n = 0; n < NC; ++n) mk[i][n] = __builtin_amdgcn_raw_buffer_load_b64(mres, offs[i][n], 0, 0);
+    }
   }
   if (addend) {
 #pragma unroll
@@ -452,11 +471,15 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
       float v[4] = {acc[i][n][0] + bz[n].x, acc[i][n][1] + bz[n].y, acc[i][n][2] + bz[n].z, acc[i][n][3] + bz[n].w};
-      if (relu) {
+      if (relu & 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
-      if (mask_src) {
+      if (mask_src && mbits) {
+        const uint32_t m = mk[i][n].x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (m >> r) & 1u ? v[r] : 0.f;
+      } else if (mask_src) {
         const u32x2 m = mk[i][n];
         // bf16 > 0  <=>  sign bit clear and magnitude non-zero
         const uint32_t mm[4] = {m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16};
@@ -762,7 +785,8 @@ __global__ __launch_bounds__(256, (CK == 16 && NC == 1 && TW == 32 && !POOL) ? 4
   };
   const uint32_t y_bytes = (uint32_t)((size_t)(ntiles / (tiles_x * tiles_y)) * H * W * Co * 2);
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, y_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src ? mask_src : y), 0, y_bytes, 0x00020000);
+  const bool mbits = (relu & 2) != 0;             // BX_EPI_MASK_BITS (see k_conv_mfma)
+  const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src ? mask_src : y), 0, mbits ? y_bytes / 8 : y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend : y), 0, y_bytes, 0x00020000);
   const uint32_t lane_rel = (uint32_t)((li * Co + co_base + 4 * g) * 2);
   const int Cw = C8 ? 16 : Co;                    // rows of the packed operand (see k_conv_mfma)
@@ -862,10 +886,17 @@ __global__ __launch_bounds__(256, (CK == 16 && NC == 1 && TW == 32 && !POOL) ? 4
       continue;
     }
     if (mask_src) {
+      if (mbits) {
 #pragma unroll
-      for (int i = 0; i < MP; ++i)
+        for (int i = 0; i < MP; ++i)
 #pragma unroll
-        for (int n = 0; n < NC; ++n) mk[i][n] = __builtin_amdgcn_raw_buffer_load_b64(mres, offs[i][n], 0, 0);
+          for (int n = 0; n < NC; ++n) mk[i][n].x = __builtin_amdgcn_raw_buffer_load_b8(mres, offs[i][n] >> 3, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < MP; ++i)
+#pragma unroll
+          for (int n = 0; n < NC; ++n) mk[i][n] = __builtin_amdgcn_raw_buffer_load_b64(mres, offs[i][n], 0, 0);
+      }
     }
     if (addend) {
 #pragma unroll
@@ -878,11 +909,15 @@ __global__ __launch_bounds__(256, (CK == 16 && NC == 1 && TW == 32 && !POOL) ? 4
 #pragma unroll
       for (int n = 0; n < NC; ++n) {
         float v[4] = {acc[i][n][0] + bz[n].x, acc[i][n][1] + bz[n].y, acc[i][n][2] + bz[n].z, acc[i][n][3] + bz[n].w};
-        if (relu) {
+        if (relu & 1) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
-        if (mask_src) {
+        if (mask_src && mbits) {
+          const uint32_t m = mk[i][n].x;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (m >> r) & 1u ? v[r] : 0.f;
+        } else if (mask_src) {
           const u32x2 m = mk[i][n];
           const uint32_t mm[4] = {m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16};
 #pragma unroll
@@ -913,7 +948,7 @@ __global__ __launch_bounds__(256, (CK == 16 && NC == 1 && TW == 32 && !POOL) ? 4
 template <bool STORE1>
 __global__ __launch_bounds__(256, 4) void k_conv12_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp1, const float* __restrict__ bias1,
     const bf16_t* __restrict__ wp2, const float* __restrict__ bias2, bf16_t* __restrict__ y1, bf16_t* __restrict__ y2,
-    int H, int W, int tiles_x, int tiles_y, int ntiles, uint32_t x_bytes) {
+    unsigned char* __restrict__ m1, unsigned char* __restrict__ m2, int H, int W, int tiles_x, int tiles_y, int ntiles, uint32_t x_bytes) {
   constexpr int TH = 8, TW = 32, XW = TW + 4, XH = TH + 4, YW = TW + 2, YH = TH + 2, NX = XH * XW, NY = YH * YW;
   constexpr int NR = (NX + 255) / 256, NT1 = (NY + 15) / 16, MP = TH * TW / 64, TPR = TW / 16, KS1 = 3, KS2 = 5;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -945,6 +980,8 @@ __global__ __launch_bounds__(256, 4) void k_conv12_mfma(const bf16_t* __restrict
   const uint32_t y_bytes = (uint32_t)((size_t)(ntiles / (tiles_x * tiles_y)) * H * W * 16 * 2);
   const __amdgpu_buffer_rsrc_t y1res = __builtin_amdgcn_make_buffer_rsrc((void*)(STORE1 ? y1 : y2), 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t y2res = __builtin_amdgcn_make_buffer_rsrc((void*)y2, 0, y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t m1res = __builtin_amdgcn_make_buffer_rsrc((void*)(STORE1 && m1 ? (void*)m1 : (void*)y2), 0, STORE1 && m1 ? y_bytes / 8 : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t m2res = __builtin_amdgcn_make_buffer_rsrc((void*)(STORE1 && m2 ? (void*)m2 : (void*)y2), 0, STORE1 && m2 ? y_bytes / 8 : 0u, 0x00020000);
   // both layers' weight fragments are loop-invariant: 3 + 5 K-steps x 16 bytes per lane
   bf16x8 a1[KS1], a2[KS2];
 #pragma unroll
@@ -993,6 +1030,7 @@ __global__ __launch_bounds__(256, 4) void k_conv12_mfma(const bf16_t* __restrict
         const bool own = inside && r >= 1 && r <= TH && c >= 1 && c <= TW;
         const uint32_t off = own ? (uint32_t)((((b * H + iy) * W + ix) * 16 + 4 * g) * 2) : 0x80000000u;
         __builtin_amdgcn_raw_buffer_store_b64(out, y1res, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8(relu_bits(out), m1res, off >> 3, 0, 0);     // (zero-sized resource when no mask is wanted: dropped)
       }
     }
     __syncthreads();
@@ -1026,6 +1064,7 @@ __global__ __launch_bounds__(256, 4) void k_conv12_mfma(const bf16_t* __restrict
       const u32x2 out = {pack2bf(fmaxf(acc2[i][0] + b2z.x, 0.f), fmaxf(acc2[i][1] + b2z.y, 0.f)),
                          pack2bf(fmaxf(acc2[i][2] + b2z.z, 0.f), fmaxf(acc2[i][3] + b2z.w, 0.f))};
       __builtin_amdgcn_raw_buffer_store_b64(out, y2res, off, 0, 0);
+      if constexpr (STORE1) __builtin_amdgcn_raw_buffer_store_b8(relu_bits(out), m2res, off >> 3, 0, 0);
     }
   }
 }
@@ -1035,7 +1074,7 @@ __global__ __launch_bounds__(256, 4) void k_conv12_mfma(const bf16_t* __restrict
 template <bool STORE1>
 __global__ __launch_bounds__(256, 4) void k_conv12b_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp1, const float* __restrict__ bias1,
     const bf16_t* __restrict__ wp2, const float* __restrict__ bias2, bf16_t* __restrict__ y1, bf16_t* __restrict__ y2,
-    int H, int W, int tiles_x, int tiles_y, int ntiles, uint32_t x_bytes) {
+    unsigned char* __restrict__ m1, unsigned char* __restrict__ m2, int H, int W, int tiles_x, int tiles_y, int ntiles, uint32_t x_bytes) {
   constexpr int TH = 8, TW = 32, XW = TW + 4, XH = TH + 4, YW = TW + 2, YH = TH + 2, NX = XH * XW, NY = YH * YW;
   constexpr int C0 = 16, C1 = 32, NU = NX * (C0 / 8), NR = (NU + 255) / 256, NT1 = (NY + 15) / 16, MP = TH * TW / 64, TPR = TW / 16;
   constexpr int KS1 = (9 * C0 + 31) / 32, KS2 = (9 * C1 + 31) / 32, NC = C1 / 16;
@@ -1068,6 +1107,8 @@ __global__ __launch_bounds__(256, 4) void k_conv12b_mfma(const bf16_t* __restric
   const uint32_t y_bytes = (uint32_t)((size_t)(ntiles / (tiles_x * tiles_y)) * H * W * C1 * 2);
   const __amdgpu_buffer_rsrc_t y1res = __builtin_amdgcn_make_buffer_rsrc((void*)(STORE1 ? y1 : y2), 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t y2res = __builtin_amdgcn_make_buffer_rsrc((void*)y2, 0, y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t m1res = __builtin_amdgcn_make_buffer_rsrc((void*)(STORE1 && m1 ? (void*)m1 : (void*)y2), 0, STORE1 && m1 ? y_bytes / 8 : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t m2res = __builtin_amdgcn_make_buffer_rsrc((void*)(STORE1 && m2 ? (void*)m2 : (void*)y2), 0, STORE1 && m2 ? y_bytes / 8 : 0u, 0x00020000);
   float4 b1z[NC], b2z[NC];
 #pragma unroll
   for (int n = 0; n < NC; ++n) {
@@ -1123,7 +1164,10 @@ __global__ __launch_bounds__(256, 4) void k_conv12b_mfma(const bf16_t* __restric
         const u32x2 out = {pack2bf(v0, v1), pack2bf(v2, v3)};
         // channels n*16 + 4g .. +3 = 16-byte chunk 2n + g/2, second half of it when g is odd
         if (p < NY) *reinterpret_cast<u32x2*>(y1s + p * 64 + 16 * lds_chunk<32>(2 * n + (g >> 1), p) + 8 * (g & 1)) = out;
-        if constexpr (STORE1) __builtin_amdgcn_raw_buffer_store_b64(out, y1res, own ? goff + (uint32_t)(n * 32) : 0x80000000u, 0, 0);
+        if constexpr (STORE1) {
+          __builtin_amdgcn_raw_buffer_store_b64(out, y1res, own ? goff + (uint32_t)(n * 32) : 0x80000000u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b8(relu_bits(out), m1res, own ? (goff + (uint32_t)(n * 32)) >> 3 : 0x80000000u, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -1171,6 +1215,7 @@ __global__ __launch_bounds__(256, 4) void k_conv12b_mfma(const bf16_t* __restric
         const u32x2 out = {pack2bf(fmaxf(acc2[i][n][0] + b2z[n].x, 0.f), fmaxf(acc2[i][n][1] + b2z[n].y, 0.f)),
                            pack2bf(fmaxf(acc2[i][n][2] + b2z[n].z, 0.f), fmaxf(acc2[i][n][3] + b2z[n].w, 0.f))};
         __builtin_amdgcn_raw_buffer_store_b64(out, y2res, inb ? off + (uint32_t)(n * 32) : 0x80000000u, 0, 0);
+        if constexpr (STORE1) __builtin_amdgcn_raw_buffer_store_b8(relu_bits(out), m2res, inb ? (off + (uint32_t)(n * 32)) >> 3 : 0x80000000u, 0, 0);
       }
     }
   }
@@ -1180,7 +1225,9 @@ extern "C" int bx_conv3x3_pair_supported(int C0_p, int C1, int C2, int dtype) {
   return dtype == BX_BF16 && ((C0_p == 8 && C1 == 16 && C2 == 16) || (second && C0_p == 16 && C1 == 32 && C2 == 32));
 }
 extern "C" int bx_conv3x3_pair(const void* x, const void* packed1_mfma, const float* bias1, const void* packed2_mfma, const float* bias2,
-                               void* y1, void* y2, int B, int H, int W, int C0_p, int C1, int C2, int dtype, bxStream stream) {
+                               void* y1, void* y2, unsigned char* mask1, unsigned char* mask2, int B, int H, int W, int C0_p, int C1, int C2,
+                               int dtype, bxStream stream) {
+  BX_REQUIRE(y1 || (!mask1 && !mask2), "bx_conv3x3_pair: the ReLU bit masks are written together with y1 (training passes)");
   BX_REQUIRE(x && packed1_mfma && bias1 && packed2_mfma && bias2 && y2 && B > 0 && H > 0 && W > 0, "bx_conv3x3_pair: bad arguments");
   BX_REQUIRE(bx_conv3x3_pair_supported(C0_p, C1, C2, dtype), "bx_conv3x3_pair: built for bf16 storage, 8 (padded) -> 16 -> 16 or 16 -> 32 -> 32 channels (got %d -> %d -> %d)",
              C0_p, C1, C2);
@@ -1194,10 +1241,10 @@ extern "C" int bx_conv3x3_pair(const void* x, const void* packed1_mfma, const fl
     const uint32_t xb2 = (uint32_t)((size_t)B * H * W * 16 * 2);
     if (y1)
       hipLaunchKernelGGL((k_conv12b_mfma<true>), dim3((unsigned)ntiles), dim3(256), lds2, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)packed1_mfma, bias1,
-                         (const bf16_t*)packed2_mfma, bias2, (bf16_t*)y1, (bf16_t*)y2, H, W, tiles_x, tiles_y, (int)ntiles, xb2);
+                         (const bf16_t*)packed2_mfma, bias2, (bf16_t*)y1, (bf16_t*)y2, mask1, mask2, H, W, tiles_x, tiles_y, (int)ntiles, xb2);
     else
       hipLaunchKernelGGL((k_conv12b_mfma<false>), dim3((unsigned)ntiles), dim3(256), lds2, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)packed1_mfma, bias1,
-                         (const bf16_t*)packed2_mfma, bias2, (bf16_t*)nullptr, (bf16_t*)y2, H, W, tiles_x, tiles_y, (int)ntiles, xb2);
+                         (const bf16_t*)packed2_mfma, bias2, (bf16_t*)nullptr, (bf16_t*)y2, (unsigned char*)nullptr, (unsigned char*)nullptr, H, W, tiles_x, tiles_y, (int)ntiles, xb2);
     BX_CHECK_LAUNCH("bx_conv3x3_pair (16 -> 32 -> 32)");
     return BX_OK;
   }
@@ -1205,10 +1252,10 @@ extern "C" int bx_conv3x3_pair(const void* x, const void* packed1_mfma, const fl
   const uint32_t xb = (uint32_t)((size_t)B * H * W * 8 * 2);
   if (y1)
     hipLaunchKernelGGL((k_conv12_mfma<true>), dim3((unsigned)gx), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)packed1_mfma, bias1,
-                       (const bf16_t*)packed2_mfma, bias2, (bf16_t*)y1, (bf16_t*)y2, H, W, tiles_x, tiles_y, (int)ntiles, xb);
+                       (const bf16_t*)packed2_mfma, bias2, (bf16_t*)y1, (bf16_t*)y2, mask1, mask2, H, W, tiles_x, tiles_y, (int)ntiles, xb);
   else
     hipLaunchKernelGGL((k_conv12_mfma<false>), dim3((unsigned)gx), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)packed1_mfma, bias1,
-                       (const bf16_t*)packed2_mfma, bias2, (bf16_t*)nullptr, (bf16_t*)y2, H, W, tiles_x, tiles_y, (int)ntiles, xb);
+                       (const bf16_t*)packed2_mfma, bias2, (bf16_t*)nullptr, (bf16_t*)y2, (unsigned char*)nullptr, (unsigned char*)nullptr, H, W, tiles_x, tiles_y, (int)ntiles, xb);
   BX_CHECK_LAUNCH("bx_conv3x3_pair");
   return BX_OK;
 }
@@ -1545,7 +1592,8 @@ static int launch_conv_nc(const void* x, const void* wp, const float* bias, cons
 }
 int bx_conv3x3_mfma_launch(const void* x, const void* packed_mfma, const float* bias, const void* relu_mask_src,
                            const void* addend, void* y, int B, int H, int W, int Ci, int Co, int flags, hipStream_t s, bxWgradPending* carry) {
-  const int relu = (flags & BX_EPI_RELU) ? 1 : 0;
+  const int relu = ((flags & BX_EPI_RELU) ? 1 : 0) | ((flags & BX_EPI_MASK_BITS) ? 2 : 0);
+  BX_REQUIRE(!(flags & BX_EPI_MASK_BITS) || (relu_mask_src && Ci <= 32 && Co >= 16), "bx_conv3x3(mfma): BX_EPI_MASK_BITS applies to the early stages' data gradients (Ci <= 32)");
   // a pending weight-gradient sum rides in this launch (pixel-split kernels only); the job is built like a chained reduce's
   WgradRedJob job = {};
   const WgradRedJob* red = nullptr;

@@ -330,8 +330,9 @@ class PackPlan:
         return self.views.get((i, flip))
 
 
-def _conv(x, packed, bias, mask_src, addend, relu: bool, dtype, carry: bool = False):
-    """carry=True: a pending chained weight-gradient sum of this device rides in the convolution's launch (bx_conv3x3_carry)."""
+def _conv(x, packed, bias, mask_src, addend, relu: bool, dtype, carry: bool = False, mask_bits: bool = False):
+    """carry=True: a pending chained weight-gradient sum of this device rides in the convolution's launch (bx_conv3x3_carry).
+    mask_bits=True: ``mask_src`` is the bit form of the ReLU decisions written by bx_conv3x3_pair (BX_EPI_MASK_BITS)."""
     pf, pm, ip, op = packed
     B, H, W, Ci = x.shape
     if Ci != ip:
@@ -339,14 +340,15 @@ def _conv(x, packed, bias, mask_src, addend, relu: bool, dtype, carry: bool = Fa
     y = torch.empty(B, H, W, op, dtype=dtype, device=x.device)
     algo = CONV_ALGO if x.dtype == torch.bfloat16 else L.BX_ALGO_DIRECT
     st = _wg_chain_state(x.device) if carry and WGRAD_CARRY else None
+    flags = (L.BX_EPI_RELU if relu else 0) | (L.BX_EPI_MASK_BITS if mask_bits else 0)
     with _Timed("fwd" if bias is not None else "dgrad"):
         if st is not None and st.pend.valid and st.stream == _stream():
             L.check(L.load().bx_conv3x3_carry(_p(x), _p(pf), _p(pm), _p(bias), _p(mask_src), _p(addend), _p(y), B, H, W, Ci, op,
-                                              bx_dtype(dtype), L.BX_EPI_RELU if relu else 0, algo, C.byref(st.pend), _stream()), "bx_conv3x3_carry")
+                                              bx_dtype(dtype), flags, algo, C.byref(st.pend), _stream()), "bx_conv3x3_carry")
             st.keep = None
         else:
             L.check(L.load().bx_conv3x3(_p(x), _p(pf), _p(pm), _p(bias), _p(mask_src), _p(addend), _p(y), B, H, W, Ci, op,
-                                        bx_dtype(dtype), L.BX_EPI_RELU if relu else 0, algo, _stream()), "bx_conv3x3")
+                                        bx_dtype(dtype), flags, algo, _stream()), "bx_conv3x3")
     return y
 
 
@@ -361,6 +363,8 @@ WGRAD_CARRY = _os.environ.get("BX_WGRAD_CARRY", "1") == "1"
 TAIL_IN_LAUNCH = _os.environ.get("BX_TAIL_IN_LAUNCH", "1") == "1"
 # conv3 of a Block pools and sums the batch statistics in its epilogue (bx_block_conv3_tail_fwd); 0 = conv3, then the pooling kernel
 FUSE_POOL = _os.environ.get("BX_FUSE_POOL", "1") == "1"
+# the pair launch also writes the ReLU decisions as bits and the data gradients read those (BX_EPI_MASK_BITS); 0 = read the activations
+MASK_BITS = _os.environ.get("BX_MASK_BITS", "1") == "1"
 # stage 1's conv1 and conv2 in one launch (bx_conv3x3_pair); 0 = two bx_conv3x3 launches
 CONV_PAIR = _os.environ.get("BX_CONV_PAIR", "1") == "1"
 # EEGNet front end without the conv1 output tensor (bxEegDesc.collapse); 0 = conv1, BatchNorm1 and the electrode mix layer by layer
@@ -450,6 +454,7 @@ class BlockFn(torch.autograd.Function):
         fused = FUSE_POOL and dt == torch.bfloat16 and CONV_ALGO != L.BX_ALGO_DIRECT and cfg.preact != 3 and Cc >= 16 and CONV_PROFILE is None
         packed3 = None
         first = 0
+        masks = None
         # stage 1 (8 padded input channels -> 16 -> 16, bf16): conv1 and conv2 in one launch, conv1's output kept in LDS and written
         # out only when a backward pass (or a debugging hook) will read it
         if (CONV_PAIR and dt == torch.bfloat16 and CONV_ALGO != L.BX_ALGO_DIRECT and cfg.preact not in (1, 2) and CONV_PROFILE is None
@@ -462,9 +467,13 @@ class BlockFn(torch.autograd.Function):
                 need_y1 = cfg.keep is not None or (getattr(cfg, "grad_mode", True) and any(ctx.needs_input_grad[:11]))
                 y1 = torch.empty(B, H, W, w1.shape[0], dtype=dt, device=x.device) if need_y1 else None
                 y2 = torch.empty(B, H, W, w2.shape[0], dtype=dt, device=x.device)
+                if need_y1 and MASK_BITS:             # the ReLU decisions of y1 / y2 as bits for the data gradients (1/8 of the bytes)
+                    masks = (torch.empty(B, H, W, w1.shape[0] // 4, dtype=torch.uint8, device=x.device),
+                             torch.empty(B, H, W, w2.shape[0] // 4, dtype=torch.uint8, device=x.device))
                 with _Timed("fwd"):
-                    L.check(lib.bx_conv3x3_pair(_p(x), _p(pk[0][1]), _p(b1), _p(pk[1][1]), _p(b2), _p(y1), _p(y2), B, H, W, x.shape[3], w1.shape[0],
-                                                w2.shape[0], bx_dtype(dt), _stream()), "bx_conv3x3_pair")
+                    L.check(lib.bx_conv3x3_pair(_p(x), _p(pk[0][1]), _p(b1), _p(pk[1][1]), _p(b2), _p(y1), _p(y2),
+                                                _p(masks[0]) if masks else None, _p(masks[1]) if masks else None, B, H, W, x.shape[3],
+                                                w1.shape[0], w2.shape[0], bx_dtype(dt), _stream()), "bx_conv3x3_pair")
                 acts += [y1 if y1 is not None else x.new_empty(0), y2]
                 first = 2
         for k in range(first, 3):
@@ -503,6 +512,7 @@ class BlockFn(torch.autograd.Function):
             L.check(lib.bx_block_tail_fwd(C.byref(desc), _p(y3), _p(x), _p(w11), w11.shape[1], _p(b11), _p(bnw), _p(bnb), _p(rm), _p(rv), _p(nbt),
                                           _p(seed), _p(pooled), _p(out), _p(mean), _p(invstd), _p(ws), ws.numel(), _stream()), "bx_block_tail_fwd")
         ctx.cfg, ctx.desc, ctx.seed = cfg, desc, seed
+        ctx.masks = masks                                   # (plain attributes: uint8 side outputs of the pair launch, never differentiated)
         ctx.save_for_backward(x, acts[1], acts[2], y3, pooled, mean, invstd, w1, b1, w2, b2, w3, b3, bnw, bnb, w11, b11)
         if pre is not None:
             cfg.capture["act"] = pre
@@ -551,7 +561,9 @@ class BlockFn(torch.autograd.Function):
                 grads_w[k], grads_b[k] = _wgrad(acts[k], dz, wts[k], bss[k], chain=True)
             packed = cfg.prepacked.get(cfg.pack_base + k, True) if cfg.prepacked is not None else None
             if k > 0:
-                dz = _conv(dz, packed or _pack(wts[k], flip=True, dtype=dt), None, acts[k], None, False, dt)
+                mb = ctx.masks is not None and CONV_ALGO != L.BX_ALGO_DIRECT
+                dz = _conv(dz, packed or _pack(wts[k], flip=True, dtype=dt), None, ctx.masks[k - 1] if mb else acts[k], None, False, dt,
+                           mask_bits=mb)
                 if cfg.preact == k:
                     cfg.capture["grad"] = dz
             elif need_dx:

@@ -152,9 +152,9 @@ def test_conv_pair_is_bit_identical_to_two_launches(cin, c1, batch, h, w):
     z1 = torch.full_like(y1, 3.0)
     z2, z2b = torch.full_like(y1, 3.0), torch.full_like(y1, 3.0)
     L.check(lib.bx_conv3x3_pair(xn.data_ptr(), p1[1].data_ptr(), b1d.data_ptr(), p2[1].data_ptr(), b2d.data_ptr(), z1.data_ptr(), z2.data_ptr(),
-                                batch, h, w, cp, c1, c1, L.BX_BF16, st), "pair")
+                                None, None, batch, h, w, cp, c1, c1, L.BX_BF16, st), "pair")
     L.check(lib.bx_conv3x3_pair(xn.data_ptr(), p1[1].data_ptr(), b1d.data_ptr(), p2[1].data_ptr(), b2d.data_ptr(), None, z2b.data_ptr(),
-                                batch, h, w, cp, c1, c1, L.BX_BF16, st), "pair (no y1)")
+                                None, None, batch, h, w, cp, c1, c1, L.BX_BF16, st), "pair (no y1)")
     torch.cuda.synchronize()
     assert torch.equal(z1.view(torch.int16), y1.view(torch.int16))
     assert torch.equal(z2.view(torch.int16), y2.view(torch.int16))
@@ -162,6 +162,46 @@ def test_conv_pair_is_bit_identical_to_two_launches(cin, c1, batch, h, w):
     if batch <= 3:                                         # and against the fp32 reference of the two layers
         want = F.relu(F.conv2d(_bf(F.relu(F.conv2d(x, w1, b1, padding=1))), w2, b2, padding=1))
         assert rel_err(ops.to_nchw_f32(z2, c1).cpu(), want) < 8e-3
+
+
+@pytest.mark.parametrize("cin,c1,batch,h,w", [(4, 16, 3, 20, 45), (4, 16, 64, 128, 256), (16, 32, 3, 20, 45), (16, 32, 64, 64, 128)])
+def test_relu_bit_masks_give_the_same_data_gradient(cin, c1, batch, h, w):
+    """bx_conv3x3_pair also writes the ReLU decisions of y1 / y2 as bits (one byte per pixel and 4 channels); a data gradient that
+    reads the bits (BX_EPI_MASK_BITS) must equal, bit for bit, the one that reads the activations -- one-shot kernels at the small
+    sizes, the persistent kernel (16 channels) at the benchmark's batch; and the bits themselves must be (y > 0)"""
+    torch.manual_seed(9 + h + c1)
+    x = _bf(torch.rand(batch, cin, h, w) - 0.3)
+    w1 = _bf(torch.randn(c1, cin, 3, 3) / (3 * cin ** 0.5))
+    w2 = _bf(torch.randn(c1, c1, 3, 3) / (3 * c1 ** 0.5))
+    b1, b2 = (torch.randn(c1) * 0.1).to(DEV), (torch.randn(c1) * 0.1).to(DEV)
+    cp = ops.pad8(cin)
+    xn = ops.to_nhwc(x.to(DEV), torch.bfloat16)
+    p1, p2 = ops._pack(w1.to(DEV), False, torch.bfloat16), ops._pack(w2.to(DEV), False, torch.bfloat16)
+    lib = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+    y1 = torch.empty(batch, h, w, c1, dtype=torch.bfloat16, device=DEV)
+    y2 = torch.empty_like(y1)
+    m1 = torch.full((batch, h, w, c1 // 4), 255, dtype=torch.uint8, device=DEV)
+    m2 = torch.full_like(m1, 255)
+    L.check(lib.bx_conv3x3_pair(xn.data_ptr(), p1[1].data_ptr(), b1.data_ptr(), p2[1].data_ptr(), b2.data_ptr(), y1.data_ptr(), y2.data_ptr(),
+                                m1.data_ptr(), m2.data_ptr(), batch, h, w, cp, c1, c1, L.BX_BF16, st), "pair")
+    torch.cuda.synchronize()
+    for y, m in ((y1, m1), (y2, m2)):
+        pos = (y.float() > 0).reshape(batch, h, w, c1 // 4, 4).to(torch.uint8)
+        want = pos[..., 0] | (pos[..., 1] << 1) | (pos[..., 2] << 2) | (pos[..., 3] << 3)
+        assert torch.equal(m, want)
+        assert 0.05 < float(pos.float().mean()) < 0.95          # both decisions occur
+    # data gradient of conv2 (c1 -> c1): dZ1 = conv(dZ2, W2^T flipped) * (y1 > 0)
+    dz = ops.to_nhwc(_bf(torch.randn(batch, c1, h, w)).to(DEV), torch.bfloat16)
+    pd = ops._pack(w2.to(DEV), True, torch.bfloat16)
+    outs = []
+    for mask, flags in ((y1, 0), (m1, L.BX_EPI_MASK_BITS)):
+        o = torch.full((batch, h, w, c1), 5.0, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.bx_conv3x3(dz.data_ptr(), None, pd[1].data_ptr(), None, mask.data_ptr(), None, o.data_ptr(), batch, h, w, c1, c1, L.BX_BF16,
+                               flags, L.BX_ALGO_MFMA, st), "dgrad")
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
 
 
 def test_block_bf16_mfma_matches_direct_path():

@@ -22,7 +22,7 @@ def main():
     spec = torch.rand(B, 4, 128, 256, generator=g).to(dev)
     eeg = torch.randn(B, 1, 19, 2000, generator=g).to(dev)
     model = brainxai.build_multimodal(19, 2000, 4, dropout=0.5, compute_dtype=torch.bfloat16).to(dev).eval()
-    mb = int(os.environ.get("IG_MAX_BATCH", "256"))
+    mb = int(os.environ.get("IG_MAX_BATCH", "1024"))
     brainxai.integrated_gradients(model, (eeg, spec), None, n_steps=4, max_batch=mb)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
