@@ -740,7 +740,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma_c(const bf16_t* __restrict__ 
 // workgroup and relies on occupancy alone to hide it).
 // Launch bound: the block-1 instantiation <16,1,32> (HBM-bound, five launches per training step) allocated 108 + 24 registers, four
 // over the limit for four workgroups per CU; bounded, the compiler finds 122 without spilling: 1.560 -> 1.547 ms/step (same box).
-template <int CK, int NC, int TW, bool POOL = false, bool C8 = false>
+// DL (round 2, CK <= 16 where the staged tile is linear in the thread index): halos go from HBM straight into one of THREE LDS
+// images, two tiles ahead (buffer_load ... lds: no registers hold them -- 95 instead of 122 -- no LDS write instructions, one barrier
+// per tile instead of two); out-of-image lanes load zeros through the same out-of-range offsets.  Not faster (see the launcher).
+template <int CK, int NC, int TW, bool POOL = false, bool C8 = false, bool DL = false>
 __global__ __launch_bounds__(256, (CK == 16 && NC == 1 && TW == 32 && !POOL) ? 4 : 1) void k_conv_mfma_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const bf16_t* __restrict__ mask_src, const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
     int H, int W, int Co, int relu, int tiles_x, int tiles_y, int ntiles, uint32_t x_bytes, BxConvPoolEpi pe, WgradRedJob red, int nred) {
@@ -771,7 +774,8 @@ __global__ __launch_bounds__(256, (CK == 16 && NC == 1 && TW == 32 && !POOL) ? 4
     hpx[k] = p % HWID - 1;
     hrel[k] = (uint32_t)(((p / HWID - 1) * W + (p % HWID - 1)) * CK + c * 8) * 2u;
   }
-  auto fetch = [&](int tile) {
+  constexpr int IMG_BYTES = NR * 256 * 16;        // DL: one LDS image (thread-linear, padded to whole waves)
+  auto fetch = [&](int tile, int img = 0) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int y0 = ty * TH, x0 = tx * TW;
     const uint32_t tbase = (uint32_t)(((b * H + y0) * W + x0) * CK) * 2u;        // bytes; < 2^31 (checked by the launcher)
@@ -779,8 +783,13 @@ __global__ __launch_bounds__(256, (CK == 16 && NC == 1 && TW == 32 && !POOL) ? 4
     for (int k = 0; k < NR; ++k) {
       const bool ok = (unsigned)(y0 + hpy[k]) < (unsigned)H && (unsigned)(x0 + hpx[k]) < (unsigned)W;
       const uint32_t off = ok ? tbase + hrel[k] : 0x80000000u;
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0);
-      rv[k] = make_uint4(v.x, v.y, v.z, v.w);
+      if constexpr (DL) {      // lane l of this wave lands at (wave base of trip k) + 16 l
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (__attribute__((address_space(3))) void*)(lds + img * IMG_BYTES + (k * 256 + wave * 64) * 16), 16,
+                                                 (int)off, 0, 0, 0);
+      } else {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0);
+        rv[k] = make_uint4(v.x, v.y, v.z, v.w);
+      }
     }
   };
   const uint32_t y_bytes = (uint32_t)((size_t)(ntiles / (tiles_x * tiles_y)) * H * W * Co * 2);
@@ -796,6 +805,7 @@ __global__ __launch_bounds__(256, (CK == 16 && NC == 1 && TW == 32 && !POOL) ? 4
   for (int n = 0; n < NC; ++n)
     bz[n] = bias && ch_ok ? *reinterpret_cast<const float4*>(bias + co_base + n * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
   if (first_tile < ntiles) fetch(first_tile);
+  if constexpr (DL) { if (first_tile + tile_stride < ntiles) fetch(first_tile + tile_stride, 1); }      // two tiles ahead, three images
   // pooled form: statistics accumulate over the workgroup's tiles in registers; one reduction-tree row per workgroup at the end
   float st[2][NC][4];
   __amdgpu_buffer_rsrc_t pres = yres;
@@ -807,9 +817,21 @@ __global__ __launch_bounds__(256, (CK == 16 && NC == 1 && TW == 32 && !POOL) ? 4
 #pragma unroll
       for (int r = 0; r < 4; ++r) st[0][n][r] = st[1][n][r] = 0.f;
   }
-  for (int tile = first_tile; tile < ntiles; tile += tile_stride) {
+  int it = 0;
+  for (int tile = first_tile; tile < ntiles; tile += tile_stride, ++it) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int y0 = ty * TH, x0 = tx * TW;
+    const char* cur = lds;
+    if constexpr (DL) {
+      // this wave's loads of the tile have landed (vmcnt counts in issue order: only the previous tile's MP*NC output stores, issued
+      // after them, may still be in flight), then everybody's; the other image was last read before this barrier
+      static_assert(MP * NC + NR <= 15, "vmcnt immediate");
+      if (tile + tile_stride < ntiles) __builtin_amdgcn_s_waitcnt(0x0F70 | (MP * NC + NR));    // + the NR loads of the tile after this one
+      else __builtin_amdgcn_s_waitcnt(0x0F70 | (MP * NC));
+      __syncthreads();
+      cur = lds + (it % 3) * IMG_BYTES;
+      if (tile + 2 * tile_stride < ntiles) fetch(tile + 2 * tile_stride, (it + 2) % 3);
+    } else {
     __syncthreads();                          // previous tile's fragment reads are done
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
@@ -821,6 +843,7 @@ __global__ __launch_bounds__(256, (CK == 16 && NC == 1 && TW == 32 && !POOL) ? 4
     }
     __syncthreads();
     if (tile + tile_stride < ntiles) fetch(tile + tile_stride);
+    }
     f32x4 acc[MP][NC];
 #pragma unroll
     for (int i = 0; i < MP; ++i)
@@ -848,7 +871,7 @@ __global__ __launch_bounds__(256, (CK == 16 && NC == 1 && TW == 32 && !POOL) ? 4
       for (int i = 0; i < MP; ++i) {
         const int t = wave * MP + i;
         const int p = (t / TPR + dy) * HWID + (t % TPR) * 16 + li + dx;
-        bf16x8 bv = *reinterpret_cast<const bf16x8*>(lds + p * CKB + 16 * lds_chunk<CK>(c, p));
+        bf16x8 bv = *reinterpret_cast<const bf16x8*>(cur + p * CKB + 16 * lds_chunk<CK>(c, p));
         if (!valid) bv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int n = 0; n < NC; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s % 3][n], bv, acc[i][n], 0, 0, 0);
@@ -1452,6 +1475,20 @@ static int launch_conv(const void* x, const void* wp, const float* bias, const v
                              (const bf16_t*)wp, bias, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (bf16_t*)y, H, W, Co, 1, tiles_x, tiles_y, ntiles,
                              (uint32_t)((size_t)B * H * W * CK * 2), *pe, nored, 0);
           BX_CHECK_LAUNCH("bx_conv3x3(mfma persistent, pooled)");
+          return BX_OK;
+        }
+      }
+      if constexpr (CK <= 16 && NC == 1) {
+        // Measured (same box, training step): 1.534-1.538 ms with it (two images, one tile ahead: 1.539-1.542) against 1.532-1.536
+        // without -- the block-1 kernels are bound by instruction issue (LDS reads + MFMA + epilogue arithmetic of four waves per
+        // SIMD), not by the latency of their input loads; opt-in (BX_CONV_DLDS=1), results bit-identical.
+        static const bool use_dl = getenv("BX_CONV_DLDS") != nullptr;
+        if (use_dl) {                          // three thread-linear LDS images filled by direct-to-LDS loads, two tiles ahead
+          const size_t lds_dl = (size_t)3 * ((10 * (TW + 2) * (CK / 8) + 255) / 256) * 256 * 16;
+          hipLaunchKernelGGL((k_conv_mfma_p<CK, NC, TW, false, false, true>), dim3((unsigned)(gx + nred), (unsigned)ygroups), dim3(256),
+                             lds_dl < 4096 ? 4096 : lds_dl, s, (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)mask, (const bf16_t*)addend,
+                             (bf16_t*)y, H, W, Co, relu, tiles_x, tiles_y, ntiles, (uint32_t)((size_t)B * H * W * CK * 2), none, rj, nred);
+          BX_CHECK_LAUNCH("bx_conv3x3(mfma persistent, direct-to-LDS)");
           return BX_OK;
         }
       }
