@@ -582,8 +582,11 @@ __global__ __launch_bounds__(256) void k_eeg_bn_bwd_apply16(const float* __restr
 //     accumulators, sliding p1 window: 2 float4 reads per 64 FMAs.
 // Row pitch TP: multiple of 4 with TP/4 odd (the 16 fd rows a wave reads then fall on different bank groups).
 __host__ __device__ inline int eeg_sepb_pitch(int T1) { int tp = ((T1 + 7) & ~7) + 24; if (((tp >> 2) & 1) == 0) tp += 4; return tp; }
+// The BatchNorm3 backward apply (k_eeg_bn_bwd_apply: ds = a (du - k1 - xhat k2), elementwise) rides in the staging of ds when `pre`
+// is given: same expression, evaluated on the way into LDS -- one launch and one pass over du3 fewer.
 __global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ ds, const float* __restrict__ p1, const float* __restrict__ ws,
-                                                      float* __restrict__ dp1, float* __restrict__ wpart, EegGeom g) {
+                                                      float* __restrict__ dp1, float* __restrict__ wpart, EegGeom g, const float* __restrict__ pre,
+                                                      const float* __restrict__ mean, const float* __restrict__ inv, const float* __restrict__ coef) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int T1 = g.T1, TP = eeg_sepb_pitch(T1);
   float* sds = sm;                 // [16][TP]  index t + 8
@@ -600,17 +603,24 @@ __global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ d
       __syncthreads();
       const int n4 = T1 / 4, tot = 16 * n4;
       for (int i0 = threadIdx.x; i0 < tot; i0 += 256 * 8) {
-        float4 a[8], p[8];
+        float4 a[8], p[8], q8[8];
+        const float* preb = pre ? pre + (size_t)b * 16 * T1 : dsb;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int i = i0 + u * 256, ic = i < tot ? i : 0;      // (clamped, unconditional loads: a conditionally filled array went to scratch memory)
           a[u] = reinterpret_cast<const float4*>(dsb)[ic]; p[u] = reinterpret_cast<const float4*>(p1b)[ic];
+          q8[u] = reinterpret_cast<const float4*>(preb)[ic];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int i = i0 + u * 256;
           if (i < tot) {
             const int f = i / n4, c = i % n4;
+            if (pre) {
+              const float ca = coef[f], k1 = coef[EEG_MAXF + f], k2 = coef[2 * EEG_MAXF + f], mu = mean[f], is = inv[f];
+              a[u].x = ca * (a[u].x - k1 - (q8[u].x - mu) * is * k2); a[u].y = ca * (a[u].y - k1 - (q8[u].y - mu) * is * k2);
+              a[u].z = ca * (a[u].z - k1 - (q8[u].z - mu) * is * k2); a[u].w = ca * (a[u].w - k1 - (q8[u].w - mu) * is * k2);
+            }
             *reinterpret_cast<float4*>(sds + f * TP + 8 + 4 * c) = a[u];
             float* q = sp1 + f * TP + 7 + 4 * c;
             q[0] = p[u].x; q[1] = p[u].y; q[2] = p[u].z; q[3] = p[u].w;
@@ -618,7 +628,13 @@ __global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ d
         }
       }
     } else {
-      lds_fill<16>(sds, 16 * TP, [&](int i) { const int f = i / TP, ta = i % TP - 8; return (ta >= 0 && ta < T1) ? dsb[(size_t)f * T1 + ta] : 0.f; });
+      lds_fill<16>(sds, 16 * TP, [&](int i) {
+        const int f = i / TP, ta = i % TP - 8;
+        if (!(ta >= 0 && ta < T1)) return 0.f;
+        const float d = dsb[(size_t)f * T1 + ta];
+        if (!pre) return d;
+        return coef[f] * (d - coef[EEG_MAXF + f] - (pre[((size_t)b * 16 + f) * T1 + ta] - mean[f]) * inv[f] * coef[2 * EEG_MAXF + f]);
+      });
       lds_fill<16>(sp1, 16 * TP, [&](int i) { const int f = i / TP, tb = i % TP - 7; return (tb >= 0 && tb < T1) ? p1b[(size_t)f * T1 + tb] : 0.f; });
     }
     lds_fill<16>(sw, 4096, [&](int i) { return ws[i]; });
@@ -998,18 +1014,13 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
   hipLaunchKernelGGL(k_eeg_bn_bwd_finalize, dim3(1), dim3(1024), 0, s, part, g.B, (double)g.B * g.T1, g.F2, tr, p->bn3_w, st.inv3, coef3, gr->bn3_w, gr->bn3_b,
                      (const float*)nullptr, (float*)nullptr, 0, 0, 4);
   BX_CHECK_LAUNCH("eeg bn3 bwd finalize");
-  {
-    const long long n = (long long)g.B * g.F2 * g.T1;
-    hipLaunchKernelGGL(k_eeg_bn_bwd_apply, dim3(bx_ceil_div(n, 256)), dim3(256), 0, s, du3, smap, st.mean3, st.inv3, coef3, g.F2, g.T1, n);
-    BX_CHECK_LAUNCH("eeg bn3 bwd apply");
-  }
-  // separable conv
+  // separable conv (the BatchNorm3 backward apply rides in its staging)
   {
     const size_t lds = ((size_t)2 * 16 * eeg_sepb_pitch(g.T1) + 4096) * sizeof(float);
     BX_REQUIRE(lds <= 160 * 1024, "bx_eeg_features_bwd: T/P1 too long for the LDS tile (%zu bytes)", lds);
     if (hipFuncSetAttribute((const void*)k_eeg_sep_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       BX_FAIL(BX_EHIP, "bx_eeg_features_bwd: cannot reserve %zu bytes of LDS", lds);
-    hipLaunchKernelGGL(k_eeg_sep_bwd, dim3(g.B, 4), dim3(256), lds, s, du3, p1, p->sep_w, dp1, sepp, g);
+    hipLaunchKernelGGL(k_eeg_sep_bwd, dim3(g.B, 4), dim3(256), lds, s, du3, p1, p->sep_w, dp1, sepp, g, smap, st.mean3, st.inv3, (const float*)coef3);
     BX_CHECK_LAUNCH("eeg sep bwd");
   }
   // pool1/dropout/ELU/BN2
