@@ -82,7 +82,7 @@ def pmc_conv_traffic(dtype):
     for path in reversed(files):
         tot, launches = 0.0, 0.0
         for line in open(path):
-            if not line.startswith(("k_conv_mfma", "k_conv3x3", "k_wgrad_mfma", "k_wgrad_own", "k_wgrad_reduce")):
+            if not line.startswith(("k_conv_mfma", "k_conv12", "k_conv3x3", "k_wgrad_mfma", "k_wgrad_own", "k_wgrad_reduce")):
                 continue
             try:
                 wr, fe, n = float(line.split()[-1]), float(line.split()[-2]), float(line.split()[-3])
@@ -90,7 +90,7 @@ def pmc_conv_traffic(dtype):
                 continue
             tot += n * (fe + wr) * 1e6
             if not line.startswith("k_wgrad_reduce"):
-                launches += n
+                launches += 2 * n if line.startswith("k_conv12") else n        # a pair launch runs two of the family's 44 layer launches
         if launches > 0:
             stamp = time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(path)))
             return round(tot / launches), f"profiles/{os.path.basename(path)} ({stamp})"
