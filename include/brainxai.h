@@ -84,7 +84,7 @@ int bx_conv3x3_pack_many_step(const bxPackJob* jobs_device, int njobs, int total
  * written to y1 only when y1 != NULL (a backward pass will read it; evaluation-mode passes hand NULL).  Built for bf16 storage and
  * 8 (padded) -> 16 -> 16 channels (bx_conv3x3_pair_supported); results are bit-identical to two bx_conv3x3 calls with BX_EPI_RELU.
  * x [B,H,W,C0_p], y1 / y2 [B,H,W,C1]; packed*_mfma from bx_conv3x3_pack / _pack_many (forward operands).  Also built for
- * 16 -> 32 -> 32.  mask1 / mask2 (nullable, only with y1): the ReLU decisions of y1 / y2 as bits, uint8 [B,H,W,C1/4], bit r of byte q =
+ * 16 -> 32 -> 32 and 32 -> 64 -> 64.  mask1 / mask2 (nullable, only with y1): the ReLU decisions of y1 / y2 as bits, uint8 [B,H,W,C1/4], bit r of byte q =
  * channel 4q + r is positive -- what the layers' data gradients read instead of the activations (bx_conv3x3 with BX_EPI_MASK_BITS:
  * 1/8 of the bytes in the HBM-bound early stages). */
 int bx_conv3x3_pair_supported(int C0_p, int C1, int C2, int dtype);

@@ -1091,185 +1091,185 @@ __global__ __launch_bounds__(256, 4) void k_conv12_mfma(const bf16_t* __restrict
     }
   }
 }
-// The same for stage 2 (16 -> 32 -> 32 channels): conv1's tile has 64 bytes per pixel and sits in LDS in k_conv_mfma<32,...>'s swizzled
-// layout (16-byte chunk c of pixel p at c ^ ((p >> 1) & 3)); weight fragments come from L2 per K-step (5 x 2 + 9 x 2 fragments do not fit
-// the register budget as loop invariants), conv2's two K-steps ahead of their use as in k_conv_mfma.
-template <bool STORE1>
-__global__ __launch_bounds__(256, 4) void k_conv12b_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp1, const float* __restrict__ bias1,
+// The same for stages 2 and 3 (16 -> 32 -> 32 and 32 -> 64 -> 64 channels): both tiles sit in LDS in the one-shot kernels' swizzled
+// layouts (lds_chunk<C>), weight fragments come from L2 per K-step, two K-steps ahead of their use (5 x 2 + 9 x 2 fragments and more do
+// not fit the register budget as loop invariants).  ONE tile per workgroup: see the note at the tile below.
+template <int C0, int C1, bool STORE1>
+__global__ __launch_bounds__(256, C1 <= 32 ? 4 : 2) void k_conv12b_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp1, const float* __restrict__ bias1,
     const bf16_t* __restrict__ wp2, const float* __restrict__ bias2, bf16_t* __restrict__ y1, bf16_t* __restrict__ y2,
     unsigned char* __restrict__ m1, unsigned char* __restrict__ m2, int H, int W, int tiles_x, int tiles_y, int ntiles, uint32_t x_bytes) {
   constexpr int TH = 8, TW = 32, XW = TW + 4, XH = TH + 4, YW = TW + 2, YH = TH + 2, NX = XH * XW, NY = YH * YW;
-  constexpr int C0 = 16, C1 = 32, NU = NX * (C0 / 8), NR = (NU + 255) / 256, NT1 = (NY + 15) / 16, MP = TH * TW / 64, TPR = TW / 16;
+  constexpr int NCH0 = C0 / 8, XB = C0 * 2, YB = C1 * 2, NU = NX * NCH0, NR = (NU + 255) / 256, NT1 = (NY + 15) / 16, MP = TH * TW / 64, TPR = TW / 16;
   constexpr int KS1 = (9 * C0 + 31) / 32, KS2 = (9 * C1 + 31) / 32, NC = C1 / 16;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  char* xs = lds;                           // [NX] pixels x 32 bytes
-  char* y1s = lds + NX * 32;                // [NY] pixels x 64 bytes, swizzled
+  char* xs = lds;                           // [NX] pixels x XB bytes, 16-byte chunks swizzled as k_conv_mfma<C0> does
+  char* y1s = lds + NX * XB;                // [NY] pixels x YB bytes, swizzled as k_conv_mfma<C1> does
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
-  int hpy[NR], hpx[NR];
-  uint32_t hrel[NR];
-#pragma unroll
-  for (int k = 0; k < NR; ++k) {
-    const int u = threadIdx.x + k * 256, px = u >> 1, c = u & 1;
-    hpy[k] = u < NU ? px / XW - 2 : -100000;
-    hpx[k] = px % XW - 2;
-    hrel[k] = (uint32_t)(((px / XW - 2) * W + (px % XW - 2)) * C0 + c * 8) * 2u;
-  }
-  uint4 rv[NR];
-  auto fetch = [&](int tile) {
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-    const int y0 = ty * TH, x0 = tx * TW;
-    const uint32_t tbase = (uint32_t)(((b * H + y0) * W + x0) * C0) * 2u;
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const bool ok = (unsigned)(y0 + hpy[k]) < (unsigned)H && (unsigned)(x0 + hpx[k]) < (unsigned)W;
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? tbase + hrel[k] : 0x80000000u, 0, 0);
-      rv[k] = make_uint4(v.x, v.y, v.z, v.w);
-    }
-  };
   const uint32_t y_bytes = (uint32_t)((size_t)(ntiles / (tiles_x * tiles_y)) * H * W * C1 * 2);
   const __amdgpu_buffer_rsrc_t y1res = __builtin_amdgcn_make_buffer_rsrc((void*)(STORE1 ? y1 : y2), 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t y2res = __builtin_amdgcn_make_buffer_rsrc((void*)y2, 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t m1res = __builtin_amdgcn_make_buffer_rsrc((void*)(STORE1 && m1 ? (void*)m1 : (void*)y2), 0, STORE1 && m1 ? y_bytes / 8 : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t m2res = __builtin_amdgcn_make_buffer_rsrc((void*)(STORE1 && m2 ? (void*)m2 : (void*)y2), 0, STORE1 && m2 ? y_bytes / 8 : 0u, 0x00020000);
+  // one tile per workgroup (no persistent loop: with one, the compiler hoists the fragment addresses of both phases out of it as loop
+  // invariants and the 16 -> 32 -> 32 kernel needed 276 registers -- k_conv_mfma_p<32,2,32> has the same problem)
+  const int tile = (int)blockIdx.x;
+  const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+  const int y0 = ty * TH, x0 = tx * TW;
+  {
+    const uint32_t tbase = (uint32_t)(((b * H + y0) * W + x0) * C0) * 2u;
+    uint4 rv[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int u = threadIdx.x + k * 256, px = u / NCH0, c = u % NCH0;
+      const int hy = px / XW - 2, hx = px % XW - 2;
+      const bool ok = u < NU && (unsigned)(y0 + hy) < (unsigned)H && (unsigned)(x0 + hx) < (unsigned)W;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? tbase + (uint32_t)((hy * W + hx) * C0 + c * 8) * 2u : 0x80000000u, 0, 0);
+      rv[k] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int u = threadIdx.x + k * 256, px = u / NCH0, c = u % NCH0;
+      if (u < NU) *reinterpret_cast<uint4*>(xs + px * XB + 16 * lds_chunk<C0>(c, px)) = rv[k];
+    }
+  }
   float4 b1z[NC], b2z[NC];
 #pragma unroll
   for (int n = 0; n < NC; ++n) {
     b1z[n] = *reinterpret_cast<const float4*>(bias1 + n * 16 + 4 * g);
     b2z[n] = *reinterpret_cast<const float4*>(bias2 + n * 16 + 4 * g);
   }
-  // one tile per workgroup (no persistent loop: with one, the compiler hoists the 36 + 30 fragment addresses of both phases out of
-  // it as loop invariants and the kernel needs 276 registers -- k_conv_mfma_p<32,2,32> has the same problem)
-  {
-    const int tile = (int)blockIdx.x;
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-    const int y0 = ty * TH, x0 = tx * TW;
-    fetch(tile);
+  __syncthreads();
+  // ---- conv1 (C0 -> C1) on the flattened (8+2) x (32+2) halo
+  for (int t = wave; t < NT1; t += 4) {
+    const int p = 16 * t + li, pc = p < NY ? p : NY - 1;
+    const int r = pc / YW, c = pc - r * YW;
+    f32x4 acc[NC];
 #pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const int u = threadIdx.x + k * 256;
-      if (u < NU) *reinterpret_cast<uint4*>(xs + u * 16) = rv[k];
-    }
-    __syncthreads();
-    // ---- conv1 (16 -> 32) on the flattened (8+2) x (32+2) halo
-    for (int t = wave; t < NT1; t += 4) {
-      const int p = 16 * t + li, pc = p < NY ? p : NY - 1;
-      const int r = pc / YW, c = pc - r * YW;
-      f32x4 acc[NC];
+    for (int n = 0; n < NC; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 a1[3][NC];
+    auto load_a1 = [&](int s_, bf16x8 (&dst)[NC]) {
 #pragma unroll
-      for (int n = 0; n < NC; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      bf16x8 a1[KS1][NC];                      // (from L1/L2 every round: as loop invariants they pushed the kernel past 256 registers)
-#pragma unroll
-      for (int s = 0; s < KS1; ++s)
-#pragma unroll
-        for (int n = 0; n < NC; ++n) a1[s][n] = *reinterpret_cast<const bf16x8*>(wp1 + ((size_t)s * C1 + n * 16 + li) * 32 + 8 * g);
-#pragma unroll
-      for (int s = 0; s < KS1; ++s) {
-        const int q0 = s * 32 + 8 * g;
-        int tap = q0 / C0;
-        const int c8 = (q0 % C0) / 8;
-        const bool valid = tap < 9;
-        if (!valid) tap = 0;
-        const int dy = tap / 3, dx = tap - 3 * dy;
-        bf16x8 bv = *reinterpret_cast<const bf16x8*>(xs + ((r + dy) * XW + c + dx) * 32 + 16 * c8);
-        if (!valid) bv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int n = 0; n < NC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[s][n], bv, acc[n], 0, 0, 0);
-      }
-      const int iy = y0 - 1 + r, ix = x0 - 1 + c;
-      const bool inside = p < NY && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      const bool own = inside && r >= 1 && r <= TH && c >= 1 && c <= TW;
-      const uint32_t goff = own ? (uint32_t)((((b * H + iy) * W + ix) * C1 + 4 * g) * 2) : 0x80000000u;
-#pragma unroll
-      for (int n = 0; n < NC; ++n) {
-        const float v0 = inside ? fmaxf(acc[n][0] + b1z[n].x, 0.f) : 0.f, v1 = inside ? fmaxf(acc[n][1] + b1z[n].y, 0.f) : 0.f;
-        const float v2 = inside ? fmaxf(acc[n][2] + b1z[n].z, 0.f) : 0.f, v3 = inside ? fmaxf(acc[n][3] + b1z[n].w, 0.f) : 0.f;
-        const u32x2 out = {pack2bf(v0, v1), pack2bf(v2, v3)};
-        // channels n*16 + 4g .. +3 = 16-byte chunk 2n + g/2, second half of it when g is odd
-        if (p < NY) *reinterpret_cast<u32x2*>(y1s + p * 64 + 16 * lds_chunk<32>(2 * n + (g >> 1), p) + 8 * (g & 1)) = out;
-        if constexpr (STORE1) {
-          __builtin_amdgcn_raw_buffer_store_b64(out, y1res, own ? goff + (uint32_t)(n * 32) : 0x80000000u, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b8(relu_bits(out), m1res, own ? (goff + (uint32_t)(n * 32)) >> 3 : 0x80000000u, 0, 0);
-        }
-      }
-    }
-    __syncthreads();
-    // ---- conv2 (32 -> 32) on the 8 x 32 tile: k_conv_mfma<32, 2, 32>'s loop over the LDS tile just written
-    f32x4 acc2[MP][NC];
-#pragma unroll
-    for (int i = 0; i < MP; ++i)
-#pragma unroll
-      for (int n = 0; n < NC; ++n) acc2[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 a2[3][NC];
-    auto load_a2 = [&](int s_, bf16x8 (&dst)[NC]) {
-#pragma unroll
-      for (int n = 0; n < NC; ++n) dst[n] = *reinterpret_cast<const bf16x8*>(wp2 + ((size_t)s_ * C1 + n * 16 + li) * 32 + 8 * g);
+      for (int n = 0; n < NC; ++n) dst[n] = *reinterpret_cast<const bf16x8*>(wp1 + ((size_t)s_ * C1 + n * 16 + li) * 32 + 8 * g);
     };
-    load_a2(0, a2[0]);
-    load_a2(1, a2[1]);
+    load_a1(0, a1[0]);
+    if (KS1 > 1) load_a1(1, a1[1]);
 #pragma unroll
-    for (int s = 0; s < KS2; ++s) {
-      if (s + 2 < KS2) load_a2(s + 2, a2[(s + 2) % 3]);
-      __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < KS1; ++s) {
+      if (s + 2 < KS1) load_a1(s + 2, a1[(s + 2) % 3]);
       const int q0 = s * 32 + 8 * g;
-      int tap = q0 / C1;
-      const int c8 = (q0 % C1) / 8;
+      int tap = q0 / C0;
+      const int c8 = (q0 % C0) / 8;
       const bool valid = tap < 9;
       if (!valid) tap = 0;
       const int dy = tap / 3, dx = tap - 3 * dy;
+      const int px = (r + dy) * XW + c + dx;
+      bf16x8 bv = *reinterpret_cast<const bf16x8*>(xs + px * XB + 16 * lds_chunk<C0>(c8, px));
+      if (!valid) bv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int i = 0; i < MP; ++i) {
-        const int t = wave * MP + i;
-        const int p = (t / TPR + dy) * YW + (t % TPR) * 16 + li + dx;
-        bf16x8 bv = *reinterpret_cast<const bf16x8*>(y1s + p * 64 + 16 * lds_chunk<32>(c8, p));
-        if (!valid) bv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      for (int n = 0; n < NC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[s % 3][n], bv, acc[n], 0, 0, 0);
+    }
+    const int iy = y0 - 1 + r, ix = x0 - 1 + c;
+    const bool inside = p < NY && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const bool own = inside && r >= 1 && r <= TH && c >= 1 && c <= TW;
+    const uint32_t goff = own ? (uint32_t)((((b * H + iy) * W + ix) * C1 + 4 * g) * 2) : 0x80000000u;
 #pragma unroll
-        for (int n = 0; n < NC; ++n) acc2[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[s % 3][n], bv, acc2[i][n], 0, 0, 0);
+    for (int n = 0; n < NC; ++n) {
+      const float v0 = inside ? fmaxf(acc[n][0] + b1z[n].x, 0.f) : 0.f, v1 = inside ? fmaxf(acc[n][1] + b1z[n].y, 0.f) : 0.f;
+      const float v2 = inside ? fmaxf(acc[n][2] + b1z[n].z, 0.f) : 0.f, v3 = inside ? fmaxf(acc[n][3] + b1z[n].w, 0.f) : 0.f;
+      const u32x2 out = {pack2bf(v0, v1), pack2bf(v2, v3)};
+      // channels n*16 + 4g .. +3 = 16-byte chunk 2n + g/2, second half of it when g is odd
+      if (p < NY) *reinterpret_cast<u32x2*>(y1s + p * YB + 16 * lds_chunk<C1>(2 * n + (g >> 1), p) + 8 * (g & 1)) = out;
+      if constexpr (STORE1) {
+        __builtin_amdgcn_raw_buffer_store_b64(out, y1res, own ? goff + (uint32_t)(n * 32) : 0x80000000u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8(relu_bits(out), m1res, own ? (goff + (uint32_t)(n * 32)) >> 3 : 0x80000000u, 0, 0);
       }
     }
+  }
+  __syncthreads();
+  // ---- conv2 (C1 -> C1) on the 8 x 32 tile: k_conv_mfma<C1, NC, 32>'s loop over the LDS tile just written
+  f32x4 acc2[MP][NC];
+#pragma unroll
+  for (int i = 0; i < MP; ++i)
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc2[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 a2[3][NC];
+  auto load_a2 = [&](int s_, bf16x8 (&dst)[NC]) {
+#pragma unroll
+    for (int n = 0; n < NC; ++n) dst[n] = *reinterpret_cast<const bf16x8*>(wp2 + ((size_t)s_ * C1 + n * 16 + li) * 32 + 8 * g);
+  };
+  load_a2(0, a2[0]);
+  load_a2(1, a2[1]);
+#pragma unroll
+  for (int s = 0; s < KS2; ++s) {
+    if (s + 2 < KS2) load_a2(s + 2, a2[(s + 2) % 3]);
+    __builtin_amdgcn_sched_barrier(0);
+    const int q0 = s * 32 + 8 * g;
+    int tap = q0 / C1;
+    const int c8 = (q0 % C1) / 8;
+    const bool valid = tap < 9;
+    if (!valid) tap = 0;
+    const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
     for (int i = 0; i < MP; ++i) {
       const int t = wave * MP + i;
-      const int oy = y0 + t / TPR, ox = x0 + (t % TPR) * 16 + li;
-      const bool inb = oy < H && ox < W;
-      const uint32_t off = inb ? (uint32_t)((((b * H + oy) * W + ox) * C1 + 4 * g) * 2) : 0x80000000u;
+      const int p = (t / TPR + dy) * YW + (t % TPR) * 16 + li + dx;
+      bf16x8 bv = *reinterpret_cast<const bf16x8*>(y1s + p * YB + 16 * lds_chunk<C1>(c8, p));
+      if (!valid) bv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int n = 0; n < NC; ++n) {
-        const u32x2 out = {pack2bf(fmaxf(acc2[i][n][0] + b2z[n].x, 0.f), fmaxf(acc2[i][n][1] + b2z[n].y, 0.f)),
-                           pack2bf(fmaxf(acc2[i][n][2] + b2z[n].z, 0.f), fmaxf(acc2[i][n][3] + b2z[n].w, 0.f))};
-        __builtin_amdgcn_raw_buffer_store_b64(out, y2res, inb ? off + (uint32_t)(n * 32) : 0x80000000u, 0, 0);
-        if constexpr (STORE1) __builtin_amdgcn_raw_buffer_store_b8(relu_bits(out), m2res, inb ? (off + (uint32_t)(n * 32)) >> 3 : 0x80000000u, 0, 0);
-      }
+      for (int n = 0; n < NC; ++n) acc2[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[s % 3][n], bv, acc2[i][n], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MP; ++i) {
+    const int t = wave * MP + i;
+    const int oy = y0 + t / TPR, ox = x0 + (t % TPR) * 16 + li;
+    const bool inb = oy < H && ox < W;
+    const uint32_t off = inb ? (uint32_t)((((b * H + oy) * W + ox) * C1 + 4 * g) * 2) : 0x80000000u;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      const u32x2 out = {pack2bf(fmaxf(acc2[i][n][0] + b2z[n].x, 0.f), fmaxf(acc2[i][n][1] + b2z[n].y, 0.f)),
+                         pack2bf(fmaxf(acc2[i][n][2] + b2z[n].z, 0.f), fmaxf(acc2[i][n][3] + b2z[n].w, 0.f))};
+      __builtin_amdgcn_raw_buffer_store_b64(out, y2res, inb ? off + (uint32_t)(n * 32) : 0x80000000u, 0, 0);
+      if constexpr (STORE1) __builtin_amdgcn_raw_buffer_store_b8(relu_bits(out), m2res, inb ? (off + (uint32_t)(n * 32)) >> 3 : 0x80000000u, 0, 0);
     }
   }
 }
 extern "C" int bx_conv3x3_pair_supported(int C0_p, int C1, int C2, int dtype) {
-  static const int second = getenv("BX_CONV_PAIR2") ? atoi(getenv("BX_CONV_PAIR2")) : 1;       // 0 = stage 1 only
-  return dtype == BX_BF16 && ((C0_p == 8 && C1 == 16 && C2 == 16) || (second && C0_p == 16 && C1 == 32 && C2 == 32));
+  static const int second = getenv("BX_CONV_PAIR2") ? atoi(getenv("BX_CONV_PAIR2")) : 2;       // 0 = stage 1 only, 1 = stages 1-2, 2 = stages 1-3
+  return dtype == BX_BF16 && ((C0_p == 8 && C1 == 16 && C2 == 16) || (second >= 1 && C0_p == 16 && C1 == 32 && C2 == 32) ||
+                              (second >= 2 && C0_p == 32 && C1 == 64 && C2 == 64));
 }
 extern "C" int bx_conv3x3_pair(const void* x, const void* packed1_mfma, const float* bias1, const void* packed2_mfma, const float* bias2,
                                void* y1, void* y2, unsigned char* mask1, unsigned char* mask2, int B, int H, int W, int C0_p, int C1, int C2,
                                int dtype, bxStream stream) {
   BX_REQUIRE(y1 || (!mask1 && !mask2), "bx_conv3x3_pair: the ReLU bit masks are written together with y1 (training passes)");
   BX_REQUIRE(x && packed1_mfma && bias1 && packed2_mfma && bias2 && y2 && B > 0 && H > 0 && W > 0, "bx_conv3x3_pair: bad arguments");
-  BX_REQUIRE(bx_conv3x3_pair_supported(C0_p, C1, C2, dtype), "bx_conv3x3_pair: built for bf16 storage, 8 (padded) -> 16 -> 16 or 16 -> 32 -> 32 channels (got %d -> %d -> %d)",
+  BX_REQUIRE(bx_conv3x3_pair_supported(C0_p, C1, C2, dtype), "bx_conv3x3_pair: built for bf16 storage, 8 (padded) -> 16 -> 16, 16 -> 32 -> 32 or 32 -> 64 -> 64 channels (got %d -> %d -> %d)",
              C0_p, C1, C2);
   BX_REQUIRE((size_t)B * H * W * C1 * 2 < ((size_t)1 << 31), "bx_conv3x3_pair: an activation tensor of 2 GiB or more is not supported");
   const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
   const long long ntiles = (long long)tiles_x * tiles_y * B;
   BX_REQUIRE(ntiles < (1ll << 31), "bx_conv3x3_pair: too many tiles");
   const int gx = ntiles < 2048 ? (int)ntiles : 2048;
-  if (C1 == 32) {
-    const size_t lds2 = (size_t)12 * 36 * 32 + (size_t)10 * 34 * 64;
-    const uint32_t xb2 = (uint32_t)((size_t)B * H * W * 16 * 2);
-    if (y1)
-      hipLaunchKernelGGL((k_conv12b_mfma<true>), dim3((unsigned)ntiles), dim3(256), lds2, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)packed1_mfma, bias1,
-                         (const bf16_t*)packed2_mfma, bias2, (bf16_t*)y1, (bf16_t*)y2, mask1, mask2, H, W, tiles_x, tiles_y, (int)ntiles, xb2);
-    else
-      hipLaunchKernelGGL((k_conv12b_mfma<false>), dim3((unsigned)ntiles), dim3(256), lds2, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)packed1_mfma, bias1,
-                         (const bf16_t*)packed2_mfma, bias2, (bf16_t*)nullptr, (bf16_t*)y2, (unsigned char*)nullptr, (unsigned char*)nullptr, H, W, tiles_x, tiles_y, (int)ntiles, xb2);
-    BX_CHECK_LAUNCH("bx_conv3x3_pair (16 -> 32 -> 32)");
-    return BX_OK;
+  if (C1 >= 32) {
+    const size_t lds2 = (size_t)12 * 36 * C0_p * 2 + (size_t)10 * 34 * C1 * 2;
+    const uint32_t xb2 = (uint32_t)((size_t)B * H * W * C0_p * 2);
+    auto go = [&](auto kern) -> int {
+      static bool attr_done = false;                       // (one static per instantiation of this lambda's call operator)
+      if (lds2 > 64 * 1024 && !attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+          BX_FAIL(BX_EHIP, "bx_conv3x3_pair: cannot reserve %zu bytes of LDS", lds2);
+        attr_done = true;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds2, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)packed1_mfma, bias1,
+                         (const bf16_t*)packed2_mfma, bias2, (bf16_t*)y1, (bf16_t*)y2, y1 ? mask1 : (unsigned char*)nullptr,
+                         y1 ? mask2 : (unsigned char*)nullptr, H, W, tiles_x, tiles_y, (int)ntiles, xb2);
+      BX_CHECK_LAUNCH("bx_conv3x3_pair (stages 2-3)");
+      return BX_OK;
+    };
+    if (C1 == 32) return y1 ? go(k_conv12b_mfma<16, 32, true>) : go(k_conv12b_mfma<16, 32, false>);
+    return y1 ? go(k_conv12b_mfma<32, 64, true>) : go(k_conv12b_mfma<32, 64, false>);
   }
   const size_t lds = (size_t)12 * 36 * 16 + (size_t)10 * 34 * 32;
   const uint32_t xb = (uint32_t)((size_t)B * H * W * 8 * 2);

@@ -467,7 +467,8 @@ class BlockFn(torch.autograd.Function):
                 need_y1 = cfg.keep is not None or (getattr(cfg, "grad_mode", True) and any(ctx.needs_input_grad[:11]))
                 y1 = torch.empty(B, H, W, w1.shape[0], dtype=dt, device=x.device) if need_y1 else None
                 y2 = torch.empty(B, H, W, w2.shape[0], dtype=dt, device=x.device)
-                if need_y1 and MASK_BITS:             # the ReLU decisions of y1 / y2 as bits for the data gradients (1/8 of the bytes)
+                if need_y1 and MASK_BITS and w1.shape[0] <= 32:     # the ReLU decisions of y1 / y2 as bits for the data gradients (1/8 of the
+                    # bytes; stages 1-2: the later stages' data gradients are not bound by those bytes and read the activations)
                     masks = (torch.empty(B, H, W, w1.shape[0] // 4, dtype=torch.uint8, device=x.device),
                              torch.empty(B, H, W, w2.shape[0] // 4, dtype=torch.uint8, device=x.device))
                 with _Timed("fwd"):

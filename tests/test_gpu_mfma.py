@@ -127,7 +127,8 @@ def test_conv_mfma_data_gradient_to_8_padded_channels(co_layer, batch, h, w):
 
 
 @pytest.mark.parametrize("cin,c1,batch,h,w", [(4, 16, 3, 20, 45), (4, 16, 2, 8, 32), (4, 16, 1, 9, 33), (4, 16, 64, 128, 256),
-                                                (16, 32, 3, 20, 45), (16, 32, 2, 8, 32), (16, 32, 1, 9, 33), (16, 32, 64, 64, 128)])
+                                                (16, 32, 3, 20, 45), (16, 32, 2, 8, 32), (16, 32, 1, 9, 33), (16, 32, 64, 64, 128),
+                                                (32, 64, 3, 20, 45), (32, 64, 2, 8, 32), (32, 64, 1, 9, 33), (32, 64, 64, 32, 64)])
 def test_conv_pair_is_bit_identical_to_two_launches(cin, c1, batch, h, w):
     """stage 1's conv1 + conv2 in one launch (conv1's tile recomputed on the halo and kept in LDS): the same MFMA sequence on the same
     operands as the two separate launches, so y1 and y2 must be EQUAL bit for bit -- with the conv1 output written out (training) and
