@@ -120,7 +120,8 @@ def timeline(out_dir, steps, delim="k_adamw"):
             acc[j][0] += r[2] - r[1]
             acc[j][1] += r[1] - t0
             acc[j][2] += (rows[lo + j + 1][1] - r[2]) if j + 1 < per else 0.0
-    print(f"# launch timeline of one training step, averaged over {used} hipGraph-replayed steps: {per} launches")
+    what = "training step" if delim.startswith("k_adamw") else f"replayed batch (closed by {delim}*)"
+    print(f"# launch timeline of one {what}, averaged over {used} hipGraph replays: {per} launches")
     print(f"{'#':>3s} {'start us':>9s} {'dur us':>8s} {'gap us':>7s} {'grid':>12s} {'wg':>5s}  kernel")
     lo = ends[-1] - per + 1
     for j in range(per):
