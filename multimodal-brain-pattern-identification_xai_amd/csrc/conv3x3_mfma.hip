@@ -1251,7 +1251,8 @@ extern "C" int bx_conv3x3_pair(const void* x, const void* packed1_mfma, const fl
   const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
   const long long ntiles = (long long)tiles_x * tiles_y * B;
   BX_REQUIRE(ntiles < (1ll << 31), "bx_conv3x3_pair: too many tiles");
-  const int gx = ntiles < 2048 ? (int)ntiles : 2048;
+  static const int gx_cap = getenv("BX_CONV12_GX") ? atoi(getenv("BX_CONV12_GX")) : 2048;      // sweep knob (workgroups of the stage-1 pair kernel)
+  const int gx = ntiles < gx_cap ? (int)ntiles : gx_cap;
   if (C1 >= 32) {
     const size_t lds2 = (size_t)12 * 36 * C0_p * 2 + (size_t)10 * 34 * C1 * 2;
     const uint32_t xb2 = (uint32_t)((size_t)B * H * W * C0_p * 2);
