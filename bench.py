@@ -29,7 +29,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense peaks (MI355X_MICROARCH.md); fp32 storage runs on the bf16 pipe, 6 products per FLOP pair
 B, CIN, H, W, CHANS, RAW_LEN, T = 64, 4, 128, 256, 19, 10000, 2000
 SWEEP_SAMPLES = 10000          # configs[3]
 # per Grad-CAM sample (eval, BN folded) forward 7.85 M elements = 15.7 MB bf16 (31.4 MB fp32), 1.90 GFLOP; plus the six
@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (stackers, pre-processing, IG, EEGNetAttentionDeep)")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying captured hipGraphs")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-storage legs (training step and Grad-CAM sweep of the parity-grade path)")
     return ap.parse_args()
 
 
@@ -124,6 +125,28 @@ def launch_ranks(args):
     sys.exit(0)
 
 
+def count_gpus_without_hip():
+    """GPUs of this node from the KFD topology in sysfs (nodes with simd_count > 0, minus what ROCR_/HIP_VISIBLE_DEVICES hides):
+    the launcher parent must not initialise the GPU before it starts the rank processes, and torch.cuda.device_count() only
+    avoids that when its amdsmi path is taken.  None when sysfs has no topology (then the ranks themselves report a shortage)."""
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for path in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def timed(fn, reps, sync):
     sync()
     t0 = time.perf_counter()
@@ -136,8 +159,8 @@ def timed(fn, reps, sync):
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("BX_BENCH_FORCE_LAUNCH") == "1"):
-        have = torch.cuda.device_count()                 # counting devices does not initialise the GPU on this stack
-        if have < args.gpus:
+        have = count_gpus_without_hip()                  # sysfs only: this parent never touches HIP
+        if have is not None and have < args.gpus:
             sys.exit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
         launch_ranks(args)
     # stdout carries exactly ONE JSON line: library banners (RCCL prints its version to stdout at init) and any
@@ -213,7 +236,8 @@ def main():
     crit = brainxai.KLDivLoss()
     # the product's own step object: first call eager, second captured (one hipGraph; data-parallel: two, with the first
     # gradient bucket's all-reduce between them), later calls replayed.  The benchmark batch IS the graph's static input.
-    stepper = brainxai.GraphedTrainStep(model, opt, crit, ddp=ddp, adopt_inputs=True)
+    # strict: a failed capture raises (a silently eager benchmark would report a ~25 % slower number with rc 0)
+    stepper = brainxai.GraphedTrainStep(model, opt, crit, ddp=ddp, adopt_inputs=True, strict=True)
     if args.no_graph:
         stepper.enabled = False
     inputs = [eeg, spec]
@@ -224,6 +248,8 @@ def main():
     for _ in range(max(args.warmup, 3)):               # >= 3 so that capture and the first replay are outside the timed region
         loss, _ = step()
     graphed = bool(stepper._graphs)
+    if not graphed and not args.no_graph and os.environ.get("BX_GRAPH_LOOPS", "1") != "0":
+        sys.exit("bench.py: the training step was not captured into a hipGraph (GraphedTrainStep fell back to eager launches)")
     # ---- timed region: exactly K steps between barrier + synchronize on both sides
     sync()
     if world > 1:
@@ -251,13 +277,35 @@ def main():
     extra["end_to_end_note"] = ("raw EEG [64,10000,19] -> GPU stacker, raw spectrogram values [64,320,400] -> GPU region stacker, then the "
                                 "training step; one stream, nothing overlapped")
 
+    # ---- the parity-grade path beside the headline: fp32 STORAGE (logits / loss / Grad-CAM maps within 1e-3 of the fp32 oracle,
+    # gradients within 1e-3 of the decision-matched fp64 twin at this very configuration: tests/test_gpu_bench_config.py), its
+    # convolutions on the matrix cores with split-bf16 operands (csrc/conv3x3_split.hip).  Same batch, same step object; N=1 only.
+    m32 = None
+    if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_fp32:
+        torch.manual_seed(42)
+        m32 = brainxai.build_multimodal(CHANS, T, CIN, dropout=0.5, compute_dtype=torch.float32).to(dev).train()
+        o32 = brainxai.FlatAdamW(m32.parameters(), lr=1e-3)
+        st32 = brainxai.GraphedTrainStep(m32, o32, crit, adopt_inputs=True, strict=True)
+        for _ in range(3):
+            st32(inputs, labels)
+        n32 = min(args.steps, 30)
+        t32 = timed(lambda: st32(inputs, labels), n32, sync)
+        extra["fp32_samples_per_sec"] = round(B * n32 / t32, 1)
+        extra["fp32"] = {"samples_per_sec": round(B * n32 / t32, 1), "ms_per_step": round(t32 / n32 * 1e3, 3), "steps": n32, "hip_graph": bool(st32._graphs),
+                         "arithmetic": "fp32 storage; 3x3 convolutions as six bf16 MFMA products per fp32 product (operands split h + m + l), "
+                                       "fp32-grade results; everything else fp32 VALU",
+                         "step_roofline": {"hbm_frac": round(104.5e6 * B / (t32 / n32) / 1e9 / HBM_PEAK_GBS, 5),
+                                           "mfma_frac": round(5.71e9 * B / (t32 / n32) / 1e12 / (MFMA_PEAK_TFLOPS["bf16"] / 6), 5)}}
+        st32.release(); o32.close()
+        del st32, o32
+
     # ---- per-kernel HIP-event timing of the conv family: the same step launched eagerly right after the timed
     # region (events cannot bracket kernels inside a replayed graph), same buffers, same data
     prof = []
     was_enabled, stepper.enabled = stepper.enabled, False
     step()
-    ops.CONV_PROFILE = []                 # one discarded step in profiling mode: it launches the per-layer kernels the fused launches
-    step()                                # of the timed region replace, which would otherwise run cold in the first measured step
+    ops.CONV_PROFILE = []                 # one discarded step in profiling mode
+    step()
     ops.CONV_PROFILE = prof
     prof_steps = min(args.steps, 10)
     # Events bracket a launch on the GPU's clock: if the host is the slower side (eager Python between forward launches) the GPU
@@ -274,48 +322,81 @@ def main():
     ops.CONV_PROFILE = None
     stepper.enabled = was_enabled
 
-    # ---- dominant kernel family (conv3x3 forward / data gradient / weight gradient): HIP-event durations around each launch
-    kinds = {}
-    for kind, ev0, ev1 in prof:
-        kinds.setdefault(kind, []).append(ev0.elapsed_time(ev1) * 1e-3)
+    # ---- dominant kernel family (conv3x3 forward / data gradient / weight gradient): HIP-event durations around each launch of
+    # the SAME launches the timed region replays (the fused ones included: conv1 + conv2 pairs of stages 1-3, conv3 with the
+    # pooled epilogue -- the library records the event pair around that kernel itself, bx_profile_next_conv3)
+    kinds, groups = {}, {}
     dbytes = 2 if args.dtype == "bf16" else 4
+    mfma_per_product = 1 if args.dtype == "bf16" else 6      # fp32 storage: six bf16 MFMAs per product (csrc/conv3x3_split.hip)
+    for kind, ev0, ev1, meta in prof:
+        dt_s = ev0.elapsed_time(ev1) * 1e-3
+        kinds.setdefault(kind, []).append(dt_s)
+        form, mb, mh, mw, ci, co = meta
+        px = mb * mh * mw
+        if form == "pair":                                   # two layers in one launch: both layers' algorithmic bytes and FLOPs
+            c1, c2 = co
+            cin_true = CIN if ci == 8 and mh == H else ci
+            by = px * ((cin_true + c1) + (c1 + c2)) * dbytes
+            fl = 2.0 * 9 * px * (cin_true * c1 + c1 * c2)
+            name, layers = f"{kind} pair {cin_true}->{c1}->{c2} @{mh}x{mw}", 2
+        else:
+            cin_true = CIN if (kind != "dgrad" and ci == 8 and mh == H) else ci
+            by = px * (cin_true + co) * dbytes + (px * co * dbytes if kind == "dgrad" else 0) + (px // 4 * co * dbytes if form == "conv3+pool" else 0)
+            fl = 2.0 * 9 * px * cin_true * co
+            name, layers = f"{kind} {'conv3+pool ' if form == 'conv3+pool' else ''}{cin_true}->{co} @{mh}x{mw}", 1
+        g_ = groups.setdefault(name, [0.0, 0, by, fl, layers])
+        g_[0] += dt_s; g_[1] += 1
     work = conv_work(B, dbytes)
     conv_time = sum(sum(v) for v in kinds.values()) / prof_steps            # seconds per step in conv kernels
     conv_flops = sum(w_[0] for w_ in work.values())
     conv_bytes = sum(w_[1] for w_ in work.values())
-    n_launch = sum(len(v) for v in kinds.values()) / max(prof_steps, 1)
+    n_launch = sum(w_[2] for w_ in work.values())                           # layer launches of the family (a pair launch runs two)
+    n_kernels = sum(len(v) for v in kinds.values()) / max(prof_steps, 1)
     roofline = None
     if conv_time > 0:
         ach_gbs = conv_bytes / conv_time / 1e9
         ach_tf = conv_flops / conv_time / 1e12
         ai = conv_flops / conv_bytes
-        ridge = MFMA_PEAK_TFLOPS[args.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
+        peak_tf = MFMA_PEAK_TFLOPS["bf16"] / mfma_per_product               # fp32-storage FLOPs run as 6 bf16 MFMA products each
+        ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
         traffic, source = pmc_conv_traffic(args.dtype)
-        # the family's arithmetic intensity (~150 FLOP/B in bf16) is below the ridge (312 FLOP/B): HBM is the binding roof
+        # bf16: the family's arithmetic intensity (~150 FLOP/B) is below the ridge (312 FLOP/B): HBM is the binding roof.
+        # fp32 storage: twice the bytes, six MFMA products per FLOP pair -> intensity 77 against a ridge of 52: the matrix cores are
         bound = "hbm" if ai < ridge else "mfma"
-        roofline = {"bound": bound, "kernel": "conv3x3 fwd+dgrad+wgrad (%d launches/step)" % round(n_launch),
-                    "achieved": round(ach_gbs if bound == "hbm" else ach_tf, 2), "peak": HBM_PEAK_GBS if bound == "hbm" else MFMA_PEAK_TFLOPS[args.dtype],
+        dom_name, dom = max(groups.items(), key=lambda kv: kv[1][0])
+        dom_t = dom[0] / dom[1]
+        roofline = {"bound": bound, "kernel": "conv3x3 fwd+dgrad+wgrad (%d layer launches in %d kernel launches per step)" % (n_launch, round(n_kernels)),
+                    "achieved": round(ach_gbs if bound == "hbm" else ach_tf, 2), "peak": HBM_PEAK_GBS if bound == "hbm" else round(peak_tf, 1),
                     "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
-                    "frac": round((ach_gbs / HBM_PEAK_GBS) if bound == "hbm" else (ach_tf / MFMA_PEAK_TFLOPS[args.dtype]), 5),
+                    "frac": round((ach_gbs / HBM_PEAK_GBS) if bound == "hbm" else (ach_tf / peak_tf), 5),
                     "traffic": traffic, "traffic_source": source,
-                    "traffic_unit": "HBM bytes per launch, family average (PMC FETCH_SIZE x2 + WRITE_SIZE; from the committed summary named in traffic_source, not measured in this run)",
+                    "traffic_unit": "HBM bytes per layer launch, family average (PMC FETCH_SIZE x2 + WRITE_SIZE; from the committed summary named in traffic_source, not measured in this run)",
                     "algorithmic_bytes_per_launch": round(conv_bytes / max(n_launch, 1)),
                     "arithmetic_intensity_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
                     "avg_launch_us": round(conv_time / max(n_launch, 1) * 1e6, 2),
                     "share_of_step": round(conv_time / (elapsed / args.steps), 3),
-                    "timing": "HIP events around each launch, %d eagerly launched steps right after the timed region; measured layer by layer: the "
-                              "timed region's fused launches (conv3 + pool + statistics, conv1 + conv2 of stages 1-2) run as their separate "
-                              "convolutions here" % prof_steps}
-        extra["roofline_mfma"] = {"achieved": round(ach_tf, 2), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                                  "frac": round(ach_tf / MFMA_PEAK_TFLOPS[args.dtype], 5)}
+                    "dominant_kernel": {"name": dom_name, "launches_per_step": round(dom[1] / prof_steps, 1), "avg_us": round(dom_t * 1e6, 2),
+                                        "share_of_step": round(dom[0] / prof_steps / (elapsed / args.steps), 4),
+                                        "algorithmic_bytes": round(dom[2]), "hbm_frac": round(dom[2] / dom_t / 1e9 / HBM_PEAK_GBS, 4),
+                                        "mfma_frac": round(dom[3] / dom_t / 1e12 / peak_tf, 4)},
+                    "timing": "HIP events around every convolution launch of %d eagerly launched steps right after the timed region -- the "
+                              "launches the timed region replays, fused ones included (conv1 + conv2 pairs, conv3 with the pooled epilogue "
+                              "bracketed inside the library call)" % prof_steps}
+        extra["roofline_mfma"] = {"achieved": round(ach_tf, 2), "peak": round(peak_tf, 1), "unit": "TFLOP/s",
+                                  "frac": round(ach_tf / peak_tf, 5),
+                                  "note": None if mfma_per_product == 1 else "fp32-storage FLOPs; each runs as 6 bf16 MFMA products, peak = 2500 / 6"}
         extra["conv_ms_per_step"] = {k_: round(sum(v) / prof_steps * 1e3, 3) for k_, v in kinds.items()}
         extra["conv_roofline_by_kind"] = {k_: {"hbm_frac": round(work[k_][1] / (sum(v) / prof_steps) / 1e9 / HBM_PEAK_GBS, 4),
-                                               "mfma_frac": round(work[k_][0] / (sum(v) / prof_steps) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 4)}
+                                               "mfma_frac": round(work[k_][0] / (sum(v) / prof_steps) / 1e12 / peak_tf, 4)}
                                           for k_, v in kinds.items()}
+        top = sorted(groups.items(), key=lambda kv: -kv[1][0])[:6]
+        extra["conv_top_kernels"] = [{"name": n_, "us": round(g_[0] / g_[1] * 1e6, 2), "per_step": round(g_[1] / prof_steps, 1),
+                                      "hbm_frac": round(g_[2] / (g_[0] / g_[1]) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "mfma_frac": round(g_[3] / (g_[0] / g_[1]) / 1e12 / peak_tf, 4)} for n_, g_ in top]
     # whole-step algorithmic roofline (5.71 GFLOP and 52.2 MB bf16 / 104.5 MB fp32 per sample)
     per_sample_bytes = 52.2e6 if args.dtype == "bf16" else 104.5e6
     extra["step_roofline"] = {"hbm_frac": round(per_sample_bytes * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
-                              "mfma_frac": round(5.71e9 * B / (elapsed / args.steps) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 5)}
+                              "mfma_frac": round(5.71e9 * B / (elapsed / args.steps) / 1e12 / (MFMA_PEAK_TFLOPS["bf16"] / mfma_per_product), 5)}
 
     # ---- configs[3]: Grad-CAM sweep over 10 000 samples (this rank's contiguous shard of them), eval mode, target block5,
     # all 6 classes, maps upsampled to 128x256: 156 batches of 64 + one of 16 per 10 000 (the ragged tail has its own capture)
@@ -352,9 +433,22 @@ def main():
                    "roofline": {"bound": "hbm", "achieved": round(sps / world * GRADCAM_BYTES[args.dtype] / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(sps / world * GRADCAM_BYTES[args.dtype] / 1e9 / HBM_PEAK_GBS, 5),
                                 "algorithmic_bytes_per_sample": GRADCAM_BYTES[args.dtype],
-                                "mfma_frac": round(sps / world * GRADCAM_FLOPS / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 5),
+                                "mfma_frac": round(sps / world * GRADCAM_FLOPS / 1e12 / (MFMA_PEAK_TFLOPS["bf16"] / mfma_per_product), 5),
                                 "note": "per GPU; SURVEY 8(d): forward 15.7 MB (bf16) + 1.90 GFLOP per sample, + the 6 upsampled fp32 maps written"},
                    "map_checksum": float(checksum)}
+        if m32 is not None:                                 # the same sweep through the fp32-storage path (first 2 048 samples)
+            m32.eval()
+            n32s = min(n_mine, 2048) // B * B
+            sweep32 = brainxai.GradCamSweep(m32, sweep_eeg[:B], sweep_spec[:B], class_idx="all")
+
+            def run_sweep32():
+                for b0 in range(0, n32s, B):
+                    sweep32(sweep_eeg[b0:b0 + B], sweep_spec[b0:b0 + B])
+            run_sweep32()
+            gradcam["fp32_samples_per_sec"] = round(n32s / timed(run_sweep32, 1, sync), 1)
+            gradcam["fp32_maps_per_sec"] = round(6 * gradcam["fp32_samples_per_sec"], 1)
+            del sweep32
+            m32.train()
         del sweep, sweep_spec, sweep_eeg
         if not args.no_extras:
             # configs[4] run literally: integrated gradients, 50 steps x B=64 (zero baselines, arg-max target), the 64 samples
@@ -409,12 +503,31 @@ def main():
                "sample": f"{args.cpu_steps} training steps of the same B={B} batch after 1 warm-up step (oracle/ref_torch.py, fp32, "
                          f"{torch.get_num_threads()} torch threads; host shows {os.cpu_count()} CPUs, share is 16)"}
         if gradcam is not None:
+            # the oracle takes the product's (trained) weights, so that its maps are also the yardstick for the maps the
+            # benchmarked sweep produces: error of the bf16 sweep (and of the fp32-storage one) on the scale of the pre-ReLU maps
+            ref.load_state_dict(model.state_dict())
             ref.eval()
             t0 = time.perf_counter()
-            for i in range(3):
-                O.grad_cam(ref, ce[16 * i:16 * i + 16], cs[16 * i:16 * i + 16], class_idx="all")
+            cams = [O.grad_cam(ref, ce[16 * i:16 * i + 16], cs[16 * i:16 * i + 16], class_idx="all") for i in range(3)]
             cpu["gradcam_maps_per_sec"] = round(3 * 16 * 6 / (time.perf_counter() - t0), 2)
             cpu["gradcam_sample"] = "3 batches of 16 samples, forward hook + one autograd pass per class"
+            raw0 = O.grad_cam(ref, ce[:16], cs[:16], class_idx="all", relu=False)
+            scale0 = float(raw0.abs().max())
+            model.eval()
+            sw16 = brainxai.GradCamSweep(model, eeg[:16], spec[:16], class_idx="all")
+            got = sw16(eeg[:16], spec[:16]).float().cpu()
+            gradcam["max_rel_err_vs_fp32_oracle"] = float((got.double() - cams[0].double()).abs().max()) / scale0
+            gradcam["max_rel_err_note"] = ("maps of the benchmarked %s sweep (GradCamSweep, 16 samples x 6 classes, trained weights) against the CPU fp32 "
+                                           "oracle's, relative to the largest pre-ReLU map value" % args.dtype)
+            del sw16
+            model.train()
+            if m32 is not None:
+                m32.load_state_dict(model.state_dict())
+                m32.eval()
+                sw16 = brainxai.GradCamSweep(m32, eeg[:16], spec[:16], class_idx="all")
+                got = sw16(eeg[:16], spec[:16]).float().cpu()
+                gradcam["fp32_max_rel_err_vs_fp32_oracle"] = float((got.double() - cams[0].double()).abs().max()) / scale0
+                del sw16
         t0 = time.perf_counter()
         O.stack_eeg_batch(raw[:16].cpu().numpy())
         cpu["stacker_samples_per_sec"] = round(16 / (time.perf_counter() - t0), 2)                 # one host core, numpy/scipy (dataset.py:73-104)
@@ -469,12 +582,10 @@ def main():
         line.update(extra)
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():
-        # every rank is done and the result line is out: leave without tearing the communicator down (a destroy_process_group with
-        # captured graphs alive aborted once in the GPU test suite; an abort here would turn a finished measurement into a failed run)
+        # every rank is done and the result line is out.  Teardown through the product's own cleanup(): it releases the graphed
+        # step's captured graphs (they contain the RCCL collectives) and any reduction handle before the communicator goes
         dist.barrier()
-        torch.cuda.synchronize()
-        sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
+        brainxai.cleanup()
 
 
 if __name__ == "__main__":

@@ -62,12 +62,20 @@ int bx_conv3x3_pack(const float* w_oihw, float* packed_f32, void* packed_mfma, i
                     int I_p, int O_p, int transpose_flip, bxStream stream);
 /* bytes of the MFMA operand for padded dims (0 when the MFMA path does not cover them). */
 size_t bx_conv3x3_packed_mfma_bytes(int I_p, int O_p);
+/* fp32 STORAGE on the bf16 matrix cores (csrc/conv3x3_split.hip): every fp32 operand is split x = h + m + l (three bf16, 24
+ * significand bits) and a product runs as the six MFMAs whose partial products reach 2^-18 of the largest, into the fp32
+ * accumulator -- fp32-grade results (see the file's header).  bx_conv3x3_pack_split writes the weight operand in that layout
+ * (images h, m, l; bx_conv3x3_packed_split_bytes, 0 when the path does not cover the padded dims); hand it to bx_conv3x3 /
+ * bx_conv3x3_carry as `packed_mfma` with dtype BX_F32.  Same torch ops as bx_conv3x3_pack (M:49-51,64-66). */
+size_t bx_conv3x3_packed_split_bytes(int I_p, int O_p);
+int bx_conv3x3_pack_split(const float* w_oihw, void* packed_split, int Cout, int Cin, int I_p, int O_p, int transpose_flip,
+                          bxStream stream);
 /* All MFMA weight operands of a model in ONE launch.  `jobs_device` is a device array of njobs descriptors sorted by
  * block_begin (job j owns launch blocks [block_begin_j, block_begin_{j+1})); total_blocks = end of the last job. */
 typedef struct {
   const void* w_oihw;      /* fp32 [Cout,Cin,3,3] */
-  void* packed_mfma;       /* bx_conv3x3_packed_mfma_bytes(I_p, O_p) bytes */
-  int Cout, Cin, I_p, O_p, transpose_flip, block_begin;
+  void* packed_mfma;       /* bx_conv3x3_packed_mfma_bytes(I_p, O_p) bytes (bx_conv3x3_packed_split_bytes with the split bit) */
+  int Cout, Cin, I_p, O_p, transpose_flip, block_begin;   /* transpose_flip: bit 0 = data-gradient operand, bit 1 = split (fp32-storage) layout */
 } bxPackJob;
 int bx_conv3x3_pack_many(const bxPackJob* jobs_device, int njobs, int total_blocks, bxStream stream);
 /* The same launch also converts the batch: src fp32 NCHW [B,C,H,W] -> dst bf16 NHWC [B,H,W,Cp] (what bx_nchw_to_nhwc does;
@@ -96,7 +104,9 @@ int bx_conv3x3_pair(const void* x, const void* packed1_mfma, const float* bias1,
  *   relu_mask_src (dtype [B,H,W,Co], may be NULL): y *= (relu_mask_src > 0)  -- the ReLU backward
  *     of the layer that produced the tensor whose gradient this call computes;
  *   addend (dtype [B,H,W,Co], may be NULL) is added last (skip-path gradient).
- * Forward uses (bias, RELU); data-gradient uses the transpose_flip pack + relu_mask_src/addend. */
+ * Forward uses (bias, RELU); data-gradient uses the transpose_flip pack + relu_mask_src/addend.
+ * `packed_mfma` is the MFMA operand in the layout of `dtype`: bx_conv3x3_pack's for BX_BF16, bx_conv3x3_pack_split's for BX_F32
+ * (algo AUTO takes the MFMA path whenever it is given and the shape is covered, else the direct kernel on packed_f32). */
 int bx_conv3x3(const void* x, const float* packed_f32, const void* packed_mfma, const float* bias,
                const void* relu_mask_src, const void* addend, void* y,
                int B, int H, int W, int Ci, int Co, int dtype, int flags, int algo, bxStream stream);
@@ -127,6 +137,11 @@ int bx_conv3x3_wgrad_finish(bxWgradPending* pending, bxStream stream);
 int bx_conv3x3_carry(const void* x, const float* packed_f32, const void* packed_mfma, const float* bias,
                      const void* relu_mask_src, const void* addend, void* y, int B, int H, int W, int Ci, int Co,
                      int dtype, int flags, int algo, bxWgradPending* pending, bxStream stream);
+
+/* Measurement hook: the next bx_block_conv3_tail_fwd call of this host thread records the two hipEvent_t (created by the caller,
+ * timing enabled) immediately before and after its convolution kernel on the call's stream -- bench.py times the fused conv3 +
+ * pool launch of the training step with it (events cannot bracket one kernel of a multi-launch call from outside).  One-shot. */
+int bx_profile_next_conv3(void* ev_start, void* ev_stop);
 
 /* ---- Block tail: 2x2 pool -> BatchNorm2d -> Dropout -> + conv1x1(bilinear(x))  (M:67-76) ------ */
 typedef struct {
@@ -416,6 +431,10 @@ size_t bx_adamw_partials(size_t n);
 size_t bx_adamw_step_words(size_t n);
 int bx_adamw_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, float* step_count,
                       float* sumsq_partials, float* l2_value, bxStream stream);
+/* dst_device[0..7] = values_host[0..7], ordered on `stream`.  The eight values travel as kernel arguments (copied when the call
+ * returns), so the host buffer needs no lifetime beyond the call -- how FlatAdamW refreshes `hyper` when a torch LR scheduler
+ * changed param_groups (DDP:98-101), also between replays of a captured step. */
+int bx_store_f32x8(float* dst_device, const float* values_host, bxStream stream);
 /* sum of squares of a flat fp32 arena -> out[1] (DDP loop's manual L2 term, DDP:52-53). */
 int bx_sumsq(const float* x, size_t n, float* out, bxStream stream);
 /* LIME's batched inference (XAI_Multimodality.py:1567-1574): uint8 images [N,H,W,C] -> scale * value in the internal

@@ -74,6 +74,8 @@ SIGNATURES = {
     "bx_nhwc_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "bx_conv3x3_pack": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "bx_conv3x3_packed_mfma_bytes": (sz, [i32, i32]),
+    "bx_conv3x3_packed_split_bytes": (sz, [i32, i32]),
+    "bx_conv3x3_pack_split": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "bx_conv3x3_pack_many": (i32, [vp, i32, i32, vp]),
     "bx_conv3x3_pack_many_layout": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "bx_conv3x3_pair_supported": (i32, [i32, i32, i32, i32]),
@@ -136,6 +138,8 @@ SIGNATURES = {
     "bx_adamw_partials": (sz, [sz]),
     "bx_adamw_step_words": (sz, [sz]),
     "bx_adamw_step_dev": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
+    "bx_store_f32x8": (i32, [vp, vp, vp]),
+    "bx_profile_next_conv3": (i32, [vp, vp]),
     "bx_sumsq": (i32, [vp, sz, vp, vp]),
     "bx_u8_to_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),
     "bx_softmax_rows": (i32, [vp, vp, i32, i32, vp]),

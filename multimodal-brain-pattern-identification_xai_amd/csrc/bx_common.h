@@ -15,6 +15,10 @@ void bx_set_error(const char* fmt, ...);
   if (e_ != hipSuccess) BX_FAIL(BX_EHIP, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)
 #define BX_DTYPE_OK(dt) do { if ((dt) != BX_F32 && (dt) != BX_BF16) BX_FAIL(BX_EDTYPE, "unsupported dtype %d", (dt)); } while (0)
 
+// measurement hook (bx_profile_next_conv3): event pair the next pooled-epilogue convolution launch of this thread records around
+// its kernel, so that bench.py can time the FUSED launch the training step really runs (HIP events cannot reach inside a C call)
+extern thread_local hipEvent_t g_bx_prof_ev[2];
+
 static inline int bx_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t bx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline size_t bx_esize(int dtype) { return dtype == BX_BF16 ? 2 : 4; }

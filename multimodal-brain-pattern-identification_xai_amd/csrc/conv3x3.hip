@@ -15,6 +15,16 @@ int bx_wgrad_mfma_supported(int Ci_p, int Co, int dtype);
 int bx_wgrad_mfma_launch(const void* x, const void* dz, float* dw, float* db, int B, int H, int W, int Cin, int Ci_p,
                          int Co, void* ws, size_t ws_bytes, bxWgradPending* pending, hipStream_t s);
 int bx_wgrad_mfma_finish(bxWgradPending* pending, hipStream_t s);
+// implemented in conv3x3_split.hip: fp32 storage on the bf16 matrix cores (operands split hi + lo, three MFMAs per product)
+int bx_conv3x3_split_supported(int Ci, int Co);
+int bx_conv3x3_split_launch(const void* x, const void* packed_split, const float* bias, const void* relu_mask_src, const void* addend, void* y,
+                            int B, int H, int W, int Ci, int Co, int flags, hipStream_t s);
+int bx_wgrad_split_supported(int Ci_p, int Co);
+size_t bx_wgrad_split_workspace(int B, int H, int W, int Ci_p, int Co);
+int bx_wgrad_split_launch(const void* x, const void* dz, float* dw, float* db, int B, int H, int W, int Cin, int Ci_p, int Co, void* ws,
+                          size_t ws_bytes, bxWgradPending* pending, hipStream_t s);
+static inline int conv_mfma_ok(int Ci, int Co, int dtype) { return dtype == BX_BF16 ? bx_conv3x3_mfma_supported(Ci, Co, dtype) : bx_conv3x3_split_supported(Ci, Co); }
+static inline int wgrad_mfma_ok(int Ci_p, int Co, int dtype) { return dtype == BX_BF16 ? bx_wgrad_mfma_supported(Ci_p, Co, dtype) : bx_wgrad_split_supported(Ci_p, Co); }
 
 // ------------------------------------------------------------------------------------------------
 // Packing: fp32 [9][I_p][O_p]
@@ -140,10 +150,17 @@ static int conv3x3_impl(const void* x, const float* packed_f32, const void* pack
   BX_REQUIRE(Ci % 8 == 0 && Co % 8 == 0, "bx_conv3x3: Ci (%d) and Co (%d) must be multiples of 8 (pad the tensors)", Ci, Co);
   hipStream_t s = (hipStream_t)stream;
   if (algo == BX_ALGO_AUTO)
-    algo = (packed_mfma && bx_conv3x3_mfma_supported(Ci, Co, dtype)) ? BX_ALGO_MFMA : BX_ALGO_DIRECT;
+    algo = (packed_mfma && conv_mfma_ok(Ci, Co, dtype)) ? BX_ALGO_MFMA : BX_ALGO_DIRECT;
   if (algo == BX_ALGO_MFMA) {
-    if (!packed_mfma || !bx_conv3x3_mfma_supported(Ci, Co, dtype))
-      BX_FAIL(BX_EUNSUPPORTED, "bx_conv3x3: MFMA path needs bf16 storage, packed_mfma and Ci%%8==0, Co%%16==0 (Ci=%d Co=%d dtype=%d)", Ci, Co, dtype);
+    if (!packed_mfma || !conv_mfma_ok(Ci, Co, dtype))
+      BX_FAIL(BX_EUNSUPPORTED, "bx_conv3x3: MFMA path needs packed_mfma in the layout of `dtype` and Ci%%8==0, Co%%16==0 (Ci=%d Co=%d dtype=%d)", Ci, Co, dtype);
+    if (dtype == BX_F32) {                                       // fp32 storage: split-bf16 operands (conv3x3_split.hip); cannot carry a reduce
+      if (carry && carry->valid) {
+        const int rc = bx_wgrad_mfma_finish(carry, s);
+        if (rc) return rc;
+      }
+      return bx_conv3x3_split_launch(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, flags, s);
+    }
     return bx_conv3x3_mfma_launch(x, packed_mfma, bias, relu_mask_src, addend, y, B, H, W, Ci, Co, flags, s, carry);
   }
   BX_REQUIRE(!(flags & BX_EPI_MASK_BITS), "bx_conv3x3: BX_EPI_MASK_BITS needs the MFMA path");
@@ -275,8 +292,8 @@ static int wgrad_direct_chunks(int B, int H, int W, int Ci_p, int Co, int* seg, 
 }
 
 extern "C" size_t bx_conv3x3_wgrad_workspace(int B, int H, int W, int Ci_p, int Co, int dtype, int algo) {
-  if (algo == BX_ALGO_AUTO) algo = bx_wgrad_mfma_supported(Ci_p, Co, dtype) ? BX_ALGO_MFMA : BX_ALGO_DIRECT;
-  if (algo == BX_ALGO_MFMA) return bx_wgrad_mfma_workspace(B, H, W, Ci_p, Co);
+  if (algo == BX_ALGO_AUTO) algo = wgrad_mfma_ok(Ci_p, Co, dtype) ? BX_ALGO_MFMA : BX_ALGO_DIRECT;
+  if (algo == BX_ALGO_MFMA) return dtype == BX_F32 ? bx_wgrad_split_workspace(B, H, W, Ci_p, Co) : bx_wgrad_mfma_workspace(B, H, W, Ci_p, Co);
   int seg, nseg_x, ipc; long long nitems;
   const int nchunk = wgrad_direct_chunks(B, H, W, Ci_p, Co, &seg, &nseg_x, &nitems, &ipc);
   return (size_t)nchunk * ((size_t)9 * Ci_p * Co + Co) * sizeof(float);
@@ -305,11 +322,12 @@ static int wgrad_impl(const void* x, const void* dz, float* dw_oihw, float* dbia
   BX_REQUIRE(x && dz && dw_oihw && B > 0 && H > 0 && W > 0, "bx_conv3x3_wgrad: bad arguments");
   BX_REQUIRE(Ci_p % 8 == 0 && Co % 16 == 0 && Cin <= Ci_p, "bx_conv3x3_wgrad: need Ci_p%%8==0, Co%%16==0 (Ci_p=%d Co=%d)", Ci_p, Co);
   hipStream_t s = (hipStream_t)stream;
-  if (algo == BX_ALGO_AUTO) algo = bx_wgrad_mfma_supported(Ci_p, Co, dtype) ? BX_ALGO_MFMA : BX_ALGO_DIRECT;
+  if (algo == BX_ALGO_AUTO) algo = wgrad_mfma_ok(Ci_p, Co, dtype) ? BX_ALGO_MFMA : BX_ALGO_DIRECT;
   const size_t need = bx_conv3x3_wgrad_workspace(B, H, W, Ci_p, Co, dtype, algo);
   if (!workspace || workspace_bytes < need) BX_FAIL(BX_EWORKSPACE, "bx_conv3x3_wgrad: workspace %zu < %zu", workspace_bytes, need);
   if (algo == BX_ALGO_MFMA) {
-    if (!bx_wgrad_mfma_supported(Ci_p, Co, dtype)) BX_FAIL(BX_EUNSUPPORTED, "bx_conv3x3_wgrad: MFMA path unsupported for Ci_p=%d Co=%d dtype=%d", Ci_p, Co, dtype);
+    if (!wgrad_mfma_ok(Ci_p, Co, dtype)) BX_FAIL(BX_EUNSUPPORTED, "bx_conv3x3_wgrad: MFMA path unsupported for Ci_p=%d Co=%d dtype=%d", Ci_p, Co, dtype);
+    if (dtype == BX_F32) return bx_wgrad_split_launch(x, dz, dw_oihw, dbias, B, H, W, Cin, Ci_p, Co, workspace, workspace_bytes, pending, s);
     return bx_wgrad_mfma_launch(x, dz, dw_oihw, dbias, B, H, W, Cin, Ci_p, Co, workspace, workspace_bytes, pending, s);
   }
   if (pending && pending->valid) {                             // the direct kernels cannot carry a reduce: finish the chain first

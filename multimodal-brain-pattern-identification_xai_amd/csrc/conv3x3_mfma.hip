@@ -128,10 +128,23 @@ __global__ __launch_bounds__(256) void k_pack_mfma_many(const bxPackJob* __restr
         const int s = (int)(so - (unsigned)chunk * (unsigned)ks);
         const int q = s * 32 + kk, tap = q / ck, i = chunk * ck + q % ck;
         if (tap < 9) {
-          if (!jb.transpose_flip) { if (i < jb.Cin && o < jb.Cout) v[u] = w[((size_t)o * jb.Cin + i) * 9 + tap]; }
+          if (!(jb.transpose_flip & 1)) { if (i < jb.Cin && o < jb.Cout) v[u] = w[((size_t)o * jb.Cin + i) * 9 + tap]; }
           else                    { if (i < jb.Cout && o < jb.Cin) v[u] = w[((size_t)i * jb.Cin + o) * 9 + (8 - tap)]; }
         }
       }
+    }
+    if (jb.transpose_flip & 2) {              // fp32-storage operand (conv3x3_split.hip): images h, m, l with w = h + m + l
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const size_t idx = i0 + u * 256;
+        if (idx < n) {
+          const bf16_t h = f2bf(v[u]);
+          const float r = v[u] - bf2f(h);
+          const bf16_t m = f2bf(r);
+          wp[idx] = h; wp[n + idx] = m; wp[2 * n + idx] = f2bf(r - bf2f(m));
+        }
+      }
+      continue;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {

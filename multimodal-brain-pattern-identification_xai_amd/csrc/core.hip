@@ -11,6 +11,11 @@ void bx_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" int bx_version(void) { return BX_VERSION; }
+thread_local hipEvent_t g_bx_prof_ev[2] = {nullptr, nullptr};
+extern "C" int bx_profile_next_conv3(void* ev_start, void* ev_stop) {
+  g_bx_prof_ev[0] = (hipEvent_t)ev_start; g_bx_prof_ev[1] = (hipEvent_t)ev_stop;
+  return BX_OK;
+}
 extern "C" const char* bx_last_error_string(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------------
@@ -255,24 +260,34 @@ __global__ __launch_bounds__(256) void k_adamw_dev(float* __restrict__ p, const 
                                                    float* __restrict__ v, size_t n, const float* __restrict__ hyper,
                                                    float* step, float* __restrict__ sumsq_partials) {
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], gscale = hyper[5], l2 = 2.f * hyper[6];
-  float t_prev = *reinterpret_cast<volatile float*>(step);
+  // ONE lane of the workgroup reads the count and draws the ticket; the other waves take the count from LDS behind a barrier.
+  // (Round 2 let every wave load step[0] itself while only wave 0's load was ordered before the workgroup's ticket: a late wave
+  // could have read the count the last ticket holder had already advanced and applied the next step's bias correction.)
+  __shared__ float s_tprev;
   unsigned ticket = 0;
   unsigned* const cnt_top = reinterpret_cast<unsigned*>(step) + 16;
   unsigned* const cnt_grp = cnt_top + 16 * (1 + (blockIdx.x / BX_ADAMW_GROUP));
   if (threadIdx.x == 0) {
+    float tp = *reinterpret_cast<volatile float*>(step);
     unsigned one = 1u;
-    asm volatile("" : "+v"(one), "+v"(t_prev));          // the count has ARRIVED in a register before the ticket is requested
+    asm volatile("" : "+v"(one), "+v"(tp));              // the count has ARRIVED in a register before the ticket is requested
+    s_tprev = tp;
     ticket = __hip_atomic_fetch_add(cnt_grp, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  const float t = t_prev + 1.f;
-  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
-  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
   const size_t n4 = n / 4;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // the arena loads do not depend on the count: they are in flight while lane 0's read of it travels
+  float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), mv = pv, vv = pv, gv = pv;
+  if (i < n4) {
+    pv = reinterpret_cast<float4*>(p)[i]; mv = reinterpret_cast<float4*>(m)[i]; vv = reinterpret_cast<float4*>(v)[i];
+    gv = reinterpret_cast<const float4*>(g)[i];
+  }
+  __syncthreads();
+  const float t = s_tprev + 1.f;
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
   float ss = 0.f;
   if (i < n4) {
-    float4 pv = reinterpret_cast<float4*>(p)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
-    const float4 gv = reinterpret_cast<const float4*>(g)[i];
     ss = pv.x * pv.x + pv.y * pv.y + pv.z * pv.z + pv.w * pv.w;
     adamw_one(pv.x, gv.x * gscale + l2 * pv.x, mv.x, vv.x, lr, b1, b2, eps, wd, 1.f, step_size, inv_sqrt_bc2);
     adamw_one(pv.y, gv.y * gscale + l2 * pv.y, mv.y, vv.y, lr, b1, b2, eps, wd, 1.f, step_size, inv_sqrt_bc2);
@@ -320,6 +335,19 @@ __global__ __launch_bounds__(1024) void k_l2_finalize(const float* __restrict__ 
     for (int w = 0; w < 16; ++w) t += wsum[w];
     out[0] = (float)(t * (double)hyper[6]);
   }
+}
+// eight fp32 values from the HOST into a device buffer as kernel arguments: they are copied at launch time, so the caller's
+// buffer may be reused at once (a pinned staging buffer + asynchronous copy would have to outlive the copy -- under hipGraph replay
+// the host runs many steps ahead of the GPU) and the store is ordered on `stream` like any kernel
+struct BxF32x8 { float v[8]; };
+__global__ void k_store_f32x8(float* dst, BxF32x8 a) { if (threadIdx.x < 8) dst[threadIdx.x] = a.v[threadIdx.x]; }
+extern "C" int bx_store_f32x8(float* dst_device, const float* values_host, bxStream stream) {
+  BX_REQUIRE(dst_device && values_host, "bx_store_f32x8: null pointer");
+  BxF32x8 a;
+  for (int i = 0; i < 8; ++i) a.v[i] = values_host[i];
+  hipLaunchKernelGGL(k_store_f32x8, dim3(1), dim3(64), 0, (hipStream_t)stream, dst_device, a);
+  BX_CHECK_LAUNCH("bx_store_f32x8");
+  return BX_OK;
 }
 extern "C" size_t bx_adamw_partials(size_t n) { return (n / 4 + 255) / 256 + 1; }
 extern "C" size_t bx_adamw_step_words(size_t n) {

@@ -376,7 +376,10 @@ extern "C" int bx_block_conv3_tail_fwd(const bxTailDesc* d, const void* y2, cons
     pe.fin = BxBnFinalize{bn_weight, bn_bias, running_mean, running_var, num_batches_tracked, d->momentum, d->eps, scale, shift, save_mean, save_invstd,
                           (double)g.npool};
   }
+  if (g_bx_prof_ev[0]) (void)hipEventRecord(g_bx_prof_ev[0], s);          // bx_profile_next_conv3: bracket the convolution kernel only
   const int rc = bx_conv3x3_mfma_pool_launch(y2, w3_mfma, b3, y3, d->B, d->H, d->W, d->C, d->C, &pe, s);
+  if (g_bx_prof_ev[1]) (void)hipEventRecord(g_bx_prof_ev[1], s);
+  g_bx_prof_ev[0] = g_bx_prof_ev[1] = nullptr;
   if (rc != BX_OK) return rc;
   if (d->training && !pe.tree.cnt) {                    // many partial rows: the separate finalize launch (its workgroups split the channels)
     hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.C)), dim3(1024), 0, s, partials, pe.tree.nrows, (double)g.npool, g.C, 1, bn_weight, bn_bias,

@@ -212,6 +212,10 @@ def sharded_sweep(fn, n_samples, batch_size, fetch, rank=None, world=None, gathe
     if world is None:
         world = dist.get_world_size(group) if have_pg else 1
     lo, hi = shard_bounds(n_samples, rank, world)
+    if gather and world > 1 and n_samples < world:
+        # decided from (n_samples, world), which every rank knows, BEFORE any collective: all ranks raise together instead of the
+        # empty ones raising while the others wait in dist.gather
+        raise RuntimeError("sharded_sweep(gather=True) needs at least one sample per rank; use gather=False for tiny sweeps")
     parts = []
     for b0 in range(lo, hi, batch_size):
         b1 = min(hi, b0 + batch_size)
@@ -223,8 +227,6 @@ def sharded_sweep(fn, n_samples, batch_size, fetch, rank=None, world=None, gathe
         return mine
     # every rank needs the trailing shape to build its padded block: take it from a rank that has samples
     cap = shard_bounds(n_samples, 0, world)[1]           # rank 0 holds the largest shard
-    if mine is None:
-        raise RuntimeError("sharded_sweep(gather=True) needs at least one sample per rank; use gather=False for tiny sweeps")
     pad = torch.zeros(cap, *mine.shape[1:], dtype=mine.dtype, device=mine.device)
     pad[:mine.shape[0]] = mine
     blocks = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None

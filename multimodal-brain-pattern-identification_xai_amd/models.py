@@ -107,12 +107,12 @@ class Spectrogram_Model(nn.Module):
         blocks = [getattr(self, f"block{i}") for i in range(1, 6)]
         for blk in blocks:
             blk._prepacked = None
-        if self.compute_dtype != torch.bfloat16 or ops.CONV_ALGO == ops.L.BX_ALGO_DIRECT or not self.fc.weight.is_cuda:
+        if ops.CONV_ALGO == ops.L.BX_ALGO_DIRECT or not self.fc.weight.is_cuda:
             return (None,) + tuple(ops.next_seed_pair(x.device)) if seed_pair else None
         weights = [getattr(b, f"conv{k}").weight for b in blocks for k in (1, 2, 3)]
         plan = getattr(self, "_pack_plan", None)
-        if plan is None or plan.key != tuple(w.data_ptr() for w in weights):
-            plan = ops.PackPlan(weights)
+        if plan is None or plan.key != tuple(w.data_ptr() for w in weights) + (self.compute_dtype,):
+            plan = ops.PackPlan(weights, self.compute_dtype)     # fp32 storage: split (hi + lo) operands, same single launch
             self._pack_plan = plan
         raw = (x is not None and x.is_cuda and x.dim() == 4 and x.shape[1] == blocks[0].in_channels and not x.requires_grad
                and not _is_internal(x, torch.bfloat16) and blocks[0].compute_dtype == torch.bfloat16)

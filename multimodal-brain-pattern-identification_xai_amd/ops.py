@@ -16,7 +16,8 @@ from . import _lib as L
 
 CONV_ALGO = L.BX_ALGO_AUTO        # module-level switch used by tests to force the direct / MFMA kernels
 WGRAD_ALGO = L.BX_ALGO_AUTO
-CONV_PROFILE = None               # bench.py sets a list: every conv launch appends (kind, start_event, end_event)
+CONV_PROFILE = None               # bench.py sets a list: every conv launch appends (kind, start_event, end_event, meta); meta =
+                                  # (form, B, H, W, Ci, Co) with form "conv" | "pair" (two layers, Co = both widths) | "conv3+pool"
 # Multi-stream overlap (most kernels of this model are latency-bound and leave CUs idle): weight-gradient kernels run
 # on a side stream beside the data-gradient chain, the EEG branch beside the spectrogram branch.  join_side_streams()
 # must run before anything consumes the gradients (FlatAdamW.step / DataParallel.sync_gradients do it).
@@ -64,8 +65,8 @@ def _join_after_backward():
 class _Timed:
     """HIP-event bracket around one launch on the current stream (only active while CONV_PROFILE is a list)."""
 
-    def __init__(self, kind):
-        self.kind = kind
+    def __init__(self, kind, meta=None):
+        self.kind, self.meta = kind, meta
 
     def __enter__(self):
         if CONV_PROFILE is not None:
@@ -76,7 +77,7 @@ class _Timed:
         if CONV_PROFILE is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            CONV_PROFILE.append((self.kind, self.e0, e1))
+            CONV_PROFILE.append((self.kind, self.e0, e1, self.meta))
 
 
 def _require_gpu(t: torch.Tensor, what: str):
@@ -247,20 +248,31 @@ class InputLayout(torch.autograd.Function):
 
 
 def _pack(w: torch.Tensor, flip: bool, dtype=None):
-    """fp32 OIHW -> library operand(s). Returns (packed_f32|None, packed_mfma|None, I_p, O_p).
-    With bf16 activations and an MFMA layout available only the MFMA operand is produced."""
+    """fp32 OIHW -> library operand(s). Returns (packed_f32|None, packed_mfma|None, I_p, O_p, layout).
+    ``layout`` names what packed_mfma holds: "bf16" (bf16 activations) or "split" (fp32 activations on the matrix cores: h + m + l
+    images, csrc/conv3x3_split.hip).  With a compute dtype given and an MFMA layout available only that operand is produced;
+    dtype=None produces the fp32 operand and the bf16 one."""
     lib = L.load()
     co, ci = w.shape[0], w.shape[1]
     i_log, o_log = (co, ci) if flip else (ci, co)
     ip, op = pad8(i_log), pad8(o_log)
-    pm = None
-    nb = lib.bx_conv3x3_packed_mfma_bytes(ip, op) if dtype in (None, torch.bfloat16) and CONV_ALGO != L.BX_ALGO_DIRECT else 0
-    if nb:
-        pm = torch.empty(nb, dtype=torch.uint8, device=w.device)
-    need_f32 = dtype is None or pm is None or CONV_ALGO == L.BX_ALGO_DIRECT
+    pm, layout = None, None
+    if CONV_ALGO != L.BX_ALGO_DIRECT:
+        if dtype == torch.float32:
+            nb, layout = lib.bx_conv3x3_packed_split_bytes(ip, op), "split"
+        else:
+            nb, layout = lib.bx_conv3x3_packed_mfma_bytes(ip, op), "bf16"
+        if nb:
+            pm = torch.empty(nb, dtype=torch.uint8, device=w.device)
+        else:
+            layout = None
+    need_f32 = dtype is None or pm is None
     pf = torch.empty(9 * ip * op, dtype=torch.float32, device=w.device) if need_f32 else None
-    L.check(lib.bx_conv3x3_pack(_p(w), _p(pf), _p(pm), co, ci, ip, op, 1 if flip else 0, _stream()), "bx_conv3x3_pack")
-    return pf, pm, ip, op
+    if layout == "split":
+        L.check(lib.bx_conv3x3_pack_split(_p(w), _p(pm), co, ci, ip, op, 1 if flip else 0, _stream()), "bx_conv3x3_pack_split")
+    else:
+        L.check(lib.bx_conv3x3_pack(_p(w), _p(pf), _p(pm), co, ci, ip, op, 1 if flip else 0, _stream()), "bx_conv3x3_pack")
+    return pf, pm, ip, op, layout
 
 
 class PackPlan:
@@ -270,18 +282,21 @@ class PackPlan:
     weights change.  ``get(i, flip)`` returns the operand tuple _conv expects, or None when the MFMA path does not
     cover that shape (the caller then packs it individually)."""
 
-    def __init__(self, weights):
+    def __init__(self, weights, dtype=torch.bfloat16):
         import ctypes
         lib = L.load()
         dev = weights[0].device
-        self.key = tuple(w.data_ptr() for w in weights)
+        self.dtype = dtype
+        split = dtype == torch.float32                  # fp32 storage: h + m + l images (csrc/conv3x3_split.hip), job bit 1
+        nbytes = lib.bx_conv3x3_packed_split_bytes if split else lib.bx_conv3x3_packed_mfma_bytes
+        self.key = tuple(w.data_ptr() for w in weights) + (dtype,)
         entries, off = [], 0
         for i, w in enumerate(weights):
             co, ci = w.shape[0], w.shape[1]
             for flip in (False, True):
                 i_log, o_log = (co, ci) if flip else (ci, co)
                 ip, op = pad8(i_log), pad8(o_log)
-                nb = lib.bx_conv3x3_packed_mfma_bytes(ip, op)
+                nb = nbytes(ip, op)
                 if nb:
                     entries.append((i, flip, w, co, ci, ip, op, off, nb))
                     off += (nb + 255) // 256 * 256
@@ -289,9 +304,9 @@ class PackPlan:
         self.views, jobs, blk = {}, (L.PackJob * len(entries))(), 0
         for j, (i, flip, w, co, ci, ip, op, o, nb) in enumerate(entries):
             view = self.buf.narrow(0, o, nb)
-            self.views[(i, flip)] = (None, view, ip, op)
-            jobs[j] = L.PackJob(w.data_ptr(), view.data_ptr(), co, ci, ip, op, 1 if flip else 0, blk)
-            blk += max(1, (nb // 2 + 2047) // 2048)            # 2048 packed elements (8 per thread) per workgroup
+            self.views[(i, flip)] = (None, view, ip, op, "split" if split else "bf16")
+            jobs[j] = L.PackJob(w.data_ptr(), view.data_ptr(), co, ci, ip, op, (1 if flip else 0) | (2 if split else 0), blk)
+            blk += max(1, (nb // (6 if split else 2) + 2047) // 2048)   # 2048 packed elements (8 per thread) per workgroup
         self.njobs, self.nblocks = len(entries), blk
         raw = bytes(memoryview(jobs)) if entries else b"\0" * 8
         self.jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
@@ -303,6 +318,7 @@ class PackPlan:
         seeds = torch.empty(2, dtype=torch.int64, device=dev)
         out, src, dims = None, None, (0, 0, 0, 0, 8)
         if x_nchw is not None:
+            assert self.dtype == torch.bfloat16, "the packing launch converts the batch to the bf16 layout only"
             B, Cc, H, W = x_nchw.shape
             src = x_nchw.detach().to(torch.float32).contiguous()
             out = torch.empty(B, H, W, pad8(Cc), dtype=torch.bfloat16, device=dev)
@@ -316,6 +332,7 @@ class PackPlan:
         """Pack every operand; with ``x_nchw`` (fp32 NCHW, no gradient needed) the same launch also produces the batch in the
         internal bf16 channels-last layout and returns it as a logical-NCHW view."""
         if x_nchw is not None and self.njobs:
+            assert self.dtype == torch.bfloat16, "the packing launch converts the batch to the bf16 layout only"
             B, Cc, H, W = x_nchw.shape
             src = x_nchw.detach().to(torch.float32).contiguous()
             out = torch.empty(B, H, W, pad8(Cc), dtype=torch.bfloat16, device=x_nchw.device)
@@ -333,15 +350,19 @@ class PackPlan:
 def _conv(x, packed, bias, mask_src, addend, relu: bool, dtype, carry: bool = False, mask_bits: bool = False):
     """carry=True: a pending chained weight-gradient sum of this device rides in the convolution's launch (bx_conv3x3_carry).
     mask_bits=True: ``mask_src`` is the bit form of the ReLU decisions written by bx_conv3x3_pair (BX_EPI_MASK_BITS)."""
-    pf, pm, ip, op = packed
+    pf, pm, ip, op, layout = packed
     B, H, W, Ci = x.shape
     if Ci != ip:
         raise RuntimeError(f"brainxai: conv input has {Ci} channels, packed weights expect {ip}")
     y = torch.empty(B, H, W, op, dtype=dtype, device=x.device)
-    algo = CONV_ALGO if x.dtype == torch.bfloat16 else L.BX_ALGO_DIRECT
+    if pm is not None and layout != ("bf16" if x.dtype == torch.bfloat16 else "split"):
+        pm = None                                           # an MFMA operand packed for the other storage type: direct kernel
+        if pf is None:
+            raise RuntimeError(f"brainxai: weights were packed for {layout} activations, the input is {x.dtype}")
+    algo = CONV_ALGO if pm is not None else L.BX_ALGO_DIRECT
     st = _wg_chain_state(x.device) if carry and WGRAD_CARRY else None
     flags = (L.BX_EPI_RELU if relu else 0) | (L.BX_EPI_MASK_BITS if mask_bits else 0)
-    with _Timed("fwd" if bias is not None else "dgrad"):
+    with _Timed("fwd" if bias is not None else "dgrad", ("conv", B, H, W, Ci, op)):
         if st is not None and st.pend.valid and st.stream == _stream():
             L.check(L.load().bx_conv3x3_carry(_p(x), _p(pf), _p(pm), _p(bias), _p(mask_src), _p(addend), _p(y), B, H, W, Ci, op,
                                               bx_dtype(dtype), flags, algo, C.byref(st.pend), _stream()), "bx_conv3x3_carry")
@@ -397,7 +418,7 @@ def _wgrad(x, dz, w: torch.Tensor, b: torch.Tensor, chain: bool = False):
     B, H, W, Cip = x.shape
     Co = dz.shape[3]
     dt = bx_dtype(x.dtype)
-    algo = WGRAD_ALGO if x.dtype == torch.bfloat16 else L.BX_ALGO_DIRECT
+    algo = WGRAD_ALGO
     need = lib.bx_conv3x3_wgrad_workspace(B, H, W, Cip, Co, dt, algo)
     dw, db = new_grad(w), new_grad(b)
     if chain and WGRAD_CHAIN and x.dtype == torch.bfloat16 and algo != L.BX_ALGO_DIRECT:
@@ -415,14 +436,14 @@ def _wgrad(x, dz, w: torch.Tensor, b: torch.Tensor, chain: bool = False):
             buf = torch.empty(big, dtype=torch.uint8, device=x.device)
             st.ring[st.slot] = buf
         st.stream = _stream()
-        with _Timed("wgrad"):
+        with _Timed("wgrad", ("conv", B, H, W, Cip, Co)):
             L.check(lib.bx_conv3x3_wgrad_chained(_p(x), _p(dz), _p(dw), _p(db), B, H, W, w.shape[1], Cip, Co, dt, algo, _p(buf), buf.numel(),
                                                  C.byref(st.pend), st.stream), "bx_conv3x3_wgrad_chained")
         st.keep = (buf, dw, db)                             # what the pending reduce reads / writes
         st.slot ^= 1
         return dw, db
     ws = workspace(need, x.device)
-    with _Timed("wgrad"):
+    with _Timed("wgrad", ("conv", B, H, W, Cip, Co)):
         L.check(lib.bx_conv3x3_wgrad(_p(x), _p(dz), _p(dw), _p(db), B, H, W, w.shape[1], Cip, Co, dt, algo, _p(ws), ws.numel(), _stream()),
                 "bx_conv3x3_wgrad")
     return dw, db
@@ -451,13 +472,13 @@ class BlockFn(torch.autograd.Function):
         B, H, W, _ = x.shape
         Cc = w3.shape[0]
         # conv3 with the pool and the batch statistics in its epilogue (two launches for conv3 + tail instead of four)
-        fused = FUSE_POOL and dt == torch.bfloat16 and CONV_ALGO != L.BX_ALGO_DIRECT and cfg.preact != 3 and Cc >= 16 and CONV_PROFILE is None
+        fused = FUSE_POOL and dt == torch.bfloat16 and CONV_ALGO != L.BX_ALGO_DIRECT and cfg.preact != 3 and Cc >= 16
         packed3 = None
         first = 0
         masks = None
         # stage 1 (8 padded input channels -> 16 -> 16, bf16): conv1 and conv2 in one launch, conv1's output kept in LDS and written
         # out only when a backward pass (or a debugging hook) will read it
-        if (CONV_PAIR and dt == torch.bfloat16 and CONV_ALGO != L.BX_ALGO_DIRECT and cfg.preact not in (1, 2) and CONV_PROFILE is None
+        if (CONV_PAIR and dt == torch.bfloat16 and CONV_ALGO != L.BX_ALGO_DIRECT and cfg.preact not in (1, 2)
                 and lib.bx_conv3x3_pair_supported(x.shape[3], w1.shape[0], w2.shape[0], bx_dtype(dt))):
             pk = []
             for k in range(2):
@@ -471,7 +492,7 @@ class BlockFn(torch.autograd.Function):
                     # bytes; stages 1-2: the later stages' data gradients are not bound by those bytes and read the activations)
                     masks = (torch.empty(B, H, W, w1.shape[0] // 4, dtype=torch.uint8, device=x.device),
                              torch.empty(B, H, W, w2.shape[0] // 4, dtype=torch.uint8, device=x.device))
-                with _Timed("fwd"):
+                with _Timed("fwd", ("pair", B, H, W, x.shape[3], (w1.shape[0], w2.shape[0]))):
                     L.check(lib.bx_conv3x3_pair(_p(x), _p(pk[0][1]), _p(b1), _p(pk[1][1]), _p(b2), _p(y1), _p(y2),
                                                 _p(masks[0]) if masks else None, _p(masks[1]) if masks else None, B, H, W, x.shape[3],
                                                 w1.shape[0], w2.shape[0], bx_dtype(dt), _stream()), "bx_conv3x3_pair")
@@ -502,6 +523,11 @@ class BlockFn(torch.autograd.Function):
             y3 = torch.empty(B, H, W, Cc, dtype=dt, device=x.device)
             desc = _tail_desc(x, y3, cfg)
             ws = workspace(lib.bx_block_tail_workspace(C.byref(desc)), x.device)
+            if CONV_PROFILE is not None:                    # the library records the pair around the convolution kernel of this call
+                pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                pe0.record(); pe1.record()                  # (creates the hipEvent handles)
+                L.check(lib.bx_profile_next_conv3(pe0.cuda_event, pe1.cuda_event), "bx_profile_next_conv3")
+                CONV_PROFILE.append(("fwd", pe0, pe1, ("conv3+pool", B, H, W, acts[2].shape[3], Cc)))
             L.check(lib.bx_block_conv3_tail_fwd(C.byref(desc), _p(acts[2]), _p(packed3[1]), _p(b3), _p(y3), _p(x), _p(w11), w11.shape[1], _p(b11),
                                                 _p(bnw), _p(bnb), _p(rm), _p(rv), _p(nbt), _p(seed), _p(pooled), _p(out), _p(mean), _p(invstd),
                                                 _p(ws), ws.numel(), _stream()), "bx_block_conv3_tail_fwd")

@@ -77,8 +77,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.is_cuda = dev.type == "cuda"
         if self.is_cuda:
             self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
-            self._hyper_host = [torch.zeros(8, dtype=torch.float32).pin_memory() for _ in range(2)]
-            self._hyper_slot, self._hyper_seen = 0, None
+            self._hyper_seen = None
             self.l2_value = torch.zeros((), dtype=torch.float32, device=dev)
             self._l2_partials = torch.zeros(int(L.load().bx_adamw_partials(self.n)), dtype=torch.float32, device=dev)
             self.refresh_hyper()
@@ -100,10 +99,12 @@ class FlatAdamW(torch.optim.Optimizer):
         vals = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
                 float(self.grad_scale), float(self.l2_lambda), 0.0)
         if vals != self._hyper_seen:
-            self._hyper_slot ^= 1
-            host = self._hyper_host[self._hyper_slot]
-            host.copy_(torch.tensor(vals, dtype=torch.float32))
-            self.hyper.copy_(host, non_blocking=True)
+            # the values ride as kernel arguments of a one-wave store, ordered on the current stream: no host staging buffer
+            # whose reuse could race with a copy still queued behind many replayed steps (a per-step scheduler under hipGraph
+            # replay runs the host far ahead of the GPU)
+            import ctypes
+            host = (ctypes.c_float * 8)(*vals)
+            L.check(L.load().bx_store_f32x8(_p(self.hyper), ctypes.addressof(host), _stream()), "bx_store_f32x8")
             self._hyper_seen = vals
 
     def zero_grad(self, set_to_none=True):
@@ -178,8 +179,34 @@ def setup(rank, world_size, backend=None):
         dist.init_process_group(backend, rank=rank, world_size=world_size)
 
 
+# What this library itself created against the live process group: asynchronous-reduction handles (each holds a c10d Work, i.e.
+# RCCL stream events and a reference to the communicator) and graphed steps (hipGraphs captured while the group was alive; the
+# one-graph data-parallel step even contains the collectives, and RCCL requires a communicator to outlive every graph that
+# captured one of its operations).  cleanup() releases them before the communicator goes -- the reference's calling pattern is a
+# bare ``cleanup()`` with model, wrapper and step objects all still alive (XAI_Multimodality.py:70-71).
+import weakref as _weakref
+
+_LIVE_REDUCTIONS = _weakref.WeakSet()
+_LIVE_STEPPERS = _weakref.WeakSet()
+
+
+def release_group_objects():
+    """Wait for and drop every outstanding reduction handle, drop every captured graph of a data-parallel GraphedTrainStep (they
+    are re-captured on their next use).  Returns (handles released, graphs released)."""
+    nred = ngraph = 0
+    for r in list(_LIVE_REDUCTIONS):
+        nred += 1 if r.finish() else 0
+    for st in list(_LIVE_STEPPERS):
+        ngraph += st.release()
+    return nred, ngraph
+
+
 def cleanup():
+    """dist.destroy_process_group() (reference XAI_Multimodality.py:70-71), made safe for what brainxai keeps alive: outstanding
+    reductions are waited for and their c10d Work handles dropped, graphs captured under the group are destroyed, the device is
+    drained -- then the communicator is torn down."""
     if dist.is_initialized():
+        release_group_objects()
         if torch.cuda.is_available():
             torch.cuda.synchronize()                      # nothing may still be queued on RCCL's stream when the communicator goes
         dist.destroy_process_group()
@@ -260,11 +287,23 @@ class _Reduction:
         self.tensor, self.world = tensor, world
         self.div = not tensor.is_cuda                       # gloo has no AVG
         self.work = dist.all_reduce(tensor, op=dist.ReduceOp.SUM if self.div else dist.ReduceOp.AVG, group=group, async_op=True)
+        _LIVE_REDUCTIONS.add(self)
 
     def wait(self):
+        if self.work is None:
+            return
         self.work.wait()                                    # NCCL/RCCL: the current stream waits for the collective's stream
+        self.work = None                                    # the c10d Work (its events, its reference to the communicator) goes now
+        _LIVE_REDUCTIONS.discard(self)
         if self.div:
             self.tensor.div_(self.world)
+
+    def finish(self):
+        """cleanup(): a handle nobody waited for is waited for now.  True when there was something to release."""
+        if self.work is None:
+            return False
+        self.wait()
+        return True
 
 
 def overlap_plan(model, optimizer):
@@ -362,15 +401,22 @@ class GraphedTrainStep:
     (Round 1 carried an experimental six-graph "branch-parallel" replay, BX_BRANCH_GRAPHS: it left the eager trajectory at
     B=64 -- cross-queue visibility at graph launches -- gained 1.4 % and was removed in round 2)"""
 
-    def __init__(self, model, optimizer, criterion, ddp=None, adopt_inputs=False):
+    def __init__(self, model, optimizer, criterion, ddp=None, adopt_inputs=False, strict=False):
         """``adopt_inputs``: the tensors of the capturing call become the graph's static inputs themselves (no clone, no
-        per-step copy when the same tensors are passed again) -- for callers that refill one resident batch in place."""
-        self.model, self.opt, self.crit, self.ddp, self.adopt = model, optimizer, criterion, ddp, adopt_inputs
+        per-step copy when the same tensors are passed again) -- for callers that refill one resident batch in place.
+        ``strict``: a failed capture raises instead of continuing eagerly (bench.py: a slower number must not pass silently)."""
+        self.model, self.opt, self.crit, self.ddp, self.adopt, self.strict = model, optimizer, criterion, ddp, adopt_inputs, strict
+        if ddp is not None:
+            _LIVE_STEPPERS.add(self)                        # cleanup() destroys this step's graphs before the communicator
         self.enabled = isinstance(optimizer, FlatAdamW) and optimizer.is_cuda and os.environ.get("BX_GRAPH_LOOPS", "1") != "0"
         self._seen, self._graphs = set(), {}
-        # data-parallel: two graphs cut after spectrogram stage 2, the first bucket's all-reduce between them (BX_DDP_OVERLAP=0:
-        # one graph, one collective after it)
+        # data-parallel: the step is cut after spectrogram stage 2 and the gradient arena is exchanged in two buckets, the first
+        # (everything from stage 3 on, 88 % of the bytes) beside the early stages' backward (BX_DDP_OVERLAP=0: one collective after
+        # the whole backward).  Default since round 3: ONE hipGraph holds forward, backward, both all-reduces (forked onto RCCL's
+        # stream inside the capture) and the fused AdamW, so a data-parallel step is one replay like the single-GPU step;
+        # BX_DDP_GRAPH=pieces keeps round 2's form (graph -> all-reduce -> graph -> all-reduce -> eager AdamW, four host-side pieces).
         self.plan = overlap_plan(model, optimizer) if (ddp is not None and os.environ.get("BX_DDP_OVERLAP", "1") != "0") else None
+        self.one_graph = ddp is not None and os.environ.get("BX_DDP_GRAPH", "one") != "pieces"
 
     def _finish(self):
         if self.ddp is not None:
@@ -392,6 +438,37 @@ class GraphedTrainStep:
             self.opt.gather_grads(0, pidx)
         return ("overlap", (g1, g2), static_in, static_lab, loss.detach(), out.detach(), cut)
 
+    def _capture_ddp_one(self, static_in, static_lab):
+        """The whole data-parallel step in one graph.  The collectives are captured: ProcessGroupNCCL launches them on RCCL's stream,
+        which the capture forks from the step's stream at the call and joins again at ``wait()`` -- bucket 1 therefore sits on a
+        branch beside the backward of stages 2-1, exactly the eager step's dependencies.  Same kernels, same order per stream: the
+        trajectory is bit-identical to the eager overlapped step (tests/test_gpu_parity.py, 1-rank RCCL group)."""
+        cut = None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.opt.zero_grad()
+            if self.plan is not None and len(static_in) == 2:
+                k, pidx, off = self.plan
+                cut = _Cut()
+                out = self.model(*static_in, cut=(k, cut))
+                loss = self.crit(out, static_lab)
+                loss.backward(ops.unit_gradient(loss.device) if loss.is_cuda and loss.dim() == 0 else None)
+                self.opt.gather_grads(pidx, None)
+                r1 = self.ddp.reduce_async(self.opt.flat_g.narrow(0, off, self.opt.n - off))
+                cut.finish()
+                self.opt.gather_grads(0, pidx)
+                r2 = self.ddp.reduce_async(self.opt.flat_g.narrow(0, 0, off))
+                for r in (r1, r2):
+                    if r is not None:
+                        r.wait()
+            else:
+                out = self.model(*static_in)
+                loss = self.crit(out, static_lab)
+                loss.backward(ops.unit_gradient(loss.device) if loss.is_cuda and loss.dim() == 0 else None)
+                self.ddp.sync_gradients(self.opt)
+            self.opt.step(gathered=True)
+        return ("ddp_one", g, static_in, static_lab, loss.detach(), out.detach(), cut)
+
     def _replay_overlapped(self, entry):
         _, (g1, g2), _, _, loss, out, _ = entry
         _, _, off = self.plan
@@ -404,6 +481,17 @@ class GraphedTrainStep:
                 r.wait()
         self.opt.step(gathered=True)
         return loss, out
+
+    def release(self):
+        """Drop the captured graphs (and with them their memory pools and static tensors); the next call of a known shape
+        captures again.  Returns the number of graphs dropped."""
+        n = 0
+        for entry in self._graphs.values():
+            n += len(entry[1]) if isinstance(entry[1], tuple) else 1
+        if n and torch.cuda.is_available():
+            torch.cuda.synchronize()                        # a replay may still be running: the graph objects die only after it
+        self._graphs.clear()
+        return n
 
     def _eager(self, inputs, labels):
         self.opt.zero_grad()
@@ -434,7 +522,20 @@ class GraphedTrainStep:
             static_lab = labels.detach() if self.adopt else labels.detach().clone()
             try:
                 torch.cuda.synchronize()
-                if self.plan is not None and len(inputs) == 2:
+                entry = None
+                if self.one_graph and dist.is_initialized():
+                    try:
+                        entry = self._capture_ddp_one(static_in, static_lab)
+                    except Exception as exc:          # noqa: BLE001  (a stack whose RCCL cannot be captured: fall back to the pieces)
+                        if self.strict:
+                            raise
+                        print(f"[brainxai] one-graph capture of the data-parallel step failed ({type(exc).__name__}: {exc}); "
+                              "using graph + collective pieces")
+                        self.one_graph = False
+                        torch.cuda.synchronize()
+                if entry is not None:
+                    pass
+                elif self.plan is not None and len(inputs) == 2:
                     entry = self._capture_overlapped(static_in, static_lab)
                 else:
                     graph = torch.cuda.CUDAGraph()
@@ -447,6 +548,8 @@ class GraphedTrainStep:
                             self.opt.step()
                     entry = ("one", graph, static_in, static_lab, loss.detach(), out.detach())
             except Exception as exc:                  # noqa: BLE001  (capture is an optimisation, never a requirement)
+                if self.strict:
+                    raise
                 print(f"[brainxai] hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); running eagerly")
                 self.enabled = False
                 torch.cuda.synchronize()
@@ -461,13 +564,15 @@ class GraphedTrainStep:
         self.opt.refresh_hyper()                      # lr / betas / weight decay changed by a scheduler since the last step?
         if entry[0] == "overlap":
             return self._replay_overlapped(entry)
+        if entry[0] == "ddp_one":
+            entry[1].replay()
+            self.opt._opt_called = True
+            return entry[4], entry[5]
         _, graph, _, _, loss, out = entry
         graph.replay()
         self._finish()
+        self.opt._opt_called = True                   # the optimizer step ran inside the graph: torch's LR schedulers look for this flag
         return loss, out
-
-
-_STEPPER = [None]
 
 
 class AsyncCheckpointer:
@@ -562,24 +667,21 @@ def _to_plain(obj):
     return obj
 
 
-def _run_epoch(model, loader, criterion, device, optimizer=None, ddp=None, unpack=None, per_batch_sum=False):
+def _run_epoch(model, loader, criterion, device, optimizer=None, ddp=None, unpack=None, per_batch_sum=False, stepper=None):
     """One pass; loss*B (combined loop, NB:1603) or the plain per-batch loss (DDP loop, training_distributed.py:59,89:
-    ``per_batch_sum``) and the correct counts accumulate ON DEVICE (the reference syncs three times per step)."""
+    ``per_batch_sum``) and the correct counts accumulate ON DEVICE (the reference syncs three times per step).
+    ``stepper``: the caller's GraphedTrainStep (its captured graphs then survive from epoch to epoch and die with the caller's
+    loop); without one a training pass builds its own for this epoch."""
     loss_sum = torch.zeros((), dtype=torch.float32, device=device)
     correct = torch.zeros((), dtype=torch.int64, device=device)
     total = 0
-    stepper = None
     for batch in loader:
         inputs, labels = unpack(batch) if unpack else batch
         inputs = [t.to(device, non_blocking=True) for t in (inputs if isinstance(inputs, (tuple, list)) else (inputs,))]
         labels = labels.to(device, non_blocking=True)
         if optimizer is not None:
             if stepper is None:
-                s = _STEPPER[0]                             # one cached stepper: captured graphs survive from epoch to epoch
-                if s is not None and s.model is model and s.opt is optimizer and s.crit is criterion and s.ddp is ddp:
-                    stepper = s
-                else:
-                    stepper = _STEPPER[0] = GraphedTrainStep(model, optimizer, criterion, ddp)
+                stepper = GraphedTrainStep(model, optimizer, criterion, ddp)
             loss, out = stepper(inputs, labels)
         else:
             with torch.no_grad():
@@ -602,9 +704,11 @@ def train_and_validate_combined(model, train_loader, valid_loader, epochs, optim
     name = "combined_checkpoint.pth.tar"
     start, tr_l, va_l, tr_a, va_a = load_checkpoint(checkpoint_dir, name, model, optimizer)
     saver = AsyncCheckpointer(checkpoint_dir, name) if async_checkpoint else None
+    # the loop OWNS the graphed step: model, optimizer, captured hipGraphs and their memory pools are released when it returns
+    stepper = GraphedTrainStep(model, optimizer, criterion)
     for epoch in range(start, epochs):
         model.train()
-        l, a = _run_epoch(model, train_loader, criterion, device, optimizer)
+        l, a = _run_epoch(model, train_loader, criterion, device, optimizer, stepper=stepper)
         tr_l.append(l); tr_a.append(a)
         model.eval()
         l, a = _run_epoch(model, valid_loader, criterion, device)

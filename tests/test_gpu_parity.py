@@ -434,19 +434,36 @@ def test_multimodal_train3(tag, opt):
             want = torch.from_numpy(fix["after3.shead." + n]).float()
             assert float((t.detach().float().flatten()[:32].cpu() - want).abs().max()) <= bound(want), n
         # (b) the optimizer arithmetic itself, strictly: three more steps, each started from the ORACLE's state (weights, buffers,
-        # AdamW moments and step count copied over), so that both sides take the same step from the same point.  Entries whose
-        # gradient is above 1e-3 of their tensor's (and 1e-5 of the model's) largest are well-posed: a 1e-3 relative gradient
-        # difference moves the normalised update by O(1e-3) -> 5e-6 absolute (oracle fp32 vs fp64: < 1e-6).
+        # AdamW moments and step count copied over).  The target is the EXACT AdamW update (fp64) of that state with the gradient of
+        # the decision-matched fp64 twin of this very forward -- round 2 compared with the oracle's own fp32 step here, which is
+        # only well-posed while neither side flips a ReLU / max-pool tie in any of these three forwards (tools/flip_scan.py: the
+        # reference's own fp32 run flips one in about half of them; the round-2 seed happened to avoid it for the VALU kernels).
+        # Entries whose gradient is above 1e-3 of their tensor's (and 1e-5 of the model's) largest are well-posed: a 1e-3 relative
+        # gradient difference moves the normalised update by O(1e-3) -> 5e-6 absolute.
+        import math
         for step in range(3, 6):
             mine.load_state_dict(ref.state_dict())
             _sync_adamw(opt_m, opt_r)
-            O.train_step(ref, opt_r, eeg, spec, labels)
+            ref0, st0 = copy.deepcopy(ref), copy.deepcopy(opt_r.state_dict())
+            keep = ops.keep_block_activations(mine)
+            O.train_step(ref, opt_r, eeg, spec, labels)          # the oracle's trajectory moves on (the next state to start from)
             brainxai.train_step(mine, opt_m, e, s, lab, crit)
             torch.cuda.synchronize()
-            gm = max(float(q.grad.abs().max()) for q in ref.parameters())
-            for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
-                solid = q.grad.abs() > 1e-3 * max(float(q.grad.abs().max()), 1e-2 * gm)
-                dev = (p.detach().cpu() - q.detach()).abs()
+            twin, _ = _matched(ref0, (eeg, spec), keep, f"mm {tag} step{step}")
+            ops.keep_block_activations(mine, on=False)
+            O.kl_div(twin(*_dbl(eeg, spec)), labels.double()).backward()
+            hp = opt_r.param_groups[0]
+            lr, (b1, b2), eps, wd = hp["lr"], hp["betas"], hp["eps"], hp["weight_decay"]
+            gm = max(float(q.grad.abs().max()) for q in twin.parameters())
+            for i, ((n, p), (_, q0), (_, qt)) in enumerate(zip(mine.named_parameters(), ref0.named_parameters(), twin.named_parameters())):
+                stt = st0["state"][i]
+                t = float(stt["step"]) + 1.0
+                gd = qt.grad.double()
+                m1 = b1 * stt["exp_avg"].double() + (1 - b1) * gd
+                v1 = b2 * stt["exp_avg_sq"].double() + (1 - b2) * gd * gd
+                want = q0.detach().double() * (1 - lr * wd) - lr / (1 - b1 ** t) * m1 / (v1.sqrt() / math.sqrt(1 - b2 ** t) + eps)
+                solid = gd.abs() > 1e-3 * max(float(gd.abs().max()), 1e-2 * gm)
+                dev = (p.detach().cpu().double() - want).abs()
                 if solid.any():
                     assert float(dev[solid].max()) <= 5e-6, (step, n, float(dev[solid].max()))
                 assert float(dev.max()) <= 2.2e-3, (step, n, float(dev.max()))           # a noise entry moves by <= ~lr on either side
@@ -476,7 +493,7 @@ def _attr_models():
 def test_gradcam_targets():
     ref, mine = _attr_models()
     fix = load("gradcam_4x64x128")
-    eeg, spec = O.seeded((2, 1, 19, 2000), 52, "randn"), O.seeded((2, 4, 64, 128), 53, "rand")
+    eeg, spec = O.seeded((2, 1, 19, 2000), 52, "randn"), O.seeded((2, 4, 64, 128), int(fix["spec_seed"][0]), "rand")
     e, s = eeg.to(DEV), spec.to(DEV)
     for layer in ("block5", "block5.conv3", "block3"):
         cam, raw, w, A, out = brainxai.grad_cam(mine, e, s, "spectrogram_model." + layer, "all", upsample=False, return_parts=True)
@@ -504,8 +521,8 @@ def test_gradcam_targets():
 
 def test_saliency_and_ig():
     ref, mine = _attr_models()
-    eeg, spec = O.seeded((2, 1, 19, 2000), 52, "randn"), O.seeded((2, 4, 64, 128), 53, "rand")
     sal = load("saliency_4x64x128")
+    eeg, spec = O.seeded((2, 1, 19, 2000), 52, "randn"), O.seeded((2, 4, 64, 128), int(sal["spec_seed"][0]), "rand")
     se, ss = brainxai.saliency(mine, eeg[:1].to(DEV), spec[:1].to(DEV), reference_quirk=True)
     check(sal, "eeg_ref", se[0].cpu(), tol=TOL, robust=True); check(sal, "spec_ref_x2", ss[0].cpu(), tol=TOL, robust=True)
     keep = ops.keep_block_activations(mine)
@@ -1111,11 +1128,19 @@ def test_rccl_single_rank_group_matches_plain_training():
 
 
 def test_overlapped_ddp_step_single_rank_matches_plain_training():
-    """The overlapped data-parallel step (autograd cut after spectrogram stage 2, two asynchronous RCCL all-reduces of arena
-    slices, eager and as the two-graph replay) on a 1-rank group: bit-identical to plain training, dropout on."""
+    """The data-parallel step on a 1-rank RCCL group, dropout on, in every form the product has -- the overlapped eager step (autograd
+    cut after spectrogram stage 2, two asynchronous all-reduces of arena slices), round 2's graph pieces (graph -> collective ->
+    graph -> collective -> eager AdamW), the ONE-graph step (both collectives and the fused AdamW captured, round 3's default), and
+    the single-collective variants of both: all bit-identical to plain training.
+    Teardown as the reference does it (a bare ``cleanup()`` = destroy_process_group, XAI_Multimodality.py:70-71) with everything
+    still alive on purpose: the last mode's model, wrapper, optimizer, graphed step (a captured graph that CONTAINS RCCL
+    collectives) and an asynchronous reduction nobody waited for.  A teardown in that state aborted inside
+    destroy_process_group() once in round 2 (gpurun_out/r02p_gputests.txt); brainxai.cleanup() now releases what the library
+    created against the group first."""
     import os
     import socket
     import torch.distributed as dist
+    from brainxai import train as T
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     batches = [((O.seeded((4, 1, 19, 2000), 190 + i, "randn").to(DEV), O.seeded((4, 4, 32, 64), 195 + i, "rand").to(DEV)),
@@ -1127,19 +1152,22 @@ def test_overlapped_ddp_step_single_rank_matches_plain_training():
         net = brainxai.build_multimodal(19, 2000, 4, dropout=0.5, compute_dtype=torch.bfloat16).to(DEV).train()
         return net, brainxai.FlatAdamW(net.parameters(), lr=1e-3)
     finals = {}
+    graph_modes = {"pieces_graph": ("pieces", "1", "overlap"), "one_graph": ("one", "1", "ddp_one"),
+                   "single_collective_pieces": ("pieces", "0", "one"), "single_collective_one_graph": ("one", "0", "ddp_one")}
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+    step = pending = None
     try:
-        for mode in ("plain", "overlap_eager", "overlap_graph", "single_collective_graph"):
+        for mode in ("plain", "overlap_eager", "pieces_graph", "single_collective_pieces", "single_collective_one_graph", "one_graph"):
             net, opt = make(); ops.manual_seed(4321)
             ddp = brainxai.DataParallel(net) if mode != "plain" else None
-            if mode == "overlap_graph" or mode == "single_collective_graph":
-                if mode == "single_collective_graph":
-                    os.environ["BX_DDP_OVERLAP"] = "0"
-                step = brainxai.GraphedTrainStep(net, opt, crit, ddp=ddp)
-                os.environ.pop("BX_DDP_OVERLAP", None)
-                assert (step.plan is not None) == (mode == "overlap_graph")
+            if mode in graph_modes:
+                form, overlap, kind = graph_modes[mode]
+                os.environ["BX_DDP_GRAPH"], os.environ["BX_DDP_OVERLAP"] = form, overlap
+                step = brainxai.GraphedTrainStep(net, opt, crit, ddp=ddp, strict=True)
+                os.environ.pop("BX_DDP_GRAPH", None); os.environ.pop("BX_DDP_OVERLAP", None)
+                assert (step.plan is not None) == (overlap == "1")
                 losses = [float(step([e, s_], y)[0]) for (e, s_), y in batches]
-                assert len(step._graphs) == 1 and next(iter(step._graphs.values()))[0] == ("overlap" if mode == "overlap_graph" else "one")
+                assert len(step._graphs) == 1 and next(iter(step._graphs.values()))[0] == kind, mode
             elif mode == "overlap_eager":
                 assert brainxai.overlap_plan(net, opt) is not None
                 losses = [float(brainxai.train_step_overlapped(net, opt, e, s_, y, crit, ddp)[0]) for (e, s_), y in batches]
@@ -1147,16 +1175,18 @@ def test_overlapped_ddp_step_single_rank_matches_plain_training():
                 losses = [float(brainxai.train_step(net, opt, e, s_, y, crit)[0]) for (e, s_), y in batches]
             torch.cuda.synchronize()
             finals[mode] = (losses, opt.flat_p.clone())
-            opt.close()
+            if mode != "one_graph":
+                opt.close()
+        # the state that aborted in round 2, and more: nothing is dropped, one reduction is left un-waited
+        scratch = torch.ones(1 << 16, device=DEV)
+        pending = ddp.reduce_async(scratch)
+        assert step is not None and step._graphs and pending.work is not None and len(T._LIVE_REDUCTIONS) >= 1
     finally:
-        # captured graphs, the wrapper and the last step's reduction handles go before the group does (a teardown with them alive
-        # aborted inside destroy_process_group once in 6 runs of this suite), and nothing may still be queued on RCCL's stream
-        step = ddp = net = opt = None
-        import gc
-        gc.collect()
-        torch.cuda.synchronize()
-        dist.destroy_process_group()
+        brainxai.cleanup()
         ops.clear_grad_views()
+    assert not dist.is_initialized()
+    assert pending.work is None and not step._graphs and len(T._LIVE_REDUCTIONS) == 0      # released by cleanup(), not by the test
+    assert torch.equal(scratch, torch.ones_like(scratch))                                 # AVG over one rank
     for mode in finals:
         assert finals[mode][0] == finals["plain"][0], mode
         assert torch.equal(finals[mode][1], finals["plain"][1]), mode

@@ -48,9 +48,11 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"], help="f32: the split (h + m + l, six MFMAs) kernels of fp32 storage")
     a = ap.parse_args()
     kinds = a.kinds.split(",")
-    dev, dt, B = torch.device("cuda:0"), torch.bfloat16, a.batch
+    dev, dt, B = torch.device("cuda:0"), (torch.bfloat16 if a.dtype == "bf16" else torch.float32), a.batch
+    esz, nmfma = (2, 1) if a.dtype == "bf16" else (4, 6)
     tot = {k: 0.0 for k in kinds}
     print(f"{'shape':26s} {'kind':6s} {'us':>8s} {'TF/s':>8s} {'GB/s':>8s} {'hbm_us':>7s} {'mfma_us':>7s}")
     for (H, W, cin, c) in STAGES:
@@ -64,7 +66,7 @@ def main():
             pk_b = ops._pack(w, flip=True, dtype=dt)
             y = torch.randn(B, H, W, cip, device=dev).to(dt)
             flops = 2.0 * B * H * W * 9 * cip * cop
-            byts = 2.0 * B * H * W * (cip + cop)
+            byts = float(esz) * B * H * W * (cip + cop)
             mult = 2 if (ci, co) == (c, c) else 1     # the stage has two c->c convs
             for k in kinds:
                 if k == "fwd":
@@ -78,7 +80,7 @@ def main():
                     t = timed(lambda: ops._wgrad(x, dz, w, bias), a.iters)
                 tot[k] += t * mult
                 print(f"B{B} {H}x{W} {cip:3d}->{cop:3d} x{mult}   {k:6s} {t:8.1f} {flops / t * 1e-6:8.1f} {byts / t * 1e-3:8.1f} "
-                      f"{byts / 6.3e6:7.1f} {flops / 2.5e9:7.1f}")
+                      f"{byts / 6.3e6:7.1f} {nmfma * flops / 2.5e9:7.1f}")
     print("per-step totals (us):", {k: round(v, 1) for k, v in tot.items()}, "sum", round(sum(tot.values()), 1))
 
 

@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
-"""Which input seeds give a flip-free GPU forward?  For each candidate spectrogram seed the multimodal model (train mode,
-fp32 storage) runs once on the GPU with ops.keep_block_activations; its post-ReLU activations are compared with the oracle's
-fp64 trace (oracle.ref_torch.activation_flips).  Used to choose the inputs of tests/golden/mm_native_small.npz so that the
-step-0 gradient comparison is strict (see oracle/make_golden.py: MM_CASES).
+"""Which input seeds give a flip-free GPU forward?  For each candidate spectrogram seed the multimodal model (fp32 storage) runs
+once on the GPU with ops.keep_block_activations; its post-ReLU activations are compared with the oracle's fp64 trace
+(oracle.ref_torch.activation_flips).  Both fp32 convolution paths are scanned -- the matrix-core split kernels (the default since
+round 3) and the VALU kernels (BX_ALGO_DIRECT) -- and a seed qualifies when neither flips a decision.  Used to choose the inputs
+of tests/golden/mm_native_small.npz (mode `mm`: parameter seed 41, EEG seed 42, train mode) and of the attribution fixtures
+(mode `attr`: parameter seed 51, EEG seed 52, eval mode) so that their gradient comparisons are strict ones
+(oracle/make_golden.py: MM_NATIVE_SPEC_SEED, ATTR_SPEC_SEED).
 
-    python tools/flip_scan.py 37 3000 3 100 75 4 326 339 335 321 ...
+    python tools/flip_scan.py mm 37 3000 3 100 75 4 326 339 335 321 ...
+    python tools/flip_scan.py attr 19 2000 4 64 128 2 53 54 55 ...
 """
 import os
 import sys
@@ -14,26 +18,48 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import brainxai  # noqa: E402
+from brainxai import _lib as L  # noqa: E402
 from brainxai import ops  # noqa: E402
 from oracle import ref_torch as O  # noqa: E402
-from tests.golden_util import describe_flips, observed_flips  # noqa: E402
+from tests.golden_util import _nchw_acts, describe_flips  # noqa: E402
 
-chans, samples, cin, h, w, b = (int(v) for v in sys.argv[1:7])
+mode = sys.argv[1]
+chans, samples, cin, h, w, b = (int(v) for v in sys.argv[2:8])
+pseed, eseed, train = {"mm": (41, 42, True), "attr": (51, 52, False)}[mode]
+# `mm`: the fixture's test also takes three optimizer steps from the ORACLE's states after steps 3, 4, 5 of its trajectory and
+# compares the updates with the oracle's fp32 run (test_multimodal_train3, part b): those forwards must be flip-free too
+states = (0, 3, 4, 5) if mode == "mm" else (0,)
 dev = torch.device("cuda:0")
-ref = O.fill_params(O.build_multimodal(chans, samples, cin, dropout=0.0), seed=41).train()
-mine = brainxai.build_multimodal(chans, samples, cin, dropout=0.0)
-mine.load_state_dict(ref.state_dict())
-mine.to(dev).train()
-eeg = O.seeded((b, 1, chans, samples), 42, "randn")
-for seed in (int(v) for v in sys.argv[7:]):
+mine = brainxai.build_multimodal(chans, samples, cin, dropout=0.0).to(dev).train(train)
+eeg = O.seeded((b, 1, chans, samples), eseed, "randn")
+labels = torch.softmax(O.seeded((b, 6), 44, "randn"), 1)
+good = []
+for seed in (int(v) for v in sys.argv[8:]):
     spec = O.seeded((b, cin, h, w), seed, "rand")
-    keep = ops.keep_block_activations(mine)
-    mine.load_state_dict(ref.state_dict())
-    with torch.no_grad():
-        mine(eeg.to(dev), spec.to(dev))
-    torch.cuda.synchronize()
-    try:
-        flips = observed_flips(O, ref, (eeg, spec), keep, f"seed {seed}")
-        print(f"seed {seed}: {len(flips)} flips {describe_flips(flips)}", flush=True)
-    except AssertionError as exc:
-        print(f"seed {seed}: ERROR {exc}", flush=True)
+    ref = O.fill_params(O.build_multimodal(chans, samples, cin, dropout=0.0), seed=pseed).train(train)
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+    total = {"mfma": 0, "valu": 0}
+    for step in range(max(states) + 1):
+        if step in states:
+            trace = O.relu_pool_trace(ref, (eeg, spec))           # fp64, once per state
+            # the oracle's own fp32 forward (= the reference's arithmetic) must not flip either: it is what the fixture records
+            acts32 = {k: [torch.relu(z) for z in v["z"]] for k, v in O.relu_pool_trace(ref, (eeg, spec), dtype=torch.float32).items()}
+            f32, e32 = O.activation_flips(trace, acts32)
+            total["ref32"] = total.get("ref32", 0) + len(f32) + 1000 * len(e32)
+            print(f"seed {seed} state {step} reference fp32: {len(f32)} flips {describe_flips(f32)}", flush=True)
+            for name, algo in (("mfma", L.BX_ALGO_AUTO), ("valu", L.BX_ALGO_DIRECT)):
+                ops.CONV_ALGO = ops.WGRAD_ALGO = algo
+                keep = ops.keep_block_activations(mine)
+                mine.load_state_dict(ref.state_dict())
+                with torch.no_grad():
+                    mine(eeg.to(dev), spec.to(dev))
+                torch.cuda.synchronize()
+                flips, errors = O.activation_flips(trace, _nchw_acts(keep, trace))
+                total[name] += len(flips) + 1000 * len(errors)
+                print(f"seed {seed} state {step} {name}: {len(flips)} flips {describe_flips(flips)}" + (f" ERRORS {describe_flips(errors)}" if errors else ""), flush=True)
+            ops.CONV_ALGO = ops.WGRAD_ALGO = L.BX_ALGO_AUTO
+        if step < max(states):
+            O.train_step(ref, opt, eeg, spec, labels)
+    if not any(total.values()):
+        good.append(seed)
+print("flip-free on both fp32 paths and in the reference's fp32 run:", good)
