@@ -317,8 +317,20 @@ def main():
         for _ in range(6):
             ballast[1].copy_(ballast[0], non_blocking=True)
         step()
+    # What an event pair adds to the kernel it brackets: the same bracket around NOTHING, under the same ballast (the interval then
+    # holds the two timestamp packets' own processing; a bracketed kernel's interval holds that plus the kernel).  The median over
+    # 200 empty brackets is subtracted from every measured interval below -- with it the family's time agrees with the rocprofv3
+    # kernel trace of the replayed step (profiles/*_step_timeline.txt), without it every launch reads ~3 us long.
+    empties = []
+    for _ in range(6):
+        ballast[1].copy_(ballast[0], non_blocking=True)
+    for _ in range(200):
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record(); eb.record()
+        empties.append((ea, eb))
     del ballast
     sync()
+    ev_overhead = sorted(a_.elapsed_time(b_) for a_, b_ in empties)[len(empties) // 2] * 1e-3          # seconds
     ops.CONV_PROFILE = None
     stepper.enabled = was_enabled
 
@@ -329,7 +341,7 @@ def main():
     dbytes = 2 if args.dtype == "bf16" else 4
     mfma_per_product = 1 if args.dtype == "bf16" else 6      # fp32 storage: six bf16 MFMAs per product (csrc/conv3x3_split.hip)
     for kind, ev0, ev1, meta in prof:
-        dt_s = ev0.elapsed_time(ev1) * 1e-3
+        dt_s = max(ev0.elapsed_time(ev1) * 1e-3 - ev_overhead, 0.0)
         kinds.setdefault(kind, []).append(dt_s)
         form, mb, mh, mw, ci, co = meta
         px = mb * mh * mw
@@ -379,9 +391,11 @@ def main():
                                         "share_of_step": round(dom[0] / prof_steps / (elapsed / args.steps), 4),
                                         "algorithmic_bytes": round(dom[2]), "hbm_frac": round(dom[2] / dom_t / 1e9 / HBM_PEAK_GBS, 4),
                                         "mfma_frac": round(dom[3] / dom_t / 1e12 / peak_tf, 4)},
+                    "event_pair_overhead_us": round(ev_overhead * 1e6, 2),
                     "timing": "HIP events around every convolution launch of %d eagerly launched steps right after the timed region -- the "
                               "launches the timed region replays, fused ones included (conv1 + conv2 pairs, conv3 with the pooled epilogue "
-                              "bracketed inside the library call)" % prof_steps}
+                              "bracketed inside the library call); the interval of an EMPTY event pair (event_pair_overhead_us, median of 200) "
+                              "is subtracted from every interval" % prof_steps}
         extra["roofline_mfma"] = {"achieved": round(ach_tf, 2), "peak": round(peak_tf, 1), "unit": "TFLOP/s",
                                   "frac": round(ach_tf / peak_tf, 5),
                                   "note": None if mfma_per_product == 1 else "fp32-storage FLOPs; each runs as 6 bf16 MFMA products, peak = 2500 / 6"}

@@ -254,63 +254,144 @@ def test_config0_spectrogram_model_alone():
 
 
 def test_config4_integrated_gradients_at_full_size():
-    """configs[4]: integrated gradients, 50 steps x B=64, zero baselines, at the benchmark's shapes and storage (bf16).
-    (a) size-independent property, every sample: completeness -- the attributions of a sample sum to F_c(x) - F_c(baseline), F_c the
-        target class's log-probability (50-node Gauss-Legendre quadrature of a piecewise-smooth integrand plus bf16-stored
-        activations: observed 3.5 % of the largest |F_c(x) - F_c(0)| of the batch, printed; bound 6 % -- a mis-scaled or missing
-        gradient path shows up as tens of percent; the sharp comparison is (c));
+    """configs[4]: integrated gradients, 50 steps x B=64, zero baselines, at the benchmark's shapes.
+    (a) completeness, every sample, bf16 storage (the benchmarked dtype) and fp32 storage: the attributions of a sample sum to
+        F_c(x) - F_c(baseline), F_c the target class's log-probability, up to the error of the 50-node Gauss-Legendre rule on a
+        piecewise-smooth integrand.  That quadrature error is MEASURED, not guessed: part (c) evaluates the same rule in fp64
+        (decision-matched twin) for two samples -- gaps 0.120 and 0.035 of |dF| = 5.48, i.e. 2.2e-2 and 6e-3 -- and the fp32 path
+        must reproduce the twin's gap to 1e-3 of |dF| on those samples (observed 1e-4).  Over the 64 samples the largest gap is
+        4.2e-2 (fp32) / 3.1e-2 (bf16) of the batch's largest |dF|: the rule's error, of either sign, not the storage type's; both
+        are held to 6e-2 (a mis-scaled or missing gradient path shows up as tens of percent).
     (b) what the sharded sweep computes for a rank's shard equals the rows of the one-shot result (shard_bounds arithmetic on the GPU);
-    (c) fp32 storage: the gradients the rule sums (sample 0 at eight of its 50 nodes) strictly (1e-3) against the decision-matched
-        fp64 twin; the attributions of two samples against the oracle's fp32 and fp64 integrated gradients (reported; 3e-3)."""
+    (c) fp32 storage, the WHOLE attribution of two samples: the gradient at every one of the 50 nodes strictly (1e-3) against the
+        fp64 twin whose ReLU / max-pool decisions are pinned to that very forward's (every disagreement a demonstrated tie), the
+        twin's gradients summed with the rule's weights, and ``integrated_gradients``' output held to 1e-3 of that (round 2 compared
+        the attribution with the oracle's own fp32 / fp64 runs -- unmatched decisions on both sides -- and had to allow 3e-3;
+        those figures are still printed)."""
     eeg, spec, _ = _bench_inputs()
     ref, mine = _models(29, torch.bfloat16)
     mine.eval()
     e, s = eeg.to(DEV), spec.to(DEV)
-    ie, is_ = brainxai.integrated_gradients(mine, (e, s), None, n_steps=50)
-    with torch.no_grad():
-        fx = mine(e, s)
-        f0 = mine(torch.zeros_like(e), torch.zeros_like(s))
-    tgt = fx.argmax(1)
-    delta = (fx.gather(1, tgt[:, None]) - f0.gather(1, tgt[:, None]))[:, 0].double().cpu()
-    total = (ie.double().flatten(1).sum(1) + is_.double().flatten(1).sum(1)).cpu()
-    gap = float((total - delta).abs().max()) / float(delta.abs().max())
-    print(f"config4: completeness gap {gap:.3e} of max |dF| {float(delta.abs().max()):.3f}")
-    assert gap < 6e-2, gap
+    ref32, mine32 = _models(29, torch.float32)
+    ref32.eval(); mine32.eval()
+
+    def completeness(model):
+        ie_, is__ = brainxai.integrated_gradients(model, (e, s), None, n_steps=50)
+        with torch.no_grad():
+            fx = model(e, s)
+            f0 = model(torch.zeros_like(e), torch.zeros_like(s))
+        tgt = fx.argmax(1)
+        delta = (fx.gather(1, tgt[:, None]) - f0.gather(1, tgt[:, None]))[:, 0].double().cpu()
+        total = (ie_.double().flatten(1).sum(1) + is__.double().flatten(1).sum(1)).cpu()
+        return ie_, is__, total - delta, delta, tgt
+    ie, is_, gap16, delta16, tgt16 = completeness(mine)
+    je_all, js_all, gap32, delta32, tgt32 = completeness(mine32)
+    dmax = float(delta32.abs().max())
+    same = (tgt16 == tgt32).cpu()                                        # a near-tie of two classes can pick another target in bf16
+    print(f"config4: completeness gap / max |dF| ({dmax:.3f}): bf16 {float(gap16.abs().max()) / dmax:.3e}, fp32 {float(gap32.abs().max()) / dmax:.3e}; "
+          f"{int(same.sum())} of {B} samples share the target class, largest bf16 - fp32 gap difference among them {float((gap16 - gap32)[same].abs().max()) / dmax:.3e}")
+    assert int(same.sum()) >= B - 4
+    assert float(gap16.abs().max()) < 6e-2 * dmax and float(gap32.abs().max()) < 6e-2 * dmax
     lo, hi = brainxai.shard_bounds(B, 3, 8)                             # rank 3 of 8: samples [24, 32)
     assert (lo, hi) == (24, 32)
     lo_, shard = brainxai.sharded_sweep(lambda a, b: brainxai.integrated_gradients(mine, (a, b), None, n_steps=50)[1], hi - lo, hi - lo,
                                         lambda l, h: (e[lo + l:lo + h], s[lo + l:lo + h]), gather=False)
     assert lo_ == 0 and rel_err(shard.cpu(), is_[lo:hi].cpu()) < 1e-3   # evaluation mode: a sample does not see its batch; only the order of the step sums differs
-    ref32, mine32 = _models(29, torch.float32)
-    ref32.eval(); mine32.eval()
-    # (c) the gradient evaluations the rule sums: sample 0 at eight of the 50 nodes, one batch, strict against the fp64 twin
+    # (c) every gradient evaluation the rule sums for samples 0 and 1, strict against the decision-matched fp64 twin, ten nodes at a time
     from brainxai.explain import _eval_frozen, ig_nodes
-    alphas, _ = ig_nodes(50)
-    sel = [0, 7, 14, 21, 28, 35, 42, 49]
-    xe_k = torch.stack([float(alphas[k]) * eeg[0] for k in sel])
-    xs_k = torch.stack([float(alphas[k]) * spec[0] for k in sel])
-    with torch.no_grad():
-        cls = int(mine32(e[:1], s[:1]).argmax(1))
-    onehot = F.one_hot(torch.full((len(sel),), cls), 6).float()
-    keep = ops.keep_block_activations(mine32)
-    try:
-        with _eval_frozen(mine32):
-            ek, sk = xe_k.to(DEV).requires_grad_(True), xs_k.to(DEV).requires_grad_(True)
-            ge, gs = torch.autograd.grad(mine32(ek, sk), (ek, sk), grad_outputs=onehot.to(DEV))
-        torch.cuda.synchronize()
-        twin, flips = matched_oracle(O, ref32, (xe_k, xs_k), keep, "config4")
-    finally:
-        ops.keep_block_activations(mine32, on=False)
-    ed, sd = xe_k.double().requires_grad_(True), xs_k.double().requires_grad_(True)
-    we, ws_ = torch.autograd.grad(twin(ed, sd), (ed, sd), grad_outputs=onehot.double())
-    grad_close(ge.cpu(), we, TOL, label="config4 d eeg at the rule's nodes", flips=flips)
-    grad_close(gs.cpu(), ws_, TOL, label="config4 d spec at the rule's nodes", flips=flips)
-    # the attribution itself, two samples, against the oracle's own integrated gradients in fp32 and in fp64: unmatched decisions on
-    # both sides (DESIGN section 2), so the figures are reported and held to 3e-3; the strict statement is the one above
-    je, js = brainxai.integrated_gradients(mine32, (e[:2], s[:2]), None, n_steps=50)
+    alphas, wts = ig_nodes(50)
+    NS, CH = 2, 10
+    tw_e, tw_s = torch.zeros(NS, *eeg.shape[1:], dtype=torch.float64), torch.zeros(NS, *spec.shape[1:], dtype=torch.float64)
+    nflips = 0
+    for i in range(NS):
+        cls = int(tgt32[i])
+        for c0 in range(0, 50, CH):
+            ks = list(range(c0, c0 + CH))
+            xe_k = torch.stack([float(alphas[k]) * eeg[i] for k in ks])
+            xs_k = torch.stack([float(alphas[k]) * spec[i] for k in ks])
+            onehot = F.one_hot(torch.full((CH,), cls), 6).float()
+            keep = ops.keep_block_activations(mine32)
+            try:
+                with _eval_frozen(mine32):
+                    ek, sk = xe_k.to(DEV).requires_grad_(True), xs_k.to(DEV).requires_grad_(True)
+                    ge, gs = torch.autograd.grad(mine32(ek, sk), (ek, sk), grad_outputs=onehot.to(DEV))
+                torch.cuda.synchronize()
+                twin, flips = matched_oracle(O, ref32, (xe_k, xs_k), keep, f"config4 sample {i} nodes {c0}..{c0 + CH - 1}")
+            finally:
+                ops.keep_block_activations(mine32, on=False)
+            nflips += len(flips)
+            ed, sd = xe_k.double().requires_grad_(True), xs_k.double().requires_grad_(True)
+            we, ws_ = torch.autograd.grad(twin(ed, sd), (ed, sd), grad_outputs=onehot.double())
+            grad_close(ge.cpu(), we, TOL, label=f"config4 d eeg, sample {i}, nodes {c0}..", flips=flips)
+            grad_close(gs.cpu(), ws_, TOL, label=f"config4 d spec, sample {i}, nodes {c0}..", flips=flips)
+            for j, k in enumerate(ks):
+                tw_e[i] += float(wts[k]) * we[j]
+                tw_s[i] += float(wts[k]) * ws_[j]
+    tw_e, tw_s = tw_e * eeg[:NS].double(), tw_s * spec[:NS].double()          # zero baselines: (x - x') = x
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    mx = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    je, js = je_all[:NS].cpu(), js_all[:NS].cpu()
+    d_twin = (l2(je, tw_e), l2(js, tw_s), mx(je, tw_e), mx(js, tw_s))
+    print(f"config4: integrated_gradients (fp32 storage) vs the decision-matched fp64 attribution, {NS} samples x 50 nodes, {nflips} pinned ties: "
+          f"rel-L2 eeg {d_twin[0]:.2e} spec {d_twin[1]:.2e}; max-abs on the largest entry eeg {d_twin[2]:.2e} spec {d_twin[3]:.2e}")
+    assert max(d_twin) < TOL, d_twin
+    # the rule's own error (completeness gap of the fp64 twin attribution) is what the fp32 path must show on these samples
+    gap_twin = (tw_e.flatten(1).sum(1) + tw_s.flatten(1).sum(1)) - delta32[:NS]
+    print(f"config4: quadrature gap of the 50-node rule in fp64 (samples 0..{NS - 1}): {[f'{float(v):.4f}' for v in gap_twin]}; fp32 path: "
+          f"{[f'{float(v):.4f}' for v in gap32[:NS]]}  (|dF| {[f'{float(v):.3f}' for v in delta32[:NS]]})")
+    assert float((gap_twin - gap32[:NS]).abs().max()) < TOL * dmax
+    # for the record: the same attribution against the oracle's OWN fp32 and fp64 runs (unmatched decisions on both sides)
     oe, os_ = O.integrated_gradients(ref32, (eeg[:2], spec[:2]), n_steps=50)
     xe, xs = O.integrated_gradients(copy.deepcopy(ref32).double(), (eeg[:2].double(), spec[:2].double()), n_steps=50)
-    l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
-    d_hip, d_ref = (l2(je.cpu(), xe), l2(js.cpu(), xs)), (l2(oe, xe), l2(os_, xs))
+    d_hip, d_ref = (l2(je, xe), l2(js, xs)), (l2(oe, xe), l2(os_, xs))
     print(f"config4: rel-L2 to the fp64 oracle -- HIP fp32: eeg {d_hip[0]:.2e} spec {d_hip[1]:.2e}; oracle fp32: eeg {d_ref[0]:.2e} spec {d_ref[1]:.2e}")
-    assert d_hip[0] < TOL and d_hip[1] < 3e-3, (d_hip, d_ref)
+    assert d_hip[0] < TOL and d_hip[1] < 2e-3, (d_hip, d_ref)
+
+
+def test_bf16_gradcam_sweep_against_fp32_oracle():
+    """The maps the benchmarked Grad-CAM sweep (configs[3]) produces -- bf16 storage, exactly GradCamSweep's launches: pair kernels
+    without the conv1 store, collapsed EEG evaluation path, bx_gradcam_head_sweep -- against ``O.grad_cam`` on the fp32 oracle, and
+    the fp32-storage sweep beside it (every Grad-CAM parity test ran fp32 storage, the benchmarked maps' error was
+    unquantified).  16 samples x 6 classes at the benchmark's [4,128,256] / [1,19,2000].
+
+    Derived bound.  A map is raw[p] = sum_c w_c A[p,c] over the 256 channels of block5's output A.  bf16 storage rounds every stored
+    activation of the 15 convolution layers and 5 stage outputs to 8 significand bits (2^-9 relative, round to nearest): A arrives
+    with a relative error of ~sqrt(20) 2^-9 = 9e-3 of its scale at worst, 4e-3 observed (asserted: 2^-7).  The channel sum CANCELS:
+    at random initialisation max_p sum_c |w_c A_c| is ~40 x max |raw|, so an error of eps in A is an error of up to
+    eps * max_p sum_c |w_c A_c| in the map -- on the scale of the largest pre-ReLU map value that is eps x the cancellation ratio
+    R (computed here from the oracle's own parts).  Asserted: err <= 2^-7 R (the worst case, errors of one sign) and, as the
+    regression guard, err <= 2^-7 sqrt(R) x 3 (errors of random sign add in quadrature: observed 1.8e-2 at R = 38).
+    north_star's 1e-3 belongs to fp32 storage: asserted for the fp32 sweep (observed 3e-6)."""
+    g = torch.Generator().manual_seed(4242)
+    n = 16
+    spec = torch.rand(n, CIN, H, W, generator=g)
+    eeg = torch.randn(n, 1, CHANS, T, generator=g)
+    ref = O.fill_params(O.build_multimodal(CHANS, T, CIN, dropout=0.0), seed=5).eval()
+    cam_o, raw_o, w_o, A_o, out_o = O.grad_cam(ref, eeg, spec, "spectrogram_model.block5", "all", upsample=False, return_parts=True)
+    up_o = O.grad_cam(ref, eeg, spec, class_idx="all")                                   # [16, 6, 128, 256]
+    scale = float(raw_o.abs().max())
+    ratio = float((w_o.abs()[:, :, :, None, None] * A_o.abs()[:, None]).sum(2).max()) / scale
+    errs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        mine = brainxai.build_multimodal(CHANS, T, CIN, dropout=0.0, compute_dtype=dt)
+        mine.load_state_dict(ref.state_dict())
+        mine.to(DEV).eval()
+        e, s = eeg.to(DEV), spec.to(DEV)
+        small = brainxai.GradCamSweep(mine, e, s, class_idx="all", upsample=False)(e, s).float().cpu()
+        up = brainxai.GradCamSweep(mine, e, s, class_idx="all")(e, s).float().cpu()
+        assert small.shape == cam_o.shape and up.shape == up_o.shape == (n, 6, H, W)
+        _, _, _, A, _ = brainxai.grad_cam(mine, e, s, "spectrogram_model.block5", "all", upsample=False, return_parts=True)
+        A = A.float().cpu()
+        if A.shape != A_o.shape:
+            A = A.permute(0, 3, 1, 2)
+        errs[dt] = (float((small.double() - cam_o.double()).abs().max()) / scale, float((up.double() - up_o.double()).abs().max()) / scale,
+                    float((A.double() - A_o.double()).abs().max() / A_o.double().abs().max()))
+    torch.cuda.synchronize()
+    print(f"Grad-CAM sweep vs fp32 oracle on the raw-map scale (cancellation ratio R = {ratio:.1f}): "
+          f"bf16 maps {errs[torch.bfloat16][0]:.2e} (upsampled {errs[torch.bfloat16][1]:.2e}, block5 output {errs[torch.bfloat16][2]:.2e}); "
+          f"fp32 maps {errs[torch.float32][0]:.2e} (upsampled {errs[torch.float32][1]:.2e}, block5 output {errs[torch.float32][2]:.2e})")
+    assert max(errs[torch.float32][:2]) < TOL and errs[torch.float32][2] < 1e-5
+    eps = 2.0 ** -7
+    assert errs[torch.bfloat16][2] < eps
+    assert max(errs[torch.bfloat16][:2]) < eps * ratio
+    assert max(errs[torch.bfloat16][:2]) < 3 * eps * ratio ** 0.5

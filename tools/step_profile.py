@@ -18,19 +18,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(steps):
+def run(steps, dtype="bf16", ddp=False):
     import torch
     import brainxai
     dev = torch.device("cuda", 0)
+    wrap = None
+    if ddp:                                 # the data-parallel step on a 1-rank RCCL group (one graph: collectives + AdamW captured)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     torch.manual_seed(42)
     B = 64
     g = torch.Generator().manual_seed(42)
     spec = torch.rand(B, 4, 128, 256, generator=g).to(dev)
     eeg = torch.randn(B, 1, 19, 2000, generator=g).to(dev)
     labels = torch.nn.functional.one_hot(torch.randint(0, 6, (B,), generator=g), 6).float().to(dev)
-    model = brainxai.build_multimodal(19, 2000, 4, dropout=0.5, compute_dtype=torch.bfloat16).to(dev).train()
+    model = brainxai.build_multimodal(19, 2000, 4, dropout=0.5, compute_dtype=torch.bfloat16 if dtype == "bf16" else torch.float32).to(dev).train()
+    if ddp:
+        wrap = brainxai.DataParallel(model)
     opt = brainxai.FlatAdamW(model.parameters(), lr=1e-3)
-    stepper = brainxai.GraphedTrainStep(model, opt, brainxai.KLDivLoss(), adopt_inputs=True)   # the resident batch IS the static input
+    stepper = brainxai.GraphedTrainStep(model, opt, brainxai.KLDivLoss(), ddp=wrap, adopt_inputs=True, strict=True)   # the resident batch IS the static input
     for _ in range(3):                      # eager, capture, first replay
         stepper((eeg, spec), labels)
     torch.cuda.synchronize()
@@ -41,6 +48,8 @@ def run(steps):
     e1.record()
     torch.cuda.synchronize()
     print(f"steps {steps}  ms/step {e0.elapsed_time(e1) / steps:.4f}  loss {float(loss):.5f}")
+    if ddp:
+        brainxai.cleanup()
 
 
 def run_gradcam(steps):
@@ -202,6 +211,8 @@ if __name__ == "__main__":
     ap.add_argument("--timeline", default=None, metavar="DIR")
     ap.add_argument("--delim", default="k_adamw", help="kernel-name prefix of the launch that closes a step (timeline mode)")
     ap.add_argument("--gradcam", action="store_true", help="run the configs[3] Grad-CAM sweep batches instead of training steps")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"], help="activation storage type of the profiled step")
+    ap.add_argument("--ddp", action="store_true", help="profile the data-parallel step on a 1-rank RCCL group")
     a = ap.parse_args()
     if a.timeline:
         timeline(a.timeline, a.steps, a.delim)
@@ -214,4 +225,4 @@ if __name__ == "__main__":
     elif a.gradcam:
         run_gradcam(a.steps)
     else:
-        run(a.steps)
+        run(a.steps, a.dtype, a.ddp)
