@@ -265,17 +265,52 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
-    # ---- the same step with the stacker in the loop (SURVEY 8(d) "end-to-end" figure): raw EEG [64,10000,19] -> stack -> step
+    # ---- the same step with the stackers in the loop and the inputs starting in HOST memory (SURVEY 8(d) "end-to-end" figure):
+    # brainxai.StagingRing -- three pinned host slots, H2D on a copy stream, both GPU stackers on a prep stream, the step on this
+    # stream; raw EEG [64,10000,19] + raw spectrogram values [64,320,400] = 81 MB cross PCIe per batch.  The pinned slots are filled
+    # once (decoding parquet into them is the DataLoader workers' job and is not what this figure measures); every step re-sends one.
+    raw_h, sraw_h = raw.cpu(), sraw.cpu()
+    ring = brainxai.StagingRing({"eeg": (B, RAW_LEN, CHANS), "spec": (B, 320, 400)},
+                                transform=lambda d: (brainxai.stack_eeg(d["eeg"]), brainxai_stack_regions(d["spec"])), slots=3, device=dev)
+
+    def feed(fill):
+        sl = ring.acquire()
+        if fill:
+            sl.host["eeg"].copy_(raw_h); sl.host["spec"].copy_(sraw_h)
+        ring.submit(sl)
+    for _ in range(3):
+        feed(True)
+
     def e2e():
-        inputs[0].copy_(brainxai.stack_eeg(raw))
-        inputs[1].copy_(brainxai_stack_regions(sraw))
-        step()
+        batch = ring.pop()
+        stepper(list(batch.outputs), labels)            # device-to-device copy into the graph's static inputs, then the replay
+        ring.release(batch)
+        feed(False)
     e2e()
     e2e_n = min(args.steps, 50)
     e2e_elapsed = all_max(timed(e2e, e2e_n, sync))
     extra["end_to_end_samples_per_sec"] = round(world * B * e2e_n / e2e_elapsed, 1)
-    extra["end_to_end_note"] = ("raw EEG [64,10000,19] -> GPU stacker, raw spectrogram values [64,320,400] -> GPU region stacker, then the "
-                                "training step; one stream, nothing overlapped")
+    # the PCIe leg alone: one slot's host -> device copies
+    sl = ring.slots[0]
+    e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync(); e0_.record()
+    for _ in range(5):
+        for name, host in sl.host.items():
+            sl.dev[name].copy_(host, non_blocking=True)
+    e1_.record(); sync()
+    h2d_bytes = sum(t.numel() * t.element_size() for t in sl.host.values())
+    extra["end_to_end_note"] = ("inputs start in pinned host memory: raw EEG [64,10000,19] + raw spectrogram values [64,320,400] (%.1f MB per batch) -> H2D on a "
+                                "copy stream (measured alone: %.1f GB/s) -> GPU stackers on a prep stream -> the training step; three slots in flight "
+                                "(brainxai.StagingRing)" % (h2d_bytes / 1e6, 5 * h2d_bytes / (e0_.elapsed_time(e1_) * 1e-3) / 1e9))
+    extra["end_to_end_frac_of_resident"] = round(extra["end_to_end_samples_per_sec"] / value, 4)
+    # for comparison: everything on one stream, inputs already on the device (round 2's figure)
+    def e2e_one_stream():
+        inputs[0].copy_(brainxai.stack_eeg(raw))
+        inputs[1].copy_(brainxai_stack_regions(sraw))
+        step()
+    e2e_one_stream()
+    extra["end_to_end_one_stream_device_inputs_samples_per_sec"] = round(world * B * e2e_n / all_max(timed(e2e_one_stream, e2e_n, sync)), 1)
+    del ring
 
     # ---- the parity-grade path beside the headline: fp32 STORAGE (logits / loss / Grad-CAM maps within 1e-3 of the fp32 oracle,
     # gradients within 1e-3 of the decision-matched fp64 twin at this very configuration: tests/test_gpu_bench_config.py), its

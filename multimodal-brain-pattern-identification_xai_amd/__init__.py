@@ -9,7 +9,7 @@ from .models import (Attention, Block, EEGNet, EEGNetAttentionDeep, KLDivLoss, M
 from .explain import (GradCamSweep, expected_gradients, generate_saliency_maps, grad_cam, integrated_gradients, saliency,   # noqa: F401
                       predict_fn, shard_bounds, sharded_sweep)
 from .data import (EEGStacker, stack_eeg, EEGMontageStacker, stack_eeg_montage,          # noqa: F401
-                   SpectrogramPreprocessor, preprocess_spectrograms, SpectrogramRegionStacker, stack_spectrogram_regions)                                        # noqa: F401
+                   SpectrogramPreprocessor, preprocess_spectrograms, SpectrogramRegionStacker, stack_spectrogram_regions, StagingRing)                                        # noqa: F401
 from .train import (FlatAdamW, DataParallel, GraphedTrainStep, AsyncCheckpointer, train_and_validate_combined, train_and_validate_eeg_distributed,   # noqa: F401
                     train_step, train_step_overlapped, overlap_plan, setup, cleanup, create_ddp_model, l2_penalty_, load_checkpoint, load_checkpoint_distributed,
                     save_checkpoint)

@@ -169,31 +169,36 @@ __device__ __forceinline__ int sr_mirror(int i, int n) {     // numpy 'reflect' 
   i %= period;
   return i > n - 1 ? period - i : i;
 }
-// stats[b] = {nanmean, min, max} of the windowed sample (zero padding included, NaNs replaced by the nanmean)
-__global__ __launch_bounds__(256) void k_specreg_stats(const float* __restrict__ raw, const int* __restrict__ offsets, double* __restrict__ stats,
+// Statistics of the windowed sample (zero padding included, NaNs set aside): SR_SPLIT workgroups per sample each take a band of
+// the window's rows and leave {sum, count, min, max} of its finite values in part[(b * SR_SPLIT + p) * 4 ..]; the resize kernel's
+// workgroups combine the SR_SPLIT partials of their sample in band order (specreg_stats_of).  Round 2 ran ONE workgroup per sample
+// with a 64-bit division per element: 120 us per B=64 batch for 31 MB -- longer than the resize itself and, in the overlapped
+// end-to-end step (brainxai.StagingRing), time the GPU-bound training step has to share.
+#define SR_SPLIT 8
+__global__ __launch_bounds__(256) void k_specreg_stats(const float* __restrict__ raw, const int* __restrict__ offsets, double* __restrict__ part,
                                                        int Trows, int C, int win) {
-  __shared__ double ssum[256], smin[256], smax[256];
-  __shared__ long long scnt[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ double ssum[256], smin[256], smax[256], scnt[256];
+  const int p = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int o = offsets ? offsets[b] / 2 : 0;
   const float* src = raw + (size_t)b * Trows * C;
-  double sum = 0.0, mn = INFINITY, mx = -INFINITY;
-  long long cnt = 0;
-  const long long n = (long long)win * C;
-  for (long long i0 = tid; i0 < n; i0 += 256 * 8) {
-    float v[8];
+  const int j0 = (int)((long long)win * p / SR_SPLIT), j1 = (int)((long long)win * (p + 1) / SR_SPLIT);
+  double sum = 0.0, mn = INFINITY, mx = -INFINITY, cnt = 0.0;
+  for (int c = tid; c < C; c += 256) {
+    for (int ja = j0; ja < j1; ja += 8) {                 // eight rows in flight (clamped, unconditional loads)
+      float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const long long i = i0 + (long long)u * 256;
-      const int j = (int)(i / C), c = (int)(i - (long long)j * C);
-      const bool live = i < n && o + j >= 0 && o + j < Trows;
-      v[u] = live ? src[(size_t)(o + j) * C + c] : 0.f;
-    }
+      for (int u = 0; u < 8; ++u) {
+        int t = o + ja + u;
+        t = t < 0 ? 0 : (t >= Trows ? Trows - 1 : t);
+        v[u] = src[(size_t)t * C + c];
+      }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (i0 + (long long)u * 256 >= n) continue;
-      const double d = (double)v[u];
-      if (d == d) { sum += d; ++cnt; mn = fmin(mn, d); mx = fmax(mx, d); }
+      for (int u = 0; u < 8; ++u) {
+        const int j = ja + u, t = o + j;
+        if (j >= j1) continue;
+        const double d = (t >= 0 && t < Trows) ? (double)v[u] : 0.0;        // rows outside the recording are zero padding
+        if (d == d) { sum += d; cnt += 1.0; mn = fmin(mn, d); mx = fmax(mx, d); }
+      }
     }
   }
   ssum[tid] = sum; scnt[tid] = cnt; smin[tid] = mn; smax[tid] = mx;
@@ -203,12 +208,25 @@ __global__ __launch_bounds__(256) void k_specreg_stats(const float* __restrict__
     __syncthreads();
   }
   if (tid == 0) {
-    const double mean = scnt[0] ? ssum[0] / (double)scnt[0] : 0.0;
-    double lo = smin[0], hi = smax[0];
-    if (scnt[0] < n) { lo = fmin(lo, mean); hi = fmax(hi, mean); }      // the fill value takes part in the min-max
-    if (!scnt[0]) { lo = hi = 0.0; }
-    stats[b * 3 + 0] = mean; stats[b * 3 + 1] = lo; stats[b * 3 + 2] = hi;
+    double* dst = part + ((size_t)b * SR_SPLIT + p) * 4;
+    dst[0] = ssum[0]; dst[1] = scnt[0]; dst[2] = smin[0]; dst[3] = smax[0];
   }
+}
+// {nanmean, min, max} of sample b from its SR_SPLIT partials, in band order (every thread of every resize workgroup recomputes it:
+// 32 doubles from L2)
+__device__ __forceinline__ void specreg_stats_of(const double* __restrict__ part, int b, double n, double& mean, double& lo, double& hi) {
+  double v[SR_SPLIT][4];
+#pragma unroll
+  for (int p = 0; p < SR_SPLIT; ++p)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[p][k] = part[((size_t)b * SR_SPLIT + p) * 4 + k];
+  double sum = 0.0, cnt = 0.0;
+  lo = INFINITY; hi = -INFINITY;
+#pragma unroll
+  for (int p = 0; p < SR_SPLIT; ++p) { sum += v[p][0]; cnt += v[p][1]; lo = fmin(lo, v[p][2]); hi = fmax(hi, v[p][3]); }
+  mean = cnt > 0.0 ? sum / cnt : 0.0;
+  if (cnt < n) { lo = fmin(lo, mean); hi = fmax(hi, mean); }          // the fill value takes part in the min-max
+  if (!(cnt > 0.0)) { lo = hi = 0.0; }
 }
 __global__ __launch_bounds__(256) void k_specreg_resize(const float* __restrict__ raw, const int* __restrict__ offsets, const double* __restrict__ stats,
                                                         float* __restrict__ out, int Trows, int C, int win, int bins, int Ho, int Wo,
@@ -221,7 +239,8 @@ __global__ __launch_bounds__(256) void k_specreg_resize(const float* __restrict_
   if (oy >= Ho || ox >= Wo) return;
   const int o = offsets ? offsets[b] / 2 : 0;
   const float* src = raw + (size_t)b * Trows * C + (size_t)r * bins;
-  const double mean = stats[b * 3], lo = stats[b * 3 + 1], hi = stats[b * 3 + 2];
+  double mean, lo, hi;
+  specreg_stats_of(stats, b, (double)win * (double)C, mean, lo, hi);
   auto at = [&](int f, int j) -> double {                      // filled, un-normalised sample: frequency bin f of region r, time j of the window
     const int t = o + j;
     if (t < 0 || t >= Trows) return 0.0;
@@ -247,7 +266,7 @@ __global__ __launch_bounds__(256) void k_specreg_resize(const float* __restrict_
   out[(((size_t)b * gridDim.y + r) * Ho + oy) * Wo + ox] = (float)((v - lo) / (hi - lo + eps));
 }
 
-extern "C" size_t bx_spec_regions_workspace(int B) { return (size_t)B * 3 * sizeof(double) + 256; }
+extern "C" size_t bx_spec_regions_workspace(int B) { return (size_t)B * SR_SPLIT * 4 * sizeof(double) + 256; }
 extern "C" int bx_spec_regions(const float* raw, const int* offsets, float* out, int B, int Trows, int C, int regions, int win, int Ho, int Wo,
                                const double* gauss_y, int radius_y, const double* gauss_x, int radius_x, float eps, void* workspace,
                                size_t workspace_bytes, bxStream stream) {
@@ -261,7 +280,7 @@ extern "C" int bx_spec_regions(const float* raw, const int* offsets, float* out,
   for (int i = 0; i < 2 * SR_MAX_RADIUS + 1; ++i) { k.gy[i] = radius_y && i <= 2 * radius_y ? gauss_y[i] : (i == 0 ? 1.0 : 0.0); k.gx[i] = radius_x && i <= 2 * radius_x ? gauss_x[i] : (i == 0 ? 1.0 : 0.0); }
   double* stats = reinterpret_cast<double*>(bx_align_up((uintptr_t)workspace, 8));
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_specreg_stats, dim3(B), dim3(256), 0, s, raw, offsets, stats, Trows, C, win);
+  hipLaunchKernelGGL(k_specreg_stats, dim3(SR_SPLIT, B), dim3(256), 0, s, raw, offsets, stats, Trows, C, win);
   const int bins = C / regions;
   const int tiles = ((Ho + 15) / 16) * ((Wo + 15) / 16);
   hipLaunchKernelGGL(k_specreg_resize, dim3(tiles, regions, B), dim3(256), 0, s, raw, offsets, (const double*)stats, out, Trows, C, win, bins, Ho, Wo, k,

@@ -113,3 +113,36 @@ def test_async_checkpointer_host_logic(tmp_path):
     bad.save(state)
     with pytest.raises(RuntimeError, match="asynchronous checkpoint"):
         bad.wait()
+
+
+def test_staging_ring_slot_logic():
+    """brainxai.StagingRing on a CPU device (synchronous backend): the slot state machine and FIFO order the GPU pipeline relies on
+    -- a slot is handed out only when free, cannot be submitted twice, comes back in submission order, and its outputs are the
+    transform of the data that was in the pinned buffers at submit()."""
+    import torch
+    import brainxai
+    ring = brainxai.StagingRing({"a": (2, 3), "b": (4,)}, transform=lambda d: (d["a"] * 2, d["b"] + 1), slots=3, device="cpu")
+    s0, s1, s2 = ring.acquire(), ring.acquire(), ring.acquire()
+    assert {s0.index, s1.index, s2.index} == {0, 1, 2} and ring.acquire() is None          # every slot is filling
+    for k, sl in enumerate((s0, s1, s2)):
+        sl.host["a"].fill_(float(k)); sl.host["b"].fill_(10.0 * k)
+    ring.submit(s1); ring.submit(s0)
+    with pytest.raises(RuntimeError):
+        ring.submit(s0)                                                                      # already in flight
+    s0.host["a"].fill_(99.0)                                                                 # refilling a submitted slot's host buffer ...
+    assert ring.in_flight() == 2 and ring.acquire() is None                                  # ... does not make a slot free
+    first = ring.pop()
+    assert first is s1 and torch.equal(first.outputs[0], torch.full((2, 3), 2.0)) and torch.equal(first.outputs[1], torch.full((4,), 11.0))
+    with pytest.raises(RuntimeError):
+        ring.release(s0)                                                                     # not checked out yet
+    second = ring.pop()
+    assert second is s0 and torch.equal(second.outputs[0], torch.zeros(2, 3))                # the data at submit(), not the later 99s
+    with pytest.raises(RuntimeError):
+        ring.pop()
+    ring.release(first)
+    again = ring.acquire()
+    assert again is s1 and again.outputs is None
+    ring.submit(s2); ring.release(second)
+    assert [e for e, _ in ring.log].count("submit") == 3 and ring.pop() is s2
+    with pytest.raises(ValueError):
+        brainxai.StagingRing({"a": (1,)}, slots=1, device="cpu")
