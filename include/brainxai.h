@@ -246,7 +246,7 @@ int bx_kldiv_fwd_bwd(const float* logp, const float* target, float* loss, float*
 /* ---- EEGNet branch (M:239-289); activations fp32 or bf16 NCHW ------------------------------------ */
 typedef struct {
   int B, Chans, T;      /* input [B,1,Chans,T] fp32                                  */
-  int F1, D, F2;        /* 8, 2, 16                                                  */
+  int F1, D, F2;        /* 8, 2, 16 (the reference's defaults: register-tiled kernels; any other values: the general kernel set) */
   int K1, K2;           /* temporal kernel lengths 64 and 16 ('same': left pad (K-1)/2) */
   int P1, P2;           /* average-pool widths 4 and 8                               */
   int training;
@@ -258,6 +258,8 @@ typedef struct {
                          * autocorrelation, and the gradients of conv1 / bn1 / depthwiseConv from one correlation of dL/du
                          * with the input.  Such a pass has NO input gradient (dx must be NULL);
                          * forward and backward must see the same flag.  0: the layer-by-layer path. */
+  float dropout_p2;     /* rate of the SECOND dropout (after pool 2); < 0: the same as dropout_p (EEGNet shares one module,
+                         * models.py:255; EEGNetAttentionDeep has dropout1 / dropout2, models.py:152-164) */
 } bxEegDesc;
 /* Parameter block: pointers to the fp32 tensors of the module, reference names in comments. */
 typedef struct {

@@ -29,7 +29,7 @@ class TailDesc(C.Structure):
 class EegDesc(C.Structure):
     _fields_ = [("B", i32), ("Chans", i32), ("T", i32), ("F1", i32), ("D", i32), ("F2", i32), ("K1", i32), ("K2", i32),
                 ("P1", i32), ("P2", i32), ("training", i32), ("eps", f32), ("momentum", f32), ("dropout_p", f32),
-                ("salt", u32), ("dtype", i32), ("collapse", i32)]
+                ("salt", u32), ("dtype", i32), ("collapse", i32), ("dropout_p2", f32)]
 
 
 class EegParams(C.Structure):

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbrainxai.so")
-SOURCES = ["core.hip", "conv3x3.hip", "conv3x3_mfma.hip", "conv3x3_split.hip", "tail.hip", "heads.hip", "eeg.hip", "eeg_mfma.hip", "eeg_collapse.hip", "eeg_deep.hip", "attrib.hip", "montage.hip", "specprep.hip"]
+SOURCES = ["core.hip", "conv3x3.hip", "conv3x3_mfma.hip", "conv3x3_split.hip", "tail.hip", "heads.hip", "eeg.hip", "eeg_generic.hip", "eeg_mfma.hip", "eeg_collapse.hip", "eeg_deep.hip", "attrib.hip", "montage.hip", "specprep.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
 # per-file additions (later flags win): the montage IIR must round every product and sum separately, as scipy's C loop does

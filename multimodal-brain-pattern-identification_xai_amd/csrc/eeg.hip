@@ -21,6 +21,14 @@ size_t bx_eeg_conv1_wgrad_mfma_lds(int T);
 int bx_eeg_conv1_wgrad_mfma_launch(const void* c1, const float* dd, const float* x, const float* dw, const float* mean1, const float* inv1,
                                    const float* coef, float* w1part, int B, int Ch, int T, int FD, int coef_stride, hipStream_t s);
 
+// general-geometry kernel set (eeg_generic.hip): whatever the register-tiled kernels below do not cover
+size_t bx_eegg_saved_bytes(const bxEegDesc* d);
+size_t bx_eegg_workspace(const bxEegDesc* d);
+int bx_eegg_forward(const bxEegDesc* d, const bxEegParams* p, const float* x, const uint64_t* seed, float* feat, void* saved, void* workspace,
+                    size_t workspace_bytes, hipStream_t s);
+int bx_eegg_backward(const bxEegDesc* d, const bxEegParams* p, const float* x, const float* dfeat, const uint64_t* seed, const void* saved,
+                     const bxEegGrads* gr, float* dx, void* workspace, size_t workspace_bytes, hipStream_t s);
+
 // collapsed front end (eeg_collapse.hip / eeg_mfma.hip)
 size_t bx_eegc_stat_floats();
 int bx_eegc_forward(const float* x, const float* w1, const float* wd, const float* gamma, const float* beta, float* rmean, float* rvar, int64_t* nbt,
@@ -85,9 +93,12 @@ static EegStats eeg_stats(const EegGeom& g, void* saved) {
   s.mean3 = p; s.inv3 = p + g.F2; s.sc3 = p + 2 * g.F2; s.sh3 = p + 3 * g.F2;
   return s;
 }
+// the tuned path needs the reference's default family AND rows that fit its one-row LDS tile; everything else: general kernels
+static bool eeg_tuned(const bxEegDesc* d, EegGeom* g) { return eeg_geom(d, g) == 0 && d->T <= 15000; }
 extern "C" size_t bx_eeg_saved_bytes(const bxEegDesc* d) {
   EegGeom g;
-  return (d && eeg_geom(d, &g) == 0) ? g.total : 0;
+  if (!d) return 0;
+  return eeg_tuned(d, &g) ? g.total : bx_eegg_saved_bytes(d);
 }
 
 // workspace: forward needs BN partials only; backward needs gradient maps + partial buffers
@@ -125,7 +136,8 @@ static EegWs eeg_ws(const EegGeom& g) {
 }
 extern "C" size_t bx_eeg_workspace(const bxEegDesc* d) {
   EegGeom g;
-  if (!d || eeg_geom(d, &g)) return 0;
+  if (!d) return 0;
+  if (!eeg_tuned(d, &g)) return bx_eegg_workspace(d);
   return eeg_ws(g).total;
 }
 
@@ -386,9 +398,8 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
   BX_REQUIRE(d && p && x && feat && saved, "bx_eeg_features_fwd: null pointer");
   BX_DTYPE_OK(d->dtype);
   EegGeom g;
-  const int ge = eeg_geom(d, &g);
-  BX_REQUIRE(ge == 0, "bx_eeg_features_fwd: unsupported geometry (code %d): need F1=8, D=2, F2=16, K1<=64, K2=16, Chans<=64", ge);
-  BX_REQUIRE(d->T <= 15000, "bx_eeg_features_fwd: T=%d exceeds the one-row LDS tile (<= 15000)", d->T);
+  if (!eeg_tuned(d, &g))                                  // any other F1 / D / F2 / kernLength / Chans (models.py:239-262 is parametric)
+    return bx_eegg_forward(d, p, x, seed, feat, saved, workspace, workspace_bytes, (hipStream_t)stream);
   const EegWs w = eeg_ws(g);
   if (!workspace || workspace_bytes < w.total) BX_FAIL(BX_EWORKSPACE, "bx_eeg_features_fwd: workspace %zu < %zu", workspace_bytes, w.total);
   BX_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "bx_eeg_features_fwd: dropout_p must be in [0,1)");
@@ -401,7 +412,8 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
   float* smap = (float*)((char*)saved + g.off_s);
   const int tr = d->training;
   const float pdrop = tr ? d->dropout_p : 0.f;
-  BX_REQUIRE(pdrop == 0.f || seed, "bx_eeg_features_fwd: dropout needs a device seed");
+  const float pdrop2 = tr ? (d->dropout_p2 >= 0.f ? d->dropout_p2 : d->dropout_p) : 0.f;      // the second dropout's own rate (EEGNetAttentionDeep.dropout2)
+  BX_REQUIRE((pdrop == 0.f && pdrop2 == 0.f) || seed, "bx_eeg_features_fwd: dropout needs a device seed");
 
   if (!tr) {
     hipLaunchKernelGGL(k_eeg_eval_stats, dim3(1), dim3(64), 0, s, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, g.F1, st.sc1, st.sh1, st.mean1, st.inv1,
@@ -463,7 +475,7 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
   {
     const long long n = (long long)g.B * g.F2 * g.T2;
     hipLaunchKernelGGL(k_eeg_bn_elu_pool, dim3(bx_ceil_div(n, 256)), dim3(256), 0, s, smap, st.sc3, st.sh3, feat, g.B, g.F2, g.T1, g.T2, g.P2,
-                       seed, pdrop, d->salt + 1);
+                       seed, pdrop2, d->salt + 1);
     BX_CHECK_LAUNCH("eeg pool2");
   }
   return BX_OK;
@@ -981,8 +993,8 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
   BX_REQUIRE(d && p && x && dfeat && saved, "bx_eeg_features_bwd: null pointer");
   BX_DTYPE_OK(d->dtype);
   EegGeom g;
-  const int ge = eeg_geom(d, &g);
-  BX_REQUIRE(ge == 0, "bx_eeg_features_bwd: unsupported geometry (code %d)", ge);
+  if (!eeg_tuned(d, &g))
+    return bx_eegg_backward(d, p, x, dfeat, seed, saved, gr, dx, workspace, workspace_bytes, (hipStream_t)stream);
   const EegWs w = eeg_ws(g);
   if (!workspace || workspace_bytes < w.total) BX_FAIL(BX_EWORKSPACE, "bx_eeg_features_bwd: workspace %zu < %zu", workspace_bytes, w.total);
   hipStream_t s = (hipStream_t)stream;
@@ -1004,12 +1016,13 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
   float* coef1 = coef2 + 3 * EEG_MAXF;
   const int tr = d->training;
   const float pdrop = tr ? d->dropout_p : 0.f;
+  const float pdrop2 = tr ? (d->dropout_p2 >= 0.f ? d->dropout_p2 : d->dropout_p) : 0.f;
   bxEegGrads none = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (!gr) gr = &none;
 
   // pool2/dropout/ELU/BN3
   hipLaunchKernelGGL(k_eeg_act_bwd, dim3(g.B, g.F2), dim3(256), 0, s, dfeat, smap, st.mean3, st.inv3, st.sc3, st.sh3, du3, part, g.F2, g.T1, g.T2, g.P2,
-                     seed, pdrop, d->salt + 1);
+                     seed, pdrop2, d->salt + 1);
   BX_CHECK_LAUNCH("eeg act3 bwd");
   hipLaunchKernelGGL(k_eeg_bn_bwd_finalize, dim3(1), dim3(1024), 0, s, part, g.B, (double)g.B * g.T1, g.F2, tr, p->bn3_w, st.inv3, coef3, gr->bn3_w, gr->bn3_b,
                      (const float*)nullptr, (float*)nullptr, 0, 0, 4);

@@ -262,13 +262,12 @@ class EEGNetAttentionDeep(nn.Module):
         """Block 1-2 output after dropout2, flattened [B, F2 * (T//32)] (same kernels as EEGNet.features)."""
         if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != self.Chans:
             raise RuntimeError(f"EEGNetAttentionDeep expected [B,1,{self.Chans},T], got {tuple(x.shape)}")
-        if self.dropout1.p != self.dropout2.p:
-            raise NotImplementedError("brainxai EEGNetAttentionDeep: dropout1 and dropout2 share one rate in the fused block kernels")
         g = self._geom
         bn1, bn2, bn3 = self.batchnorm1, self.batchnorm2, self.batchnorm3
         cfg = SimpleNamespace(F1=g.F1, D=g.D, F2=g.F2, K1=g.K1, K2=g.K2, P1=g.P1, P2=g.P2, training=self.training,
                               eps=bn1.eps, momentum=0.1 if bn1.momentum is None else bn1.momentum,
                               dropout_p=self.dropout1.p if self.training else 0.0, salt=self.salt, dtype=self.compute_dtype,
+                              dropout_p2=self.dropout2.p if self.training else 0.0,      # the second dropout's own rate (models.py:158,163)
                               grad_mode=torch.is_grad_enabled())
         bufs = (bn1.running_mean, bn1.running_var, bn1.num_batches_tracked, bn2.running_mean, bn2.running_var,
                 bn2.num_batches_tracked, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked)

@@ -784,10 +784,10 @@ class EegFeaturesFn(torch.autograd.Function):
         collapse = 1 if EEG_COLLAPSE and ((cfg.training and not ctx.needs_input_grad[0]) or
                                           (not cfg.training and not params_need_grad)) else 0
         desc = L.EegDesc(B, Ch, T, cfg.F1, cfg.D, cfg.F2, cfg.K1, cfg.K2, cfg.P1, cfg.P2, 1 if cfg.training else 0, cfg.eps, cfg.momentum,
-                         float(cfg.dropout_p), cfg.salt, bx_dtype(cfg.dtype), collapse)
+                         float(cfg.dropout_p), cfg.salt, bx_dtype(cfg.dtype), collapse, float(getattr(cfg, "dropout_p2", -1.0)))
         nsaved = lib.bx_eeg_saved_bytes(C.byref(desc))
         if nsaved == 0:
-            raise RuntimeError("brainxai: unsupported EEGNet geometry (needs F1=8, D=2, F2=16, kernLength<=64, Chans<=64)")
+            raise RuntimeError("brainxai: EEGNet geometry outside the kernels' range (F1*D, F2 <= 1024, kernel lengths <= 4096, tensors below 2^31 elements)")
         saved = torch.empty(nsaved, dtype=torch.uint8, device=x.device)
         ws = workspace(lib.bx_eeg_workspace(C.byref(desc)), x.device)
         params = L.EegParams(_p(c1w), _p(bn1w), _p(bn1b), _p(bufs[0]), _p(bufs[1]), _p(bufs[2]), _p(dww), _p(bn2w), _p(bn2b), _p(bufs[3]),
@@ -795,7 +795,7 @@ class EegFeaturesFn(torch.autograd.Function):
         T2 = (T // cfg.P1) // cfg.P2
         feat = torch.empty(B, cfg.F2 * T2, dtype=torch.float32, device=x.device)
         seed = None
-        if cfg.training and cfg.dropout_p > 0:
+        if cfg.training and (cfg.dropout_p > 0 or getattr(cfg, "dropout_p2", 0.0) > 0):
             seed = getattr(cfg, "seed", None)
             if seed is None:
                 seed = next_seed(x.device, "eeg")

@@ -183,10 +183,17 @@ def gen_spec_models(M):
         save(tag, **rec)
 
 
+# EEGNet fixtures: the reference's default family at the benchmark's and the native geometry, and two configurations of the
+# (fully parametric, models.py:239-262) class OUTSIDE that family -- what the general kernel set of csrc/eeg_generic.hip serves
+EEG_CASES = {"eeg19x2000": (19, 2000, {}), "eeg37x3000": (37, 3000, {}),
+             "eeg_f4d3_70x1024": (70, 1024, dict(F1=4, D=3, F2=8, kernLength=128)),
+             "eeg_f16d2_5x512": (5, 512, dict(F1=16, D=2, F2=32, kernLength=33))}
+
+
 def gen_eegnet(M):
-    for tag, (chans, samples) in {"eeg19x2000": (19, 2000), "eeg37x3000": (37, 3000)}.items():
-        ref = O.fill_params(M.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0), seed=31)
-        mine = O.fill_params(O.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0), seed=31)
+    for tag, (chans, samples, kw) in EEG_CASES.items():
+        ref = O.fill_params(M.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0, **kw), seed=31)
+        mine = O.fill_params(O.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0, **kw), seed=31)
         x = O.seeded((2, 1, chans, samples), 32, "randn")
         r = O.seeded((2, 6), 33, "randn")
         rec = {"r": r}
@@ -215,8 +222,8 @@ def gen_eegnet(M):
             rec[f"{mode}.dx.tail"] = xi.grad.detach()[..., -96:].clone()
             rec[f"{mode}.dx.sum"] = O.summarize(xi.grad)
             c1 = grabbed["conv1"]
-            rec[f"{mode}.conv1.head"] = c1[..., :80].clone()      # left pad 31
-            rec[f"{mode}.conv1.tail"] = c1[..., -80:].clone()     # right pad 32
+            rec[f"{mode}.conv1.head"] = c1[..., :80].clone()      # left pad (K-1)/2: 31 at K = 64
+            rec[f"{mode}.conv1.tail"] = c1[..., -80:].clone()     # right pad K/2: 32
             rec[f"{mode}.conv1.sum"] = O.summarize(c1)
             rec[f"{mode}.dw"] = grabbed["depthwiseConv"]
             rec[f"{mode}.bn2"] = grabbed["batchnorm2"]
@@ -384,6 +391,69 @@ def gen_ddp(M, MM):
         off += p.numel()
     rec["mean.gmax"] = np.array([float(mean.abs().max())])
     save("ddp8_bench_small", **rec)
+
+
+def gen_ddp_loop(M):
+    """the reference's OWN ``train_and_validate_eeg_distributed`` (training_distributed.py:22-141), extracted
+    with ``ast`` and run here on one CPU rank with its environment stubbed -- ``dist.init_process_group`` (it hard-codes 'nccl',
+    :24) a no-op, ``DDP`` a wrapper with DDP's ``.module`` / 'module.'-prefixed ``state_dict``, ``load_checkpoint`` returning the
+    seven empty histories (:31), ``save_checkpoint`` capturing the dict it would write, ``cfg`` and ``plt`` inert -- on the
+    reference's EEGNet with a ``weight_decay`` attribute (:53), AdamW, KLDivLoss and ReduceLROnPlateau.  Two epochs of three
+    batches + two validation batches.  Pins ``oracle.distributed_epoch`` (the loop restatement the GPU test of row F compares
+    with): per-epoch train / regularisation / validation losses, accuracies, learning-rate history, final weights."""
+    import copy
+    import types
+    path = os.path.join(REF, "root/src/training/training_distributed.py")
+    captured = {}
+
+    class _DDP(nn.Module):
+        def __init__(self, module, device_ids=None):
+            super().__init__()
+            self.module = module
+
+        def forward(self, *a, **k):
+            return self.module(*a, **k)
+    dist_stub = types.SimpleNamespace(init_process_group=lambda *a, **k: None)
+    plt_stub = types.SimpleNamespace(**{n: (lambda *a, **k: None) for n in ("figure", "subplot", "plot", "title", "xlabel", "ylabel", "tight_layout", "show")})
+    ns = {"torch": torch, "nn": nn, "dist": dist_stub, "DDP": _DDP, "plt": plt_stub, "cfg": {"checkpointing_enabled": True},
+          "load_checkpoint": lambda d, f, m, o: (0, [], [], [], [], [], []),
+          "save_checkpoint": lambda state, d, f: captured.__setitem__("state", copy.deepcopy(state))}
+    ref_loop = extract(path, "train_and_validate_eeg_distributed", ns)
+    chans, samples, b, wd = 19, 2000, 4, 1e-4
+
+    def batches(seed0, n):
+        return [(O.seeded((b, 1, chans, samples), seed0 + i, "randn"), torch.softmax(O.seeded((b, 6), seed0 + 50 + i, "randn"), 1)) for i in range(n)]
+    train, valid = batches(700, 3), batches(800, 2)
+
+    class _Loader(list):
+        sampler = types.SimpleNamespace(set_epoch=lambda e: None)
+    logger = types.SimpleNamespace(info=lambda *a, **k: None)
+
+    def fresh(cls):
+        net = O.fill_params(cls(6, Chans=chans, Samples=samples, dropoutRate=0.0), seed=91)
+        net.weight_decay = wd
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-2)
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.5, patience=0, threshold=10.0)   # every epoch "plateaus": the rate halves
+        return net, opt, sched
+    ref, opt_r, sched_r = fresh(M.EEGNet)
+    tl, vl, ta, va = ref_loop(ref, _Loader(train), _Loader(valid), 2, opt_r, nn.KLDivLoss(), sched_r, "cpu", "/nonexistent", logger, 0, 1)
+    st = captured["state"]
+    assert all(k.startswith("module.") for k in st["state_dict"]) and st["epoch"] == 2
+    mine, opt_m, sched_m = fresh(O.EEGNet)
+    hist = [O.distributed_epoch(mine, train, valid, opt_m, nn.KLDivLoss(), wd, sched_m) for _ in range(2)]
+    note("ddp_loop.train_loss", torch.tensor([h["train_loss"] for h in hist]), torch.tensor(tl))
+    note("ddp_loop.reg_loss", torch.tensor([h["reg_loss"] for h in hist]), torch.tensor(st["regularization_losses"]))
+    note("ddp_loop.valid_loss", torch.tensor([h["valid_loss"] for h in hist]), torch.tensor(vl))
+    note("ddp_loop.train_acc", torch.tensor([h["train_acc"] for h in hist]), torch.tensor(ta))
+    note("ddp_loop.valid_acc", torch.tensor([h["valid_acc"] for h in hist]), torch.tensor(va))
+    note("ddp_loop.lr", torch.tensor([h["lr"] for h in hist]), torch.tensor(st["lr_scheduler"]))
+    for (n, p), (_, q) in zip(ref.state_dict().items(), mine.state_dict().items()):
+        note("ddp_loop.final_state", q.float(), p.float())
+    rec = {"train_losses": np.array(tl), "valid_losses": np.array(vl), "train_accuracies": np.array(ta), "valid_accuracies": np.array(va),
+           "regularization_losses": np.array(st["regularization_losses"]), "lr_scheduler": np.array(st["lr_scheduler"]),
+           "weight_decay": np.array([wd]), "lr0": np.array([1e-2])}
+    rec.update({"final." + k: v for k, v in state_digest(ref).items()})
+    save("ddp_loop_eeg_19x2000", **rec)
 
 
 def gen_attribution(M, MM, NB):
@@ -590,6 +660,7 @@ if __name__ == "__main__":
     if want("attention"): print("attention"); gen_attention(M)
     if want("multimodal"): print("multimodal"); gen_multimodal(M, MM)
     if want("ddp"): print("data-parallel equivalence"); gen_ddp(M, MM)
+    if want("ddp_loop"): print("data-parallel epoch loop (the reference's own function)"); gen_ddp_loop(M)
     if want("attribution"): print("attribution"); gen_attribution(M, MM, NB)
     if want("stacker"): print("stacker"); gen_stacker()
     if want("montage"): print("montage stacker"); gen_montage(NB)

@@ -160,11 +160,16 @@ def _eeg_tol(name, mode):
     return TOL if (mode == "train" and name.startswith("batchnorm1.")) else TIGHT
 
 
-@pytest.mark.parametrize("tag,chans,samples", [("eeg19x2000", 19, 2000), ("eeg37x3000", 37, 3000)])
-def test_eegnet_fwd_bwd(tag, chans, samples):
+EEG_CASES = [("eeg19x2000", 19, 2000, {}), ("eeg37x3000", 37, 3000, {}),
+             ("eeg_f4d3_70x1024", 70, 1024, dict(F1=4, D=3, F2=8, kernLength=128)),        # outside the default family: the general
+             ("eeg_f16d2_5x512", 5, 512, dict(F1=16, D=2, F2=32, kernLength=33))]          # kernel set (csrc/eeg_generic.hip), odd taps too
+
+
+@pytest.mark.parametrize("tag,chans,samples,kw", EEG_CASES)
+def test_eegnet_fwd_bwd(tag, chans, samples, kw):
     fix = load(tag)
-    ref, mine = _pair(lambda: O.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0),
-                      lambda: brainxai.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0), 31)
+    ref, mine = _pair(lambda: O.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0, **kw),
+                      lambda: brainxai.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0, **kw), 31)
     x = O.seeded((2, 1, chans, samples), 32, "randn")
     r = torch.from_numpy(fix["r"])
     for mode in ("eval", "train"):
@@ -189,6 +194,33 @@ def test_eegnet_fwd_bwd(tag, chans, samples):
     for k in ("batchnorm1", "batchnorm2", "batchnorm3"):
         assert _sync_err(getattr(mine, k).running_var, getattr(ref, k).running_var) < TIGHT
         check(fix, f"after.{k}.running_var", getattr(mine, k).running_var.cpu(), tol=TOL)
+
+
+def test_eegnet_attention_deep_with_two_dropout_rates():
+    """EEGNetAttentionDeep owns dropout1 and dropout2 (models.py:152-164); round 2 raised unless both rates were equal.  With
+    dropout1 off and dropout2 at p, the block-2 features are elementwise either 0 or 1/(1-p) times the features of the run without
+    dropout (train-mode BatchNorm statistics sit upstream of dropout2), and about a fraction p of them is dropped."""
+    torch.manual_seed(5)
+    net = brainxai.EEGNetAttentionDeep(6, Chans=19, Samples=2000, dropoutRate=0.5).to(DEV).train()
+    x = torch.randn(8, 1, 19, 2000, device=DEV)
+    net.dropout1.p, net.dropout2.p = 0.0, 0.0
+    with torch.no_grad():
+        base = net.features(x).clone()
+        for m in (net.batchnorm1, net.batchnorm2, net.batchnorm3):      # the statistics update is not what this test is about
+            m.reset_running_stats()
+        net.dropout2.p = 0.25
+        ops.manual_seed(99)
+        got = net.features(x)
+    torch.cuda.synchronize()
+    kept = got != 0
+    frac = 1.0 - float(kept.float().mean())
+    assert 0.22 < frac < 0.28, frac
+    assert float((got[kept] - base[kept] / 0.75).abs().max()) <= 1e-5 * float(base.abs().max())
+    net.dropout1.p = 0.5                                               # both on, different rates: runs forward and backward
+    out = net(x)
+    out.sum().backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and all(torch.isfinite(p.grad).all() for p in net.parameters())
 
 
 @pytest.mark.parametrize("chans,samples,b", [(19, 2000, 3), (37, 3000, 2), (19, 2100, 2), (5, 300, 1)])
@@ -1434,6 +1466,45 @@ def test_train_and_validate_eeg_distributed_against_oracle(tmp_path, arch, flat)
     finally:
         brainxai.cleanup()
         ops.clear_grad_views()
+
+
+def test_distributed_loop_against_the_reference_functions_own_histories(tmp_path):
+    """Row F, pinned: tests/golden/ddp_loop_eeg_19x2000.npz holds what the reference's OWN train_and_validate_eeg_distributed
+    (training_distributed.py:22-141, ast-extracted, dist / DDP / checkpoint I/O stubbed; oracle/make_golden.py gen_ddp_loop) returned
+    and would have checkpointed for two epochs of three batches: the product's loop on a 1-rank RCCL group reproduces the per-epoch
+    train / regularisation / validation losses, both accuracies and the learning-rate history from the same start."""
+    import os
+    import socket
+    fix = load("ddp_loop_eeg_19x2000")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    wd, lr0 = float(fix["weight_decay"][0]), float(fix["lr0"][0])
+    start = O.fill_params(O.EEGNet(6, Chans=19, Samples=2000, dropoutRate=0.0), seed=91)
+    net = brainxai.EEGNet(6, Chans=19, Samples=2000, dropoutRate=0.0)
+    net.load_state_dict(start.state_dict())
+    net.weight_decay = wd
+    batches = lambda seed0, n: [(O.seeded((4, 1, 19, 2000), seed0 + i, "randn"), torch.softmax(O.seeded((4, 6), seed0 + 50 + i, "randn"), 1)) for i in range(n)]   # noqa: E731
+    train, valid = batches(700, 3), batches(800, 2)
+    net.to(DEV)
+    opt = brainxai.FlatAdamW(net.parameters(), lr=lr0)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.5, patience=0, threshold=10.0)
+    try:
+        tl, vl, ta, va = brainxai.train_and_validate_eeg_distributed(net, train, valid, 2, opt, brainxai.KLDivLoss(), sched, DEV, str(tmp_path),
+                                                                       None, 0, 1)
+        ck = torch.load(tmp_path / "eeg_checkpoint.pth.tar", map_location="cpu", weights_only=False)
+    finally:
+        brainxai.cleanup()
+        ops.clear_grad_views()
+    # epoch 1 starts from identical weights (three AdamW steps at lr 1e-2): tight; epoch 2 has drifted by the entries whose gradient is
+    # rounding noise (EEGNet's BatchNorm1 affine has an exactly-zero gradient in train mode and walks +-lr on either side)
+    np.testing.assert_allclose(tl[0], fix["train_losses"][0], rtol=2e-3)
+    np.testing.assert_allclose(ck["regularization_losses"][0], fix["regularization_losses"][0], rtol=1e-4)
+    np.testing.assert_allclose(vl[0], fix["valid_losses"][0], rtol=3e-2)
+    np.testing.assert_allclose(tl[1], fix["train_losses"][1], rtol=5e-2)
+    np.testing.assert_allclose(ck["regularization_losses"][1], fix["regularization_losses"][1], rtol=2e-3)
+    assert ta[0] == pytest.approx(float(fix["train_accuracies"][0])) and va[0] == pytest.approx(float(fix["valid_accuracies"][0]))
+    np.testing.assert_allclose(ck["lr_scheduler"], fix["lr_scheduler"], rtol=1e-6)           # the plateau rule halves the rate after both epochs
+    assert all(k.startswith("module.") for k in ck["state_dict"]) and ck["epoch"] == 2
 
 
 def test_expected_gradients_shap_style():

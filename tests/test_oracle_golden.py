@@ -58,10 +58,15 @@ def test_spectrogram_model(tag, cin):
     check(fix, "train.logits", net(x))
 
 
-@pytest.mark.parametrize("tag,chans,samples", [("eeg19x2000", 19, 2000), ("eeg37x3000", 37, 3000)])
-def test_eegnet(tag, chans, samples):
+EEG_CASES = [("eeg19x2000", 19, 2000, {}), ("eeg37x3000", 37, 3000, {}),
+             ("eeg_f4d3_70x1024", 70, 1024, dict(F1=4, D=3, F2=8, kernLength=128)),        # outside the default family: the general
+             ("eeg_f16d2_5x512", 5, 512, dict(F1=16, D=2, F2=32, kernLength=33))]          # kernel set (csrc/eeg_generic.hip), odd taps too
+
+
+@pytest.mark.parametrize("tag,chans,samples,kw", EEG_CASES)
+def test_eegnet(tag, chans, samples, kw):
     fix = load(tag)
-    net = O.fill_params(O.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0), seed=31)
+    net = O.fill_params(O.EEGNet(6, Chans=chans, Samples=samples, dropoutRate=0.0, **kw), seed=31)
     x = O.seeded((2, 1, chans, samples), 32, "randn")
     r = torch.from_numpy(fix["r"])
     for mode in ("eval", "train"):
@@ -247,3 +252,23 @@ def test_spectrogram_preprocessing():
     check(fix, "full", got, tol=1e-6)
     w = O.gaussian_weights()
     assert len(w) == 9 and abs(w.sum() - 1) < 1e-15 and w[4] == w.max()
+
+
+def test_distributed_epoch_loop_is_pinned_by_the_reference_function():
+    """oracle.distributed_epoch (row F's loop restatement) replays the histories that the reference's OWN
+    train_and_validate_eeg_distributed produced in the build container (oracle/make_golden.py gen_ddp_loop: the function is
+    ast-extracted from training_distributed.py:22-141 and run with dist / DDP / checkpoint I/O stubbed)."""
+    import torch.nn as nn
+    fix = load("ddp_loop_eeg_19x2000")
+    wd, lr0 = float(fix["weight_decay"][0]), float(fix["lr0"][0])
+    net = O.fill_params(O.EEGNet(6, Chans=19, Samples=2000, dropoutRate=0.0), seed=91)
+    batches = lambda seed0, n: [(O.seeded((4, 1, 19, 2000), seed0 + i, "randn"), torch.softmax(O.seeded((4, 6), seed0 + 50 + i, "randn"), 1)) for i in range(n)]   # noqa: E731
+    train, valid = batches(700, 3), batches(800, 2)
+    opt = torch.optim.AdamW(net.parameters(), lr=lr0)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.5, patience=0, threshold=10.0)
+    hist = [O.distributed_epoch(net, train, valid, opt, nn.KLDivLoss(), wd, sched) for _ in range(2)]
+    for key, name in (("train_loss", "train_losses"), ("reg_loss", "regularization_losses"), ("valid_loss", "valid_losses"),
+                      ("train_acc", "train_accuracies"), ("valid_acc", "valid_accuracies"), ("lr", "lr_scheduler")):
+        np.testing.assert_allclose([h[key] for h in hist], fix[name], rtol=1e-6, err_msg=name)
+    for n, t in net.state_dict().items():
+        check(fix, "final.shead." + n, t.detach().float().flatten()[:32], tol=1e-5)

@@ -14,7 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = os.path.join(ROOT, "multimodal-brain-pattern-identification_xai_amd")
 out = "/tmp/libbrainxai_stamps.so"
-srcs = ["core.hip", "conv3x3.hip", "conv3x3_mfma.hip", "tail.hip", "heads.hip", "eeg.hip", "eeg_mfma.hip", "eeg_deep.hip", "attrib.hip", "montage.hip", "specprep.hip"]
+import importlib.util as _ilu
+_spec = _ilu.spec_from_file_location("_bx_build", os.path.join(PKG, "build.py")); _b = _ilu.module_from_spec(_spec); _spec.loader.exec_module(_b)
+srcs = _b.SOURCES
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-DBX_WGRAD_STAMPS", "-shared",
                        *[os.path.join(PKG, "csrc", f) for f in srcs], "-o", out])
 import torch  # noqa: E402
