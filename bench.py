@@ -73,17 +73,24 @@ def conv_work(bx, dtype_bytes):
 
 
 def pmc_conv_traffic(dtype):
-    """HBM bytes per conv3x3-family launch from the newest committed PMC summary (profiles/*_pmc_hbm_traffic.txt written by
-    tools/step_profile.py --pmc: same model, batch and dtype as this benchmark, FETCH_SIZE x2 + WRITE_SIZE collected in separate
-    rocprofv3 passes as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process, so the line
-    names the file (and its date) the figure comes from.  (bytes, source) or (None, None)."""
-    if dtype != "bf16":
-        return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.txt")))
+    """HBM bytes per conv3x3-family layer launch from the newest committed PMC summary of this dtype (profiles/*_pmc_hbm_traffic*.txt
+    written by tools/step_profile.py --pmc: same model, batch and dtype as this benchmark, FETCH_SIZE x2 + WRITE_SIZE collected in
+    separate rocprofv3 passes as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process, so the line
+    names the file and the provenance the file itself records (collection date, commit, digest of csrc/ at collection time) and says
+    whether that digest is the digest of the kernel sources this run was built from.  (bytes, source, matches) or (None, None, None)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_bx_build", os.path.join(ROOT, "multimodal-brain-pattern-identification_xai_amd", "build.py"))
+    bld = importlib.util.module_from_spec(spec); spec.loader.exec_module(bld)
+    now = bld._digest()
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic*.txt")))
+    fam = ("k_conv_mfma", "k_conv12", "k_conv3x3", "k_conv_split", "k_wgrad_mfma", "k_wgrad_own", "k_wgrad_split", "k_wgrad_direct", "k_wgrad_reduce")
     for path in reversed(files):
-        tot, launches = 0.0, 0.0
+        tot, launches, prov = 0.0, 0.0, {}
         for line in open(path):
-            if not line.startswith(("k_conv_mfma", "k_conv12", "k_conv3x3", "k_wgrad_mfma", "k_wgrad_own", "k_wgrad_reduce")):
+            if line.startswith("# provenance:"):
+                w_ = line.split()
+                prov = {w_[i]: w_[i + 1] for i in range(2, len(w_) - 1, 2)}
+            if not line.startswith(fam):
                 continue
             try:
                 wr, fe, n = float(line.split()[-1]), float(line.split()[-2]), float(line.split()[-3])
@@ -92,10 +99,13 @@ def pmc_conv_traffic(dtype):
             tot += n * (fe + wr) * 1e6
             if not line.startswith("k_wgrad_reduce"):
                 launches += 2 * n if line.startswith("k_conv12") else n        # a pair launch runs two of the family's 44 layer launches
+        if prov.get("dtype", "bf16") != dtype:
+            continue
         if launches > 0:
-            stamp = time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(path)))
-            return round(tot / launches), f"profiles/{os.path.basename(path)} ({stamp})"
-    return None, None
+            matches = prov.get("csrc_digest") == now if prov else None
+            src = f"profiles/{os.path.basename(path)} (collected {prov.get('collected', 'date not recorded')}, commit {prov.get('commit', 'not recorded')})"
+            return round(tot / launches), src, matches
+    return None, None, None
 
 
 def launch_ranks(args):
@@ -406,7 +416,7 @@ def main():
         ai = conv_flops / conv_bytes
         peak_tf = MFMA_PEAK_TFLOPS["bf16"] / mfma_per_product               # fp32-storage FLOPs run as 6 bf16 MFMA products each
         ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
-        traffic, source = pmc_conv_traffic(args.dtype)
+        traffic, source, traffic_current = pmc_conv_traffic(args.dtype)
         # bf16: the family's arithmetic intensity (~150 FLOP/B) is below the ridge (312 FLOP/B): HBM is the binding roof.
         # fp32 storage: twice the bytes, six MFMA products per FLOP pair -> intensity 77 against a ridge of 52: the matrix cores are
         bound = "hbm" if ai < ridge else "mfma"
@@ -417,6 +427,7 @@ def main():
                     "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
                     "frac": round((ach_gbs / HBM_PEAK_GBS) if bound == "hbm" else (ach_tf / peak_tf), 5),
                     "traffic": traffic, "traffic_source": source,
+                    "traffic_from_this_build": traffic_current,      # True: the PMC pass was taken on exactly these kernel sources; False: stale
                     "traffic_unit": "HBM bytes per layer launch, family average (PMC FETCH_SIZE x2 + WRITE_SIZE; from the committed summary named in traffic_source, not measured in this run)",
                     "algorithmic_bytes_per_launch": round(conv_bytes / max(n_launch, 1)),
                     "arithmetic_intensity_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),

@@ -328,19 +328,67 @@ __device__ __forceinline__ int wsplit_read_off(int row, int col, int m, int pc) 
   return (row * ROWLEN + (col ^ (((col >> 3) & 1) << 2))) * 32 + pc * 8;
 }
 
+// fixed-order sum of a layer's partials + scatter to OIHW: the arithmetic of wgrad_reduce3_body (conv3x3_mfma.hip) on the same partial
+// layout ([split][slice][9*MA*NB tiles][64 lanes][4] fragments, then Co bias sums); S slices of the splits per output, combined in
+// slice order through LDS.
+struct WsplitRedJob { const float* partial; float* dw; float* db; int nsplit, Cin, Co, S, MA, NB, ztiles, nfrag4, nblocks; };
+__device__ __forceinline__ void wsplit_reduce_body(const WsplitRedJob& jb, int bid, float4* sm) {
+  const size_t per_split = (size_t)jb.nfrag4 * 4 + jb.Co;
+  const int S = jb.S, NO = 256 / S;
+  const int o = threadIdx.x % NO, part = threadIdx.x / NO;
+  const size_t e4 = (size_t)bid * NO + o;
+  const bool live = e4 * 4 < per_split;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    const float* src = jb.partial + e4 * 4;
+    for (int c = part; c < jb.nsplit; c += S) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * per_split);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (part == 0 && live) {
+    float4 r = sm[o];
+    for (int k = 1; k < S; ++k) { const float4 v = sm[k * NO + o]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+    const float rr[4] = {r.x, r.y, r.z, r.w};
+    if (e4 < (size_t)jb.nfrag4) {
+      const int NT = 9 * jb.MA * jb.NB;
+      const int lane = (int)(e4 & 63), tl = (int)(e4 >> 6);
+      const int i = tl % NT, yz = tl / NT, z = yz % jb.ztiles, y = yz / jb.ztiles;
+      const int n = i % jb.NB, m = (i / jb.NB) % jb.MA, t = i / (jb.NB * jb.MA);
+      const int cout = (z * jb.NB + n) * 16 + (lane & 15), cin0 = (y * jb.MA + m) * 16 + 4 * (lane >> 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (cin0 + j < jb.Cin) jb.dw[((size_t)cout * jb.Cin + cin0 + j) * 9 + t] = rr[j];
+    } else if (jb.db) {
+      const size_t b0 = (e4 - jb.nfrag4) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) jb.db[b0 + j] = rr[j];
+    }
+  }
+}
+
 template <int MA, int NB>
 __global__ __launch_bounds__(256, 2) void k_wgrad_split(const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ partial,
-    int H, int W, int Ci_p, int Co, int tiles_x, int tiles_y, int ntiles, int tiles_per_split) {
+    int H, int W, int Ci_p, int Co, int tiles_x, int tiles_y, int ntiles, int tiles_per_split, WsplitRedJob prev, int zextra) {
   constexpr int TH = 8, TW = 16, HWID = TW + 2, HH = TH + 2, CIT = 16 * MA, COT = 16 * NB, XB = CIT * 2, ZB = COT * 2;
   constexpr int Q = MA * NB, KW = 4 / Q, KSTEPS = TH * TW / 32;        // 4 K-steps of 32 pixels (two tile rows each) per tile
   constexpr int XIMG = HH * HWID * XB, ZIMG = TH * TW * ZB;
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  // chained mode (as k_wgrad_mfma): the first `zextra` z-slices of the grid sum the PREVIOUS layer's partials, so that layer needs no
+  // reduce launch of its own; these light workgroups are dispatched first and overlap with the heavy ones behind them
+  if ((int)blockIdx.z < zextra) {
+    const int rid = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+    if (rid < prev.nblocks) wsplit_reduce_body(prev, rid, reinterpret_cast<float4*>(lds));
+    return;
+  }
   char* xs = lds;                            // X halo tile: images h, m, l (XIMG bytes each), then the dZ tile's three images
   char* zs = lds + 3 * XIMG;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
   const int q = li >> 2, pc = li & 3;
   const int quad = wave % Q, kpart = wave / Q, m = quad / NB, n = quad % NB;
-  const int by = blockIdx.y, bz = blockIdx.z;
+  const int by = blockIdx.y, bz = (int)blockIdx.z - zextra;
   const int ci0 = by * CIT, co0 = bz * COT;
   const bool want_bias = by == 0;
 
@@ -488,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(const float* __restrict_
   }
   // ---- the partial: k_wgrad_mfma's fragment order [slice][tile = tap*MA*NB + m*NB + n][lane][reg], then Co bias sums
   constexpr int NT = 9 * Q;
-  const int gy = (int)gridDim.y, gz = (int)gridDim.z;
+  const int gy = (int)gridDim.y, gz = (int)gridDim.z - zextra;
   const size_t nfrag = (size_t)gy * gz * NT * 256;
   const size_t per_split = nfrag + Co;
   float* out = partial + (size_t)blockIdx.x * per_split;
@@ -541,8 +589,8 @@ size_t bx_wgrad_split_workspace(int B, int H, int W, int Ci_p, int Co) {
   return (size_t)p.nsplit * ((size_t)p.ytiles * p.ztiles * 9 * p.ma * p.nb * 256 + Co) * sizeof(float);
 }
 int bx_wgrad_mfma_finish(bxWgradPending* pd, hipStream_t s);      // conv3x3_mfma.hip: k_wgrad_reduce3 over a pending descriptor
-// pending == NULL: partials are reduced right away.  Otherwise a valid *pending (previous layer) is finished first (this kernel does
-// not carry another layer's sum) and *pending is overwritten with this layer's unreduced partials.
+// pending == NULL: partials are reduced right away.  Otherwise a valid *pending (previous layer) is summed by extra workgroups of THIS
+// launch and *pending is overwritten with this layer's unreduced partials (bx_conv3x3_wgrad_chained's contract).
 int bx_wgrad_split_launch(const void* x, const void* dz, float* dw, float* db, int B, int H, int W, int Cin, int Ci_p, int Co, void* ws,
                           size_t ws_bytes, bxWgradPending* pending, hipStream_t s) {
   const WsplitPlan p = wsplit_plan(B, H, W, Ci_p, Co);
@@ -550,14 +598,25 @@ int bx_wgrad_split_launch(const void* x, const void* dz, float* dw, float* db, i
   BX_REQUIRE(bx_wgrad_split_supported(Ci_p, Co), "bx_conv3x3_wgrad(split): unsupported channel counts Ci_p=%d Co=%d", Ci_p, Co);
   BX_REQUIRE((size_t)B * H * W * (Ci_p > Co ? Ci_p : Co) * 4 < ((size_t)1 << 31), "bx_conv3x3_wgrad(split): an activation tensor of 2 GiB or more is not supported");
   BX_REQUIRE(p.ytiles <= 65535 && p.ztiles <= 65535, "bx_conv3x3_wgrad(split): too many channel slices");
-  if (pending && pending->valid) {
+  WsplitRedJob prev;
+  memset(&prev, 0, sizeof(prev));
+  int zextra = 0;
+  if (pending && pending->valid) {                       // the previous layer's sum rides in this launch
     BX_REQUIRE(pending->partial != ws, "bx_conv3x3_wgrad(chained): the pending partials live in this call's workspace");
-    const int rc = bx_wgrad_mfma_finish(pending, s);
-    if (rc) return rc;
+    prev.partial = (const float*)pending->partial; prev.dw = pending->dw; prev.db = pending->db; prev.nsplit = pending->nsplit; prev.Cin = pending->Cin;
+    prev.Co = pending->Co; prev.MA = pending->ma; prev.NB = pending->nb; prev.ztiles = pending->ztiles; prev.nfrag4 = pending->nfrag4;
+    int S = 1;
+    while (S < 64 && pending->nsplit > 8 * S) S *= 2;      // few workgroups, short chains of loads per thread (wgrad_reduce_slices, chained form)
+    prev.S = S;
+    const size_t per_split = (size_t)pending->nfrag4 * 4 + pending->Co;
+    prev.nblocks = (int)((per_split / 4 + (256 / S) - 1) / (256 / S));
+    zextra = (prev.nblocks + p.nsplit * p.ytiles - 1) / (p.nsplit * p.ytiles);
+    pending->valid = 0;
   }
-  dim3 grid((unsigned)p.nsplit, (unsigned)p.ytiles, (unsigned)p.ztiles);
-#define BX_WS(MA_, NB_) hipLaunchKernelGGL((k_wgrad_split<MA_, NB_>), grid, dim3(256), p.lds, s, (const float*)x, (const float*)dz, (float*)ws, H, W, \
-                                           Ci_p, Co, p.tiles_x, p.tiles_y, p.ntiles, p.tps)
+  size_t lds = p.lds < 4096 ? 4096 : p.lds;              // the reduce role's float4[256]
+  dim3 grid((unsigned)p.nsplit, (unsigned)p.ytiles, (unsigned)(p.ztiles + zextra));
+#define BX_WS(MA_, NB_) hipLaunchKernelGGL((k_wgrad_split<MA_, NB_>), grid, dim3(256), lds, s, (const float*)x, (const float*)dz, (float*)ws, H, W, \
+                                           Ci_p, Co, p.tiles_x, p.tiles_y, p.ntiles, p.tps, prev, zextra)
   if (p.ma == 1 && p.nb == 1) BX_WS(1, 1);
   else if (p.ma == 1 && p.nb == 2) BX_WS(1, 2);
   else if (p.ma == 2 && p.nb == 1) BX_WS(2, 1);

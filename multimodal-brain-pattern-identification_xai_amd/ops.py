@@ -421,7 +421,7 @@ def _wgrad(x, dz, w: torch.Tensor, b: torch.Tensor, chain: bool = False):
     algo = WGRAD_ALGO
     need = lib.bx_conv3x3_wgrad_workspace(B, H, W, Cip, Co, dt, algo)
     dw, db = new_grad(w), new_grad(b)
-    if chain and WGRAD_CHAIN and x.dtype == torch.bfloat16 and algo != L.BX_ALGO_DIRECT:
+    if chain and WGRAD_CHAIN and algo != L.BX_ALGO_DIRECT:      # both storage types chain (shapes only the direct kernel covers finish the chain themselves)
         st = _wg_chain_state(x.device)
         if st.pend.valid and st.stream != _stream():
             wgrad_flush(x.device)                           # never carry a pending reduce across streams

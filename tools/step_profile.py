@@ -16,6 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+DT = os.environ.get("BX_PROFILE_DTYPE", "bf16")          # label of the summaries (tools/collect_profiles.sh sets it)
 
 
 def run(steps, dtype="bf16", ddp=False):
@@ -94,7 +95,7 @@ def summarize(out_dir, steps):
         a[1] += e - s
     busy = sum(v[1] for v in agg.values())
     wall = sel[-1][2] - sel[0][1]
-    print(f"# {steps} hipGraph-replayed training steps (B=64, bf16): wall {wall / steps / 1e3:.1f} us/step, kernel-busy {busy / steps / 1e3:.1f} us/step, "
+    print(f"# {steps} hipGraph-replayed training steps (B=64, {DT}): wall {wall / steps / 1e3:.1f} us/step, kernel-busy {busy / steps / 1e3:.1f} us/step, "
           f"{sum(v[0] for v in agg.values()) / steps:.0f} launches/step")
     print(f"{'kernel':60s} {'launches/step':>13s} {'avg us':>9s} {'us/step':>9s} {'share':>7s}")
     for k, (cnt, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -167,7 +168,14 @@ def pmc_summarize(fetch_dir, write_dir, steps):
             a[which][1] += float(v) * scale
     tot_f = sum(v["fetch"][1] for v in out.values()) / steps / 1e6
     tot_w = sum(v["write"][1] for v in out.values()) / steps / 1e6
-    print(f"# HBM traffic of {steps} eager training steps (B=64, bf16), PMC FETCH_SIZE x2 / WRITE_SIZE in separate passes: "
+    # provenance: which kernel sources these counters belong to -- bench.py compares the digest with the library it runs
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("_bx_build", os.path.join(ROOT, "multimodal-brain-pattern-identification_xai_amd", "build.py"))
+    bld = importlib.util.module_from_spec(spec); spec.loader.exec_module(bld)
+    print(f"# provenance: csrc_digest {bld._digest()} collected {time.strftime('%Y-%m-%d', time.gmtime())} commit {os.environ.get('BX_COMMIT', 'unknown')} "
+          f"dtype {os.environ.get('BX_PROFILE_DTYPE', 'bf16')}")
+    print(f"# HBM traffic of {steps} eager training steps (B=64, {os.environ.get('BX_PROFILE_DTYPE', 'bf16')}), PMC FETCH_SIZE x2 / WRITE_SIZE in separate passes: "
           f"{tot_f:.0f} MB read + {tot_w:.0f} MB written per step")
     print(f"{'kernel':60s} {'launches/step':>13s} {'fetch MB':>10s} {'write MB':>10s}   (per launch)")
     for k, v in sorted(out.items(), key=lambda kv: -(kv[1]["fetch"][1] + kv[1]["write"][1])):
@@ -196,7 +204,7 @@ def sq_summarize(d, steps):
             counters.append(c)
         agg.setdefault(short[n], {}).setdefault(c, 0.0)
         agg[short[n]][c] += float(v)
-    print("# per-kernel SQ counters, sums over %d eager training steps (B=64, bf16)" % steps)
+    print("# per-kernel SQ counters, sums over %d eager training steps (B=64, %s)" % (steps, DT))
     print("%-44s " % "kernel" + " ".join("%14s" % c[-14:] for c in counters))
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0.0)):
         print("%-44s " % k[:44] + " ".join("%14.4g" % v.get(c, 0.0) for c in counters))
