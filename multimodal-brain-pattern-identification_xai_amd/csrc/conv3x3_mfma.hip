@@ -305,6 +305,17 @@ __device__ __forceinline__ void conv_pool_transpose_w1x1(const BxConvPoolEpi& pe
   }
 }
 
+#ifdef BX_CONV_STAMPS
+// Diagnostic build only (hipcc -DBX_CONV_STAMPS, tools/conv_stamps.py): shader-clock stamps of one workgroup in four.
+// Slots per workgroup: [start, first halo image staged, end of chunk 0..3, epilogue stores issued].
+__device__ unsigned long long bx_conv_stamps[64 * 8];
+extern "C" int bx_debug_conv_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(bx_conv_stamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -1;
+}
+#define BX_CSTAMP(i) do { if (cstamp_wg >= 0 && threadIdx.x == 0) bx_conv_stamps[cstamp_wg * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BX_CSTAMP(i) do { } while (0)
+#endif
 // IMGS (round 2): a workgroup's pixel tile may span the SAME 8 x TW window of IMGS consecutive images (their halo tiles sit one
 // after the other in LDS).  The weight fragments a wave fetches per K-step then feed IMGS times as many MFMAs: the late stages
 // (8x16 and 16x32 maps, 64-channel chunks) ran 4-8 MFMAs per K-step per wave and spent 470-830 cycles on each (in-kernel stamps).
@@ -325,6 +336,11 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   }
   const int bid = (int)blockIdx.x - nred;
   const int gx = (int)gridDim.x - nred;
+#ifdef BX_CONV_STAMPS
+  const int cstamp_lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  const int cstamp_wg = (cstamp_lin % 4 == 1 && cstamp_lin / 4 < 64) ? cstamp_lin / 4 : -1;
+#endif
+  BX_CSTAMP(0);
   const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, b = (bid / (tiles_x * tiles_y)) * IMGS;      // first image of the tile
   const int y0 = ty * TH, x0 = tx * TW, co_base = blockIdx.y * (NC * 16);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
@@ -382,6 +398,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
       }
     }
     __syncthreads();
+    if (chunk == 0) BX_CSTAMP(1);
     // Measured here and dropped (round 2): a pinned read-ahead ring for the pixel fragments as in k_conv_mfma_c (every shape 3-5 %
     // slower: with NC >= 2 MFMAs per fragment and 2-4 waves per SIMD the scheduler's own order already hides the LDS latency), and
     // requesting the bias before the chunk loop instead of in the epilogue (no change; 4-60 more registers).
@@ -405,6 +422,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
         for (int n = 0; n < NC; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s % 3][n], bv, acc[i][n], 0, 0, 0);
       }
     }
+    if (chunk < 4) BX_CSTAMP(2 + chunk);
   }
   // epilogue: lane = (pixel li of tile t, output channels co_base + n*16 + 4g .. +3).  y / mask / addend share one shape:
   // 32-bit byte offsets through buffer resources, out-of-image lanes point past the end (loads read 0, stores are dropped)
@@ -508,19 +526,9 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
       __builtin_amdgcn_raw_buffer_store_b64(out, yres, offs[i][n], 0, 0);
     }
   }
+  BX_CSTAMP(6);
 }
 
-#ifdef BX_CONV_STAMPS
-// Diagnostic build only (hipcc -DBX_CONV_STAMPS, tools/conv_stamps.py): shader-clock stamps of one workgroup in four.
-// Slots per workgroup: [start, first halo image staged, end of chunk 0..3, epilogue stores issued].
-__device__ unsigned long long bx_conv_stamps[64 * 8];
-extern "C" int bx_debug_conv_stamps(unsigned long long* host_out) {
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(bx_conv_stamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -1;
-}
-#define BX_CSTAMP(i) do { if (cstamp_wg >= 0 && threadIdx.x == 0) bx_conv_stamps[cstamp_wg * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define BX_CSTAMP(i) do { } while (0)
-#endif
 // Channel-split variant for the 64-channel-chunk layers (stages 3-5, Ci % 64 == 0, Co % 64 == 0).
 // k_conv_mfma gives each wave a quarter of the workgroup's PIXELS and all of its NC*16 output channels, so the four waves fetch the
 // same weight fragments (4 x NC KB per K-step through the CU's 64 B/clk vector-memory path: 128-256 cycles for 128 cycles of MFMA)

@@ -28,25 +28,37 @@ lib = L.load()
 lib.bx_debug_conv_stamps.restype = C.c_int
 lib.bx_debug_conv_stamps.argtypes = [C.c_void_p]
 dev = torch.device("cuda:0")
-for (H, W, ci, co) in ((32, 64, 64, 64), (16, 32, 128, 128), (8, 16, 128, 256), (8, 16, 256, 256)):
+# (H, W, ci, co, kind): fwd = bias + ReLU (channel-split kernel where it applies), dgrad = ReLU mask of the layer below + nothing
+# added (pixel-split k_conv_mfma except at 256 -> 256)
+CASES = [(32, 64, 64, 64, "fwd"), (32, 64, 64, 64, "dgrad"), (16, 32, 128, 128, "fwd"), (16, 32, 128, 128, "dgrad"), (16, 32, 128, 64, "dgrad"),
+         (8, 16, 128, 256, "fwd"), (8, 16, 256, 256, "fwd"), (8, 16, 256, 256, "dgrad"), (8, 16, 256, 128, "dgrad")]
+clock_mhz = None
+for (H, W, ci, co, kind) in CASES:
     B = 64
     x = torch.randn(B, H, W, ci, device=dev).bfloat16()
-    w = torch.randn(co, ci, 3, 3, device=dev) / (3 * ci ** 0.5)
+    w = torch.randn(co, ci, 3, 3, device=dev) / (3 * ci ** 0.5) if kind == "fwd" else torch.randn(ci, co, 3, 3, device=dev) / (3 * ci ** 0.5)
     bias = torch.zeros(co, device=dev)
-    packed = ops._pack(w, False, torch.bfloat16)
+    mask = torch.randn(B, H, W, co, device=dev).bfloat16()
+    packed = ops._pack(w, kind == "dgrad", torch.bfloat16)
+    run = (lambda: ops._conv(x, packed, bias, None, None, True, torch.bfloat16)) if kind == "fwd" else (lambda: ops._conv(x, packed, None, mask, None, False, torch.bfloat16))
     for _ in range(3):
-        ops._conv(x, packed, bias, None, None, True, torch.bfloat16)
+        run()
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
     buf = (C.c_ulonglong * 512)()
     assert lib.bx_debug_conv_stamps(C.cast(buf, C.c_void_p)) == 0
     nch = min(4, ci // 64)
     rows = [[buf[i * 8 + k] for k in range(7)] for i in range(64)]
     rows = [r for r in rows if r[0] and r[6] > r[0]]
-    t0 = min(r[0] for r in rows)
-    print(f"== {H}x{W} {ci}->{co}: {len(rows)} sampled workgroups; columns: start offset | staged | chunk0..{nch - 1} | epilogue (cycles)")
-    for r in rows[:10]:
+    print(f"== {kind} {H}x{W} {ci}->{co}: {us:.1f} us per launch (eager, back to back); {len(rows)} sampled workgroups; cycles: staged | chunk0..{nch - 1} | epilogue | lifetime")
+    for r in rows[:6]:
         seq = [r[0], r[1]] + [r[2 + k] for k in range(nch)] + [r[6]]
-        d = [r[0] - t0] + [seq[k + 1] - seq[k] for k in range(len(seq) - 1)]
-        print("   " + " ".join(f"{v:8d}" for v in d))
+        d = [seq[k + 1] - seq[k] for k in range(len(seq) - 1)]
+        print("   " + " ".join(f"{v:8d}" for v in d) + f" | {r[6] - r[0]:8d}")
     life = sorted(r[6] - r[0] for r in rows)
-    print(f"   workgroup lifetime: median {life[len(life) // 2]} cycles, max {life[-1]}; last end - first start {max(r[6] for r in rows) - t0}")
+    print(f"   workgroup lifetime: median {life[len(life) // 2]} cycles, max {life[-1]}  (kernel {us:.1f} us = {us * 2.1e3:.0f} cycles at 2.1 GHz)")
