@@ -321,12 +321,19 @@ extern "C" int bx_debug_conv_stamps(unsigned long long* host_out) {
 // (8x16 and 16x32 maps, 64-channel chunks) ran 4-8 MFMAs per K-step per wave and spent 470-830 cycles on each (in-kernel stamps).
 // C8 (round 2): the output tensor has 8 channels while the packed operand has 16 rows (see bx_conv3x3_mfma_supported); a template
 // flag, so that the ordinary instantiations keep their register allocation (as a run-time test it cost <32,2,32> one wave of occupancy)
-template <int CK, int NC, int TW, int IMGS = 1, bool POOL = false, bool C8 = false>
+// W22 (round 3; plain forward / data-gradient launches of the 64-channel-chunk layers): the four waves as a 2 x 2 grid -- wave (wpix, wc)
+// owns HALF of the pixel tiles and HALF of the NC channel tiles (same accumulator count) instead of a quarter of the pixels and all
+// channels, so a weight fragment is fetched by two waves instead of four.  The pixel-split mapping pulls NC KB per K-step per wave
+// through the CU's 64 B/clk vector-memory path for 16 NC cycles of MFMA each (in-kernel stamps: 800 cycles per K-step for 2 x 256
+// cycles of MFMA at two waves per SIMD); the fp32-storage kernels (conv3x3_split.hip), where it was found, gained 20 %.
+template <int CK, int NC, int TW, int IMGS = 1, bool POOL = false, bool C8 = false, bool W22 = false>
 __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const bf16_t* __restrict__ mask_src, const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
     int H, int W, int Ci, int Co, int relu, int tiles_x, int tiles_y, uint32_t x_bytes, BxConvPoolEpi pe, WgradRedJob red, int nred) {
   constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CKB = CK * 2, NCH = CK / 8, KS = (9 * CK + 31) / 32;
-  constexpr int MP = IMGS * TH * TW / 64;   // 16-pixel tiles per wave
+  constexpr int MP = (W22 ? 2 : 1) * IMGS * TH * TW / 64;   // 16-pixel tiles per wave
+  constexpr int NCW = W22 ? NC / 2 : NC;    // 16-channel tiles per wave
+  static_assert(!W22 || (NC % 2 == 0 && !POOL && !C8), "2 x 2 wave grid: even NC, plain epilogue");
   constexpr int TPI = TH * TW / 16;         // 16-pixel tiles per image
   constexpr int TPR = TW / 16;              // 16-pixel tiles per tile row
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -342,15 +349,16 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
 #endif
   BX_CSTAMP(0);
   const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, b = (bid / (tiles_x * tiles_y)) * IMGS;      // first image of the tile
-  const int y0 = ty * TH, x0 = tx * TW, co_base = blockIdx.y * (NC * 16);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+  const int wpix = W22 ? wave >> 1 : wave;  // which group of pixel tiles this wave owns
+  const int y0 = ty * TH, x0 = tx * TW, co_base = blockIdx.y * (NC * 16) + (W22 ? (wave & 1) * NCW * 16 : 0);
   if (POOL) conv_pool_transpose_w1x1(pe, Co);
 
-  f32x4 acc[MP][NC];
+  f32x4 acc[MP][NCW];
 #pragma unroll
   for (int i = 0; i < MP; ++i)
 #pragma unroll
-    for (int n = 0; n < NC; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NCW; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nchunk = Ci / CK;
   const int Cw = C8 ? 16 : Co;              // rows of the packed operand (C8: rows 8..15 are zero and their results are not stored)
@@ -380,10 +388,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
     }
     const bf16_t* wchunk = wp + (size_t)chunk * KS * Cw * 32;
     // weight fragments run two K-steps ahead of the MFMAs that consume them (L2 latency >> one K-step)
-    bf16x8 a[3][NC];
-    auto load_a = [&](int s, bf16x8 (&dst)[NC]) {
+    bf16x8 a[3][NCW];
+    auto load_a = [&](int s, bf16x8 (&dst)[NCW]) {
 #pragma unroll
-      for (int n = 0; n < NC; ++n)
+      for (int n = 0; n < NCW; ++n)
         dst[n] = *reinterpret_cast<const bf16x8*>(wchunk + ((size_t)s * Cw + co_base + n * 16 + li) * 32 + 8 * g);
     };
     load_a(0, a[0]);
@@ -414,12 +422,12 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
       const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
       for (int i = 0; i < MP; ++i) {
-        const int t = wave * MP + i, img = t / TPI, tl = t % TPI;
+        const int t = wpix * MP + i, img = t / TPI, tl = t % TPI;
         const int p = (img * HH + tl / TPR + dy) * HWID + (tl % TPR) * 16 + li + dx;
         bf16x8 bv = *reinterpret_cast<const bf16x8*>(lds + p * CKB + 16 * lds_chunk<CK>(c, p));
         if (!valid) bv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int n = 0; n < NC; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s % 3][n], bv, acc[i][n], 0, 0, 0);
+        for (int n = 0; n < NCW; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s % 3][n], bv, acc[i][n], 0, 0, 0);
       }
     }
     if (chunk < 4) BX_CSTAMP(2 + chunk);
@@ -432,25 +440,25 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
   const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src ? mask_src : y), 0, mbits ? y_bytes / 8 : y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend : y), 0, y_bytes, 0x00020000);
   const bool ch_ok = C8 ? g < 2 : true;           // false only for the zero rows of an 8-channel output
-  float4 bz[NC];
+  float4 bz[NCW];
 #pragma unroll
-  for (int n = 0; n < NC; ++n)
+  for (int n = 0; n < NCW; ++n)
     bz[n] = bias && ch_ok ? *reinterpret_cast<const float4*>(bias + co_base + n * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
   const uint32_t lane_off = (uint32_t)((((b * H + y0) * W + x0 + li) * Co + co_base + 4 * g) * 2);
   // Epilogue operands (ReLU mask of the data gradient, residual addend): ALL of a thread's loads are issued before the first
   // one is consumed.  Loaded inside the store loop each of the MP*NC iterations was its own memory round trip (the ISA had
   // one full `s_waitcnt vmcnt(0)` per load: 32 serial trips in the <64,4,32> data-gradient launches).  The main loop's
   // fragment registers are dead here, so the batch does not raise the kernel's register peak.
-  uint32_t offs[MP][NC];
-  u32x2 mk[MP][NC], ad[MP][NC];
+  uint32_t offs[MP][NCW];
+  u32x2 mk[MP][NCW], ad[MP][NCW];
 #pragma unroll
   for (int i = 0; i < MP; ++i) {
-    const int t = wave * MP + i, img = t / TPI, tl = t % TPI;
+    const int t = wpix * MP + i, img = t / TPI, tl = t % TPI;
     const int oy = y0 + tl / TPR, ox = x0 + (tl % TPR) * 16 + li;
     const bool inb = oy < H && ox < W && ch_ok;
     const uint32_t orow = lane_off + (uint32_t)((((img * H + tl / TPR) * W + (tl % TPR) * 16) * Co) * 2);
 #pragma unroll
-    for (int n = 0; n < NC; ++n) offs[i][n] = inb ? orow + (uint32_t)(n * 32) : 0x80000000u;
+    for (int n = 0; n < NCW; ++n) offs[i][n] = inb ? orow + (uint32_t)(n * 32) : 0x80000000u;
   }
   if constexpr (POOL) {          // conv3 of a Block: y = relu(conv + bias) stored, then pool + statistics from the stored values
 #pragma unroll
@@ -483,24 +491,24 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
 #pragma unroll
       for (int i = 0; i < MP; ++i)
 #pragma unroll
-        for (int n = 0; n < NC; ++n) mk[i][n].x = __builtin_amdgcn_raw_buffer_load_b8(mres, offs[i][n] >> 3, 0, 0);
+        for (int n = 0; n < NCW; ++n) mk[i][n].x = __builtin_amdgcn_raw_buffer_load_b8(mres, offs[i][n] >> 3, 0, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < MP; ++i)
 #pragma unroll
-        for (int n = 0; n < NC; ++n) mk[i][n] = __builtin_amdgcn_raw_buffer_load_b64(mres, offs[i][n], 0, 0);
+        for (int n = 0; n < NCW; ++n) mk[i][n] = __builtin_amdgcn_raw_buffer_load_b64(mres, offs[i][n], 0, 0);
     }
   }
   if (addend) {
 #pragma unroll
     for (int i = 0; i < MP; ++i)
 #pragma unroll
-      for (int n = 0; n < NC; ++n) ad[i][n] = __builtin_amdgcn_raw_buffer_load_b64(ares, offs[i][n], 0, 0);
+      for (int n = 0; n < NCW; ++n) ad[i][n] = __builtin_amdgcn_raw_buffer_load_b64(ares, offs[i][n], 0, 0);
   }
 #pragma unroll
   for (int i = 0; i < MP; ++i) {
 #pragma unroll
-    for (int n = 0; n < NC; ++n) {
+    for (int n = 0; n < NCW; ++n) {
       float v[4] = {acc[i][n][0] + bz[n].x, acc[i][n][1] + bz[n].y, acc[i][n][2] + bz[n].z, acc[i][n][3] + bz[n].w};
       if (relu & 1) {
 #pragma unroll
@@ -1567,6 +1575,15 @@ static int launch_conv(const void* x, const void* wp, const float* bias, const v
       return BX_OK;
     }
     BX_FAIL(BX_EUNSUPPORTED, "bx_conv3x3(pooled): needs at least 16 input channels");
+  }
+  if constexpr (CK == 64 && NC % 2 == 0) {
+    static const bool w22 = !(getenv("BX_CONV_W22") && atoi(getenv("BX_CONV_W22")) == 0);     // 2 x 2 wave grid (see k_conv_mfma)
+    if (w22) {
+      hipLaunchKernelGGL((k_conv_mfma<CK, NC, TW, 1, false, false, true>), grid, dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)wp, bias,
+                         (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), none, rj, nred);
+      BX_CHECK_LAUNCH("bx_conv3x3(mfma, 2 x 2 waves)");
+      return BX_OK;
+    }
   }
   hipLaunchKernelGGL((k_conv_mfma<CK, NC, TW>), grid, dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)wp, bias,
                      (const bf16_t*)mask, (const bf16_t*)addend, (bf16_t*)y, H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 2), none, rj, nred);

@@ -112,25 +112,39 @@ __device__ __forceinline__ int split_lds_chunk(int c, int p) {
 
 // ================================================================================================
 // forward / data gradient
-template <int CK, int NC, int TW>
-__global__ __launch_bounds__(256) void k_conv_split(const float* __restrict__ x, const bf16_t* __restrict__ wp, uint32_t lo_off,
+// SB (64-channel chunks): the weight fragments are SINGLE-buffered -- image t of K-step s+1 is requested into the registers of image
+// t of step s right after that image's last sweep (sweeps ordered h, h, h, m, m, l on the weight side), 48 instead of 96 registers, so
+// that two workgroups fit a CU (<= 256 registers) and one's MFMA sweeps cover the other's fragment and halo latencies.  Without it
+// <64,4,16> took 256 + 82 registers: one wave per SIMD with every LDS / L2 latency exposed (in place it still spills at NC = 4: the
+// launcher gives 64-channel-chunk layers 32 output channels per workgroup).
+// W22: the four waves form a 2 x 2 grid -- wave (wp, wc) owns HALF of the workgroup's pixel tiles and HALF of its output channels
+// (MPw = 2 MP tiles x NCw = NC / 2 channel tiles: the same accumulators) instead of a quarter of the pixels and all channels.  A
+// weight fragment is then fetched by two waves instead of four: the pixel-split mapping pulls 3 NC KB per K-step per wave through the
+// CU's 64 B/clk vector-memory path for 768 cycles of MFMA (NC = 4: 16 B/clk per wave, i.e. the whole path at one wave per SIMD --
+// in-kernel the MFMA pipe sat at ~50 %); 2 x 2 halves that and doubles the (cheap) LDS pixel-fragment reads.  Measured at B = 64
+// (forward / data gradient, us): 64->64 66.4 / 69.8 -> 56.6 / 57.9, 128->128 60.5 / 62.5 -> 48.4 / 50.3, 256->256 56.9 / 56.5 -> 45.8 / 48.3;
+// the HBM-bound early stages (chunks of 8-32 channels) do not gain and keep the pixel-split mapping.
+template <int CK, int NC, int TW, bool W22 = (CK == 64 && NC % 2 == 0), bool SB = false>
+__global__ __launch_bounds__(256, SB ? 2 : 1) void k_conv_split(const float* __restrict__ x, const bf16_t* __restrict__ wp, uint32_t lo_off,
     const float* __restrict__ bias, const float* __restrict__ mask_src, const float* __restrict__ addend, float* __restrict__ y,
     int H, int W, int Ci, int Co, int relu, int tiles_x, int tiles_y, uint32_t x_bytes, uint32_t y_bytes) {
   constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CKB = CK * 2, NCH = CK / 8, KS = (9 * CK + 31) / 32;
-  constexpr int MP = TH * TW / 64;          // 16-pixel tiles per wave
+  constexpr int MP = (W22 ? 2 : 1) * TH * TW / 64;          // 16-pixel tiles per wave
+  constexpr int NCW = W22 ? NC / 2 : NC;    // 16-channel tiles per wave
   constexpr int TPR = TW / 16;              // 16-pixel tiles per tile row
   constexpr int IMG = HH * HWID * CKB;      // bytes of one LDS image (h; the m and l images follow)
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int bid = (int)blockIdx.x;
   const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, b = bid / (tiles_x * tiles_y);
-  const int y0 = ty * TH, x0 = tx * TW, co_base = blockIdx.y * (NC * 16);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+  const int wpix = W22 ? wave >> 1 : wave;  // which group of pixel tiles this wave owns
+  const int y0 = ty * TH, x0 = tx * TW, co_base = blockIdx.y * (NC * 16) + (W22 ? (wave & 1) * NCW * 16 : 0);
 
-  f32x4 acc[MP][NC];
+  f32x4 acc[MP][NCW];
 #pragma unroll
   for (int i = 0; i < MP; ++i)
 #pragma unroll
-    for (int n = 0; n < NC; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NCW; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nchunk = Ci / CK;
   constexpr int NU = HH * HWID * NCH, NR = (NU + 255) / 256;
@@ -153,14 +167,15 @@ __global__ __launch_bounds__(256) void k_conv_split(const float* __restrict__ x,
       hoff[k] += (uint32_t)(CK * 4);
     }
     const bf16_t* wchunk = wp + (size_t)chunk * KS * Co * 32;
-    bf16x8 a[2][3][NC];                     // weight fragments (h, m, l) one K-step ahead
-    auto load_a = [&](int s, bf16x8 (&d)[3][NC]) {
+    bf16x8 a[SB ? 1 : 2][3][NCW];           // weight fragments (h, m, l): one K-step ahead in a second set, or (SB) in place
+    auto load_a1 = [&](int s, int t, bf16x8 (&d)[NCW]) {
 #pragma unroll
-      for (int n = 0; n < NC; ++n) {
-        const bf16_t* p = wchunk + ((size_t)s * Co + co_base + n * 16 + li) * 32 + 8 * g;
+      for (int n = 0; n < NCW; ++n)
+        d[n] = *reinterpret_cast<const bf16x8*>(wchunk + ((size_t)s * Co + co_base + n * 16 + li) * 32 + 8 * g + (size_t)t * lo_off);
+    };
+    auto load_a = [&](int s, bf16x8 (&d)[3][NCW]) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) d[t][n] = *reinterpret_cast<const bf16x8*>(p + (size_t)t * lo_off);
-      }
+      for (int t = 0; t < 3; ++t) load_a1(s, t, d[t]);
     };
     load_a(0, a[0]);
     __syncthreads();                          // previous chunk's fragment reads are done
@@ -180,8 +195,10 @@ __global__ __launch_bounds__(256) void k_conv_split(const float* __restrict__ x,
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      if (s + 1 < KS) load_a(s + 1, a[(s + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch up here (hipcc otherwise sinks the loads to their use)
+      if constexpr (!SB) {
+        if (s + 1 < KS) load_a(s + 1, a[(s + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);    // keep the prefetch up here (hipcc otherwise sinks the loads to their use)
+      }
       const int q0 = s * 32 + 8 * g;
       int tap = q0 / CK;
       const int c = (q0 % CK) / 8;
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(256) void k_conv_split(const float* __restrict__ x,
       bf16x8 bv[3][MP];
 #pragma unroll
       for (int i = 0; i < MP; ++i) {
-        const int t = wave * MP + i;
+        const int t = wpix * MP + i;
         const int p = (t / TPR + dy) * HWID + (t % TPR) * 16 + li + dx;
         const char* src = lds + p * CKB + 16 * split_lds_chunk<CK>(c, p);
 #pragma unroll
@@ -203,8 +220,23 @@ __global__ __launch_bounds__(256) void k_conv_split(const float* __restrict__ x,
       // six sweeps over the accumulators, smallest partial products first: consecutive MFMAs never write the same registers
 #define BX_SWEEP(TA, TB) \
       _Pragma("unroll") for (int i = 0; i < MP; ++i) \
-      _Pragma("unroll") for (int n = 0; n < NC; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][TA][n], bv[TB][i], acc[i][n], 0, 0, 0);
-      BX_SPLIT_TERMS(BX_SWEEP)
+      _Pragma("unroll") for (int n = 0; n < NCW; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[SB ? 0 : (s & 1)][TA][n], bv[TB][i], acc[i][n], 0, 0, 0);
+      if constexpr (SB) {                     // weight image by weight image, each re-requested for the next K-step after its last sweep
+        BX_SWEEP(0, 2) BX_SWEEP(0, 1) BX_SWEEP(0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < KS) load_a1(s + 1, 0, a[0][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        BX_SWEEP(1, 1) BX_SWEEP(1, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < KS) load_a1(s + 1, 1, a[0][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        BX_SWEEP(2, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < KS) load_a1(s + 1, 2, a[0][2]);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        BX_SPLIT_TERMS(BX_SWEEP)
+      }
 #undef BX_SWEEP
     }
   }
@@ -212,34 +244,34 @@ __global__ __launch_bounds__(256) void k_conv_split(const float* __restrict__ x,
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t mres = __builtin_amdgcn_make_buffer_rsrc((void*)(mask_src ? mask_src : y), 0, y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend : y), 0, y_bytes, 0x00020000);
-  float4 bz[NC];
+  float4 bz[NCW];
 #pragma unroll
-  for (int n = 0; n < NC; ++n)
+  for (int n = 0; n < NCW; ++n)
     bz[n] = bias ? *reinterpret_cast<const float4*>(bias + co_base + n * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
   uint32_t offs[MP];
 #pragma unroll
   for (int i = 0; i < MP; ++i) {
-    const int t = wave * MP + i;
+    const int t = wpix * MP + i;
     const int oy = y0 + t / TPR, ox = x0 + (t % TPR) * 16 + li;
     offs[i] = (oy < H && ox < W) ? (uint32_t)((((b * H + oy) * W + ox) * Co + co_base + 4 * g) * 4) : 0x80000000u;
   }
-  u32x4 mk[MP][NC], ad[MP][NC];
+  u32x4 mk[MP][NCW], ad[MP][NCW];
   if (mask_src) {
 #pragma unroll
     for (int i = 0; i < MP; ++i)
 #pragma unroll
-      for (int n = 0; n < NC; ++n) mk[i][n] = __builtin_amdgcn_raw_buffer_load_b128(mres, offs[i] + (uint32_t)(n * 64), 0, 0);
+      for (int n = 0; n < NCW; ++n) mk[i][n] = __builtin_amdgcn_raw_buffer_load_b128(mres, offs[i] + (uint32_t)(n * 64), 0, 0);
   }
   if (addend) {
 #pragma unroll
     for (int i = 0; i < MP; ++i)
 #pragma unroll
-      for (int n = 0; n < NC; ++n) ad[i][n] = __builtin_amdgcn_raw_buffer_load_b128(ares, offs[i] + (uint32_t)(n * 64), 0, 0);
+      for (int n = 0; n < NCW; ++n) ad[i][n] = __builtin_amdgcn_raw_buffer_load_b128(ares, offs[i] + (uint32_t)(n * 64), 0, 0);
   }
 #pragma unroll
   for (int i = 0; i < MP; ++i) {
 #pragma unroll
-    for (int n = 0; n < NC; ++n) {
+    for (int n = 0; n < NCW; ++n) {
       float v[4] = {acc[i][n][0] + bz[n].x, acc[i][n][1] + bz[n].y, acc[i][n][2] + bz[n].z, acc[i][n][3] + bz[n].w};
       if (relu) {
 #pragma unroll
@@ -265,15 +297,24 @@ static int launch_split(const float* x, const bf16_t* wp, const float* bias, con
                         int B, int H, int W, int Ci, int Co, int relu, hipStream_t s) {
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + 7) / 8;
   const size_t lds = (size_t)3 * 10 * (TW + 2) * CK * 2;
-  static bool attr_done = false;
-  if (lds > 64 * 1024 && !attr_done) {
-    if (hipFuncSetAttribute((const void*)k_conv_split<CK, NC, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      BX_FAIL(BX_EHIP, "bx_conv3x3(split): cannot reserve %zu bytes of LDS", lds);
-    attr_done = true;
+  static_assert((size_t)3 * 10 * (TW + 2) * CK * 2 <= 64 * 1024 + 8 * 1024 || true, "");
+  if (lds > 64 * 1024) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute((const void*)k_conv_split<CK, NC, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_conv_split<CK, NC, TW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        BX_FAIL(BX_EHIP, "bx_conv3x3(split): cannot reserve %zu bytes of LDS", lds);
+      attr_done = true;
+    }
   }
+  static const bool w22 = !(getenv("BX_SPLIT_W22") && atoi(getenv("BX_SPLIT_W22")) == 0);      // 0: the pixel-split wave mapping (A/B sweeps)
   dim3 grid((unsigned)(tiles_x * tiles_y * B), (unsigned)(Co / (16 * NC)));
-  hipLaunchKernelGGL((k_conv_split<CK, NC, TW>), grid, dim3(256), lds, s, x, wp, (uint32_t)split_image_elems(Ci, Co), bias, mask, addend, y,
-                     H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 4), (uint32_t)((size_t)B * H * W * Co * 4));
+  if (w22)
+    hipLaunchKernelGGL((k_conv_split<CK, NC, TW>), grid, dim3(256), lds, s, x, wp, (uint32_t)split_image_elems(Ci, Co), bias, mask, addend, y,
+                       H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 4), (uint32_t)((size_t)B * H * W * Co * 4));
+  else
+    hipLaunchKernelGGL((k_conv_split<CK, NC, TW, false>), grid, dim3(256), lds, s, x, wp, (uint32_t)split_image_elems(Ci, Co), bias, mask, addend, y,
+                       H, W, Ci, Co, relu, tiles_x, tiles_y, (uint32_t)((size_t)B * H * W * Ci * 4), (uint32_t)((size_t)B * H * W * Co * 4));
   BX_CHECK_LAUNCH("bx_conv3x3(split mfma)");
   return BX_OK;
 }
