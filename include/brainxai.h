@@ -82,6 +82,12 @@ int bx_conv3x3_pack_many(const bxPackJob* jobs_device, int njobs, int total_bloc
  * the two are independent and both sit at the start of every training step). */
 int bx_conv3x3_pack_many_layout(const bxPackJob* jobs_device, int njobs, int total_blocks, const float* src_nchw,
                                 void* dst_nhwc_bf16, int B, int C, int H, int W, int Cp, bxStream stream);
+/* Evaluation sweeps (Grad-CAM over a dataset, integrated-gradients passes): njobs may be 0 (total_blocks 0, jobs_device ignored) when
+ * no parameter changed since the operands were last packed -- the launch is then the layout conversion alone -- and the batch's address
+ * may come from a DEVICE slot (src_slot != NULL: *src_slot is read by the kernel, src_nchw is ignored), so that a captured graph can be
+ * replayed on the caller's batch without copying it into a static buffer (bx_store_u64x2 fills the slot, stream-ordered). */
+int bx_conv3x3_pack_layout_ex(const bxPackJob* jobs_device, int njobs, int total_blocks, const float* src_nchw,
+                              const float* const* src_slot, void* dst_nhwc_bf16, int B, int C, int H, int W, int Cp, bxStream stream);
 /* The launch that opens a training step of the multimodal model (reference forward NB:1095-1105 with nn.Dropout in both
  * branches): packing, the optional layout conversion (src_nchw / dst_nhwc_bf16 both NULL: none) and bx_seed_next2's work
  * (both branches' dropout counters advance, out_a / out_b receive the seeds of this forward pass) in one launch. */
@@ -260,6 +266,10 @@ typedef struct {
                          * forward and backward must see the same flag.  0: the layer-by-layer path. */
   float dropout_p2;     /* rate of the SECOND dropout (after pool 2); < 0: the same as dropout_p (EEGNet shares one module,
                          * models.py:255; EEGNetAttentionDeep has dropout1 / dropout2, models.py:152-164) */
+  const float* const* x_slot;  /* NULL, or a DEVICE word holding the input's address (bx_store_u64x2): bx_eeg_features_fwd then reads x
+                         * through it -- a captured graph is replayed on the caller's batch without a copy.  Collapsed evaluation-mode
+                         * path only (collapse = 1, training = 0), where one kernel reads x and nothing is kept for a backward;
+                         * the `x` argument must still be a valid pointer of the same shape (it is what an eager run reads). */
 } bxEegDesc;
 /* Parameter block: pointers to the fp32 tensors of the module, reference names in comments. */
 typedef struct {
@@ -437,6 +447,9 @@ int bx_adamw_step_dev(float* p, const float* g, float* m, float* v, size_t n, co
  * returns), so the host buffer needs no lifetime beyond the call -- how FlatAdamW refreshes `hyper` when a torch LR scheduler
  * changed param_groups (DDP:98-101), also between replays of a captured step. */
 int bx_store_f32x8(float* dst_device, const float* values_host, bxStream stream);
+/* dst_device[0] = a, dst_device[1] = b (64-bit words, e.g. device addresses for bxEegDesc.x_slot / bx_conv3x3_pack_layout_ex's src_slot);
+ * the values travel as kernel arguments, the store is ordered on `stream`. */
+int bx_store_u64x2(uint64_t* dst_device, uint64_t a, uint64_t b, bxStream stream);
 /* sum of squares of a flat fp32 arena -> out[1] (DDP loop's manual L2 term, DDP:52-53). */
 int bx_sumsq(const float* x, size_t n, float* out, bxStream stream);
 /* LIME's batched inference (XAI_Multimodality.py:1567-1574): uint8 images [N,H,W,C] -> scale * value in the internal

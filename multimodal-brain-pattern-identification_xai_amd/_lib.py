@@ -29,7 +29,7 @@ class TailDesc(C.Structure):
 class EegDesc(C.Structure):
     _fields_ = [("B", i32), ("Chans", i32), ("T", i32), ("F1", i32), ("D", i32), ("F2", i32), ("K1", i32), ("K2", i32),
                 ("P1", i32), ("P2", i32), ("training", i32), ("eps", f32), ("momentum", f32), ("dropout_p", f32),
-                ("salt", u32), ("dtype", i32), ("collapse", i32), ("dropout_p2", f32)]
+                ("salt", u32), ("dtype", i32), ("collapse", i32), ("dropout_p2", f32), ("x_slot", vp)]
 
 
 class EegParams(C.Structure):
@@ -78,6 +78,7 @@ SIGNATURES = {
     "bx_conv3x3_pack_split": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "bx_conv3x3_pack_many": (i32, [vp, i32, i32, vp]),
     "bx_conv3x3_pack_many_layout": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "bx_conv3x3_pack_layout_ex": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "bx_conv3x3_pair_supported": (i32, [i32, i32, i32, i32]),
     "bx_conv3x3_pair": (i32, [vp] * 9 + [i32] * 7 + [vp]),
     "bx_conv3x3_pack_many_step": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
@@ -139,6 +140,7 @@ SIGNATURES = {
     "bx_adamw_step_words": (sz, [sz]),
     "bx_adamw_step_dev": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
     "bx_store_f32x8": (i32, [vp, vp, vp]),
+    "bx_store_u64x2": (i32, [vp, C.c_uint64, C.c_uint64, vp]),
     "bx_profile_next_conv3": (i32, [vp, vp]),
     "bx_sumsq": (i32, [vp, sz, vp, vp]),
     "bx_u8_to_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),

@@ -69,12 +69,14 @@ void bx_conv3x3_mfma_pack_launch(const float* w_oihw, void* packed, int Cout, in
 // Many pack jobs in ONE launch (all 3x3 convolutions of the model, forward and data-gradient operands): the job
 // table lives in device memory and is built once by the host (parameter pointers are stable under FlatAdamW).
 // Optional second role (workgroups >= npack): the batch's fp32 NCHW -> bf16 NHWC(Cp) conversion, which is independent of
-// the packing and otherwise a launch of its own at the start of every step (lsrc == nullptr: no such workgroups).
+// the packing and otherwise a launch of its own at the start of every step (lsrc == nullptr: no such workgroups).  njobs == 0
+// (npack == 0): only that role -- evaluation sweeps whose weights did not change since the last pack (bx_conv3x3_pack_layout_ex).
 // Optional third role (round 2): the dropout counters of the two branches advance here (thread 0 / 1 of workgroup 0; sa == nullptr:
 // not wanted) -- this launch opens the training step, every consumer of the seeds is a later launch.
 __global__ __launch_bounds__(256) void k_pack_mfma_many(const bxPackJob* __restrict__ jobs, int njobs, int npack, const float* __restrict__ lsrc,
                                                         bf16_t* __restrict__ ldst, int C, int Cp, int HW, int nbx,
-                                                        uint64_t* sa, uint64_t* oa, uint64_t* sb, uint64_t* ob) {
+                                                        uint64_t* sa, uint64_t* oa, uint64_t* sb, uint64_t* ob, const float* const* lslot = nullptr) {
+  if (lslot) lsrc = *lslot;                                // the batch's address comes from a device slot (graph replays on caller buffers)
   if (sa && blockIdx.x == 0 && threadIdx.x < 2) {
     uint64_t* st = threadIdx.x ? sb : sa;
     uint64_t* ou = threadIdx.x ? ob : oa;
@@ -171,6 +173,21 @@ extern "C" int bx_conv3x3_pack_many_layout(const bxPackJob* jobs_device, int njo
                      total_blocks, src_nchw, (bf16_t*)dst_nhwc_bf16, C, Cp, (int)HW, (int)nbx, (uint64_t*)nullptr, (uint64_t*)nullptr,
                      (uint64_t*)nullptr, (uint64_t*)nullptr);
   BX_CHECK_LAUNCH("bx_conv3x3_pack_many_layout");
+  return BX_OK;
+}
+extern "C" int bx_conv3x3_pack_layout_ex(const bxPackJob* jobs_device, int njobs, int total_blocks, const float* src_nchw,
+                                         const float* const* src_slot, void* dst_nhwc_bf16, int B, int C, int H, int W, int Cp, bxStream stream) {
+  BX_REQUIRE(njobs >= 0 && (njobs == 0 ? total_blocks == 0 : (jobs_device && total_blocks > 0)), "bx_conv3x3_pack_layout_ex: bad job table");
+  BX_REQUIRE((src_nchw || src_slot) && dst_nhwc_bf16, "bx_conv3x3_pack_layout_ex: needs a source (pointer or device slot) and a destination");
+  BX_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Cp % 8 == 0 && C <= Cp, "bx_conv3x3_pack_layout_ex: Cp must be a multiple of 8 and >= C");
+  const long long HW = (long long)H * W;
+  const long long nbx = (HW + 255) / 256;
+  BX_REQUIRE(HW < (1ll << 31) && nbx * B + total_blocks < (1ll << 31), "bx_conv3x3_pack_layout_ex: input too large");
+  hipLaunchKernelGGL(k_pack_mfma_many, dim3((unsigned)(total_blocks + nbx * B)), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs,
+                     total_blocks, src_slot ? (const float*)dst_nhwc_bf16 /* non-null marker, replaced in-kernel */ : src_nchw,
+                     (bf16_t*)dst_nhwc_bf16, C, Cp, (int)HW, (int)nbx, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr,
+                     (uint64_t*)nullptr, src_slot);
+  BX_CHECK_LAUNCH("bx_conv3x3_pack_layout_ex");
   return BX_OK;
 }
 extern "C" int bx_conv3x3_pack_many_step(const bxPackJob* jobs_device, int njobs, int total_blocks, const float* src_nchw, void* dst_nhwc_bf16,

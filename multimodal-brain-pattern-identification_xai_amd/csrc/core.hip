@@ -349,6 +349,15 @@ extern "C" int bx_store_f32x8(float* dst_device, const float* values_host, bxStr
   BX_CHECK_LAUNCH("bx_store_f32x8");
   return BX_OK;
 }
+// two 64-bit words (device addresses) into a device slot pair: a captured graph's kernels read their input pointers from such slots
+// (bxEegDesc.x_slot, bx_conv3x3_pack_layout_ex), so a replay can be pointed at the caller's batch without copying it
+__global__ void k_store_u64x2(uint64_t* dst, uint64_t a, uint64_t b) { if (threadIdx.x < 2) dst[threadIdx.x] = threadIdx.x ? b : a; }
+extern "C" int bx_store_u64x2(uint64_t* dst_device, uint64_t a, uint64_t b, bxStream stream) {
+  BX_REQUIRE(dst_device && ((uintptr_t)dst_device & 7) == 0, "bx_store_u64x2: dst must be an 8-byte aligned device pointer");
+  hipLaunchKernelGGL(k_store_u64x2, dim3(1), dim3(64), 0, (hipStream_t)stream, dst_device, a, b);
+  BX_CHECK_LAUNCH("bx_store_u64x2");
+  return BX_OK;
+}
 extern "C" size_t bx_adamw_partials(size_t n) { return (n / 4 + 255) / 256 + 1; }
 extern "C" size_t bx_adamw_step_words(size_t n) {
   const size_t nblk = (n / 4 + 255) / 256, grid = nblk ? nblk : 1;

@@ -37,7 +37,7 @@ int bx_eegc_forward(const float* x, const float* w1, const float* wd, const floa
 int bx_eegc_corr_launch(const void* g16, const float* x, float* cpart, float* gpart, int B, int Ch, int T, int nsplit, hipStream_t s);
 int bx_eegc_corr_max_T();
 int bx_eegc_forward_eval(const float* x, const float* w1, const float* wd, const float* sc1, const float* sh1, float* u, int B, int Ch, int T,
-                         hipStream_t s);
+                         hipStream_t s, const float* const* x_slot = nullptr);
 int bx_eegc_dx_launch(const float* g, const float* w1, const float* wd, const float* sc1, float* dx, int B, int Ch, int T, hipStream_t s);
 int bx_eegc_grads(const float* cpart, const float* gpart, int nsplit, const float* w1, const float* wd, const float* mean1, const float* inv1,
                   const float* sc1, const float* sh1, const double* RS, float* ep, float* d_wd, float* d_gamma, float* d_beta, float* d_w1,
@@ -398,6 +398,8 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
   BX_REQUIRE(d && p && x && feat && saved, "bx_eeg_features_fwd: null pointer");
   BX_DTYPE_OK(d->dtype);
   EegGeom g;
+  // x_slot: only the collapsed evaluation-mode front end reads the input in exactly one kernel (nothing is saved for a backward)
+  BX_REQUIRE(!d->x_slot || (eeg_tuned(d, &g) && eeg_collapsed_eval(d)), "bx_eeg_features_fwd: x_slot needs the collapsed evaluation-mode path (collapse=1, training=0, default geometry)");
   if (!eeg_tuned(d, &g))                                  // any other F1 / D / F2 / kernLength / Chans (models.py:239-262 is parametric)
     return bx_eegg_forward(d, p, x, seed, feat, saved, workspace, workspace_bytes, (hipStream_t)stream);
   const EegWs w = eeg_ws(g);
@@ -422,7 +424,7 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
     BX_CHECK_LAUNCH("eeg eval stats");
   }
   if (eeg_collapsed_eval(d)) {
-    const int rc = bx_eegc_forward_eval(x, p->conv1_w, p->dw_w, st.sc1, st.sh1, dmap, g.B, g.Ch, g.T, s);
+    const int rc = bx_eegc_forward_eval(x, p->conv1_w, p->dw_w, st.sc1, st.sh1, dmap, g.B, g.Ch, g.T, s, d->x_slot);
     BX_REQUIRE(rc == 0, "bx_eeg_features_fwd: collapsed evaluation-mode front end failed (code %d)", rc);
   } else if (eeg_collapsed(d)) {
     // conv1 -> BatchNorm1 -> electrode mix without the [B,8,Chans,T] tensor (eeg_collapse.hip): statistics, finalize, forward

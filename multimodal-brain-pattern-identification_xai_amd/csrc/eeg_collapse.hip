@@ -258,7 +258,9 @@ __global__ __launch_bounds__(1024) void k_eegc_finalize1(const float* __restrict
 #define EC_TC 256
 #define EC_VP (EC_TC + 64)        // row pitch of v in LDS (multiple of 4)
 __global__ __launch_bounds__(256) void k_eegc_fwd(const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ wd,
-    const float* __restrict__ sc1, const float* __restrict__ sh1, float* __restrict__ u, float* __restrict__ partials, int Ch, int T, int want_stats) {
+    const float* __restrict__ sc1, const float* __restrict__ sh1, float* __restrict__ u, float* __restrict__ partials, int Ch, int T, int want_stats,
+    const float* const* xslot = nullptr) {
+  if (xslot) x = *xslot;                                   // bxEegDesc.x_slot: the input's address comes from a device slot
   __shared__ __attribute__((aligned(16))) float sv[16 * EC_VP];
   __shared__ __attribute__((aligned(16))) float swt[EEG_MAXCH_C * 16];   // mix weights transposed: [ch][fd] (four 16-byte broadcast reads per electrode)
   __shared__ __attribute__((aligned(16))) float sw1[8 * EC_K];
@@ -614,10 +616,10 @@ int bx_eegc_forward(const float* x, const float* w1, const float* wd, const floa
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 int bx_eegc_forward_eval(const float* x, const float* w1, const float* wd, const float* sc1, const float* sh1, float* u, int B, int Ch, int T,
-                         hipStream_t s) {
+                         hipStream_t s, const float* const* x_slot) {
   if (Ch > EEG_MAXCH_C) return -2;
   dim3 grid((unsigned)((T + EC_TC - 1) / EC_TC), (unsigned)B);
-  hipLaunchKernelGGL(k_eegc_fwd, grid, dim3(256), 0, s, x, w1, wd, sc1, sh1, u, (float*)nullptr, Ch, T, 0);
+  hipLaunchKernelGGL(k_eegc_fwd, grid, dim3(256), 0, s, x, w1, wd, sc1, sh1, u, (float*)nullptr, Ch, T, 0, x_slot);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int bx_eegc_grads(const float* cpart, const float* gpart, int nsplit, const float* w1, const float* wd, const float* mean1, const float* inv1,

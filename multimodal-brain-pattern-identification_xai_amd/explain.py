@@ -154,10 +154,22 @@ class GradCamSweep:
         self._graphs = {}
         self._capture(eeg, spec)
 
+    @staticmethod
+    def _slot_ready(t):
+        return t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+
     def _capture(self, eeg, spec):
         model = self.model
         class_idx, upsample, relu = self.args
         s_eeg, s_spec = eeg.detach().clone().contiguous(), spec.detach().clone().contiguous()
+        # The kernels that read the raw batch take its address from a device slot (ops.INPUT_SLOTS): a replay on the caller's own
+        # fp32 tensors costs one 16-byte store instead of two copies (43 MB per batch of 64 at the bench shape, ~20 us).  Inputs in
+        # another dtype / layout still go through the static buffers.
+        slots = torch.zeros(2, dtype=torch.int64, device=s_eeg.device) if self._slot_ready(s_eeg) and self._slot_ready(s_spec) else None
+        if slots is not None:
+            L.check(L.load().bx_store_u64x2(slots.data_ptr(), s_eeg.data_ptr(), s_spec.data_ptr(), ops._stream()), "bx_store_u64x2")
+            ops.INPUT_SLOTS[s_eeg.data_ptr()] = slots.data_ptr()
+            ops.INPUT_SLOTS[s_spec.data_ptr()] = slots.data_ptr() + 8
         was_training = model.training
         model.eval()
         try:
@@ -173,7 +185,17 @@ class GradCamSweep:
                 out = _grad_cam_last_stage(model, s_eeg, s_spec, class_idx, upsample, relu, False)
         finally:
             model.train(was_training)
-        entry = (graph, s_eeg, s_spec, out)
+            used = (False, False)
+            if slots is not None:
+                # which inputs the captured kernels really read through their slot (fp32 storage converts the spectrogram in another
+                # kernel, a non-default EEGNet geometry reads x in several): the others are fed through the static buffers
+                used = (ops.INPUT_SLOTS.pop(s_eeg.data_ptr(), None) == "used", ops.INPUT_SLOTS.pop(s_spec.data_ptr(), None) == "used")
+                ops._SLOT_ADDR.pop(s_eeg.data_ptr(), None)
+                ops._SLOT_ADDR.pop(s_spec.data_ptr(), None)
+        plan = getattr(model.spectrogram_model, "_pack_plan", None)
+        # the warm-up runs packed the weights eagerly, so the captured launches hold no pack jobs when the plan was fresh: a replay
+        # must then make sure it still is (training between two sweeps, load_state_dict, ...)
+        entry = (graph, s_eeg, s_spec, out, slots, plan, used)
         self._graphs[(tuple(eeg.shape), tuple(spec.shape))] = entry
         return entry
 
@@ -183,9 +205,22 @@ class GradCamSweep:
             if eeg.shape[0] != spec.shape[0] or eeg.shape[0] == 0:
                 raise RuntimeError(f"GradCamSweep: bad batch {tuple(eeg.shape)} / {tuple(spec.shape)}")
             entry = self._capture(eeg, spec)
-        graph, s_eeg, s_spec, out = entry
-        s_eeg.copy_(eeg, non_blocking=True)
-        s_spec.copy_(spec, non_blocking=True)
+        graph, s_eeg, s_spec, out, slots, plan, used = entry
+        if plan is not None and not plan.fresh():
+            if getattr(self.model.spectrogram_model, "_pack_plan", None) is not plan:
+                # the parameters moved to other storage (a new FlatAdamW arena): the graph's operand buffers are orphaned
+                self._graphs.clear()
+                return self.__call__(eeg, spec)
+            plan.run()                                   # repack eagerly; the graph's convolutions read the same operand buffers
+        ptrs = []
+        for t, st, via_slot in ((eeg, s_eeg, used[0]), (spec, s_spec, used[1])):
+            if via_slot and self._slot_ready(t):
+                ptrs.append(t.data_ptr())
+            else:
+                st.copy_(t, non_blocking=True)
+                ptrs.append(st.data_ptr())
+        if slots is not None:
+            L.check(L.load().bx_store_u64x2(slots.data_ptr(), ptrs[0], ptrs[1], ops._stream()), "bx_store_u64x2")
         graph.replay()
         return out
 

@@ -275,12 +275,43 @@ def _pack(w: torch.Tensor, flip: bool, dtype=None):
     return pf, pm, ip, op, layout
 
 
+# Bumped by everything in this library that rewrites parameters behind torch's back (FlatAdamW's kernel, replayed training graphs);
+# together with the tensors' own version counters it tells a PackPlan whether its packed operands are still those of the weights.
+PARAM_EPOCH = [0]
+
+
+def bump_param_epoch():
+    PARAM_EPOCH[0] += 1
+
+
+# data_ptr of a static graph input -> address of the DEVICE word its kernels read the batch's address from (GradCamSweep: a replay
+# is pointed at the caller's batch with bx_store_u64x2 instead of copying the batch into the static buffer)
+INPUT_SLOTS = {}
+_SLOT_ADDR = {}
+
+
+def _take_slot(t):
+    """Slot address registered for tensor ``t`` (or None); the registration is marked "used" so that the sweep knows this input is
+    read through the slot by every captured kernel that touches it."""
+    if not INPUT_SLOTS:
+        return None
+    ptr = t.data_ptr()
+    ent = INPUT_SLOTS.get(ptr)
+    if ent is None:
+        return None
+    if ent != "used":
+        _SLOT_ADDR[ptr] = ent
+        INPUT_SLOTS[ptr] = "used"
+    return _SLOT_ADDR[ptr]
+
+
 class PackPlan:
     """All MFMA weight operands (forward + data-gradient) of a list of 3x3 convolutions, packed by ONE launch.
 
     Built once per set of parameter storages (stable under FlatAdamW); ``run()`` re-packs every step because the
-    weights change.  ``get(i, flip)`` returns the operand tuple _conv expects, or None when the MFMA path does not
-    cover that shape (the caller then packs it individually)."""
+    weights change -- except ``run(reuse=True)`` (evaluation mode), which skips the pack jobs while no parameter changed since
+    the last executed pack (``fresh()``).  ``get(i, flip)`` returns the operand tuple _conv expects, or None when the MFMA path
+    does not cover that shape (the caller then packs it individually)."""
 
     def __init__(self, weights, dtype=torch.bfloat16):
         import ctypes
@@ -290,6 +321,7 @@ class PackPlan:
         split = dtype == torch.float32                  # fp32 storage: h + m + l images (csrc/conv3x3_split.hip), job bit 1
         nbytes = lib.bx_conv3x3_packed_split_bytes if split else lib.bx_conv3x3_packed_mfma_bytes
         self.key = tuple(w.data_ptr() for w in weights) + (dtype,)
+        self.weights, self.packed_state = list(weights), None
         entries, off = [], 0
         for i, w in enumerate(weights):
             co, ci = w.shape[0], w.shape[1]
@@ -311,6 +343,17 @@ class PackPlan:
         raw = bytes(memoryview(jobs)) if entries else b"\0" * 8
         self.jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
 
+    def _state(self):
+        return (PARAM_EPOCH[0],) + tuple(w._version for w in self.weights)
+
+    def fresh(self):
+        """True while the packed operands are those of the current weights (nothing rewrote a parameter since the last pack that
+        actually executed; a pack that was only captured into a graph does not count)."""
+        return self.packed_state is not None and self.packed_state == self._state()
+
+    def _mark(self):
+        self.packed_state = None if torch.cuda.is_current_stream_capturing() else self._state()
+
     def run_step(self, x_nchw=None):
         """run() + next_seed_pair() in ONE launch (the launch that opens a multimodal training step): returns
         (batch in the internal layout or None, spectrogram-lane seed, EEG-lane seed)."""
@@ -326,21 +369,33 @@ class PackPlan:
         L.check(L.load().bx_conv3x3_pack_many_step(_p(self.jobs_dev), self.njobs, self.nblocks, _p(src), _p(out), *dims,
                                                    _p(seed_state(dev, "spec")), seeds.data_ptr(), _p(seed_state(dev, "eeg")),
                                                    seeds.data_ptr() + 8, _stream()), "bx_conv3x3_pack_many_step")
+        self._mark()
         return (None if out is None else out.permute(0, 3, 1, 2)), seeds[0:1], seeds[1:2]
 
-    def run(self, x_nchw=None):
+    def run(self, x_nchw=None, reuse=False):
         """Pack every operand; with ``x_nchw`` (fp32 NCHW, no gradient needed) the same launch also produces the batch in the
-        internal bf16 channels-last layout and returns it as a logical-NCHW view."""
+        internal bf16 channels-last layout and returns it as a logical-NCHW view.  ``reuse=True``: skip the pack jobs while
+        ``fresh()`` (the launch is then the layout conversion alone, or nothing)."""
+        skip = reuse and self.fresh()
         if x_nchw is not None and self.njobs:
             assert self.dtype == torch.bfloat16, "the packing launch converts the batch to the bf16 layout only"
             B, Cc, H, W = x_nchw.shape
             src = x_nchw.detach().to(torch.float32).contiguous()
             out = torch.empty(B, H, W, pad8(Cc), dtype=torch.bfloat16, device=x_nchw.device)
-            L.check(L.load().bx_conv3x3_pack_many_layout(_p(self.jobs_dev), self.njobs, self.nblocks, _p(src), _p(out), B, Cc, H, W, pad8(Cc),
-                                                         _stream()), "bx_conv3x3_pack_many_layout")
+            slot = _take_slot(src)
+            if skip or slot:
+                L.check(L.load().bx_conv3x3_pack_layout_ex(None if skip else _p(self.jobs_dev), 0 if skip else self.njobs,
+                                                           0 if skip else self.nblocks, _p(src), slot, _p(out), B, Cc, H, W, pad8(Cc),
+                                                           _stream()), "bx_conv3x3_pack_layout_ex")
+            else:
+                L.check(L.load().bx_conv3x3_pack_many_layout(_p(self.jobs_dev), self.njobs, self.nblocks, _p(src), _p(out), B, Cc, H, W,
+                                                             pad8(Cc), _stream()), "bx_conv3x3_pack_many_layout")
+            if not skip:
+                self._mark()
             return out.permute(0, 3, 1, 2)
-        if self.njobs:
+        if self.njobs and not skip:
             L.check(L.load().bx_conv3x3_pack_many(_p(self.jobs_dev), self.njobs, self.nblocks, _stream()), "bx_conv3x3_pack_many")
+            self._mark()
         return None
 
     def get(self, i, flip):
@@ -785,6 +840,8 @@ class EegFeaturesFn(torch.autograd.Function):
                                           (not cfg.training and not params_need_grad)) else 0
         desc = L.EegDesc(B, Ch, T, cfg.F1, cfg.D, cfg.F2, cfg.K1, cfg.K2, cfg.P1, cfg.P2, 1 if cfg.training else 0, cfg.eps, cfg.momentum,
                          float(cfg.dropout_p), cfg.salt, bx_dtype(cfg.dtype), collapse, float(getattr(cfg, "dropout_p2", -1.0)))
+        if INPUT_SLOTS and collapse and not cfg.training and not torch.is_grad_enabled() and cfg.K1 == 64:
+            desc.x_slot = _take_slot(x)                      # a graph input read through its device slot (GradCamSweep)
         nsaved = lib.bx_eeg_saved_bytes(C.byref(desc))
         if nsaved == 0:
             raise RuntimeError("brainxai: EEGNet geometry outside the kernels' range (F1*D, F2 <= 1024, kernel lengths <= 4096, tensors below 2^31 elements)")

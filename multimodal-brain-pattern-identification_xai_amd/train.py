@@ -136,6 +136,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if not gathered:
             self.gather_grads()
         g = self.param_groups[0]
+        ops.bump_param_epoch()                             # the kernel rewrites the arena behind torch's version counters (PackPlan.fresh)
         if self.is_cuda:
             capturing = torch.cuda.is_current_stream_capturing()
             if not capturing:
@@ -562,6 +563,7 @@ class GraphedTrainStep:
         if static_lab.data_ptr() != labels.data_ptr():
             static_lab.copy_(labels, non_blocking=True)
         self.opt.refresh_hyper()                      # lr / betas / weight decay changed by a scheduler since the last step?
+        ops.bump_param_epoch()                        # the replayed optimizer step rewrites the parameters
         if entry[0] == "overlap":
             return self._replay_overlapped(entry)
         if entry[0] == "ddp_one":

@@ -919,10 +919,11 @@ def test_lime_predict_fn():
     assert np.abs(brainxai.predict_fn(imgs, mm) - want).max() < 1e-5
 
 
-def test_gradcam_sweep_matches_eager():
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gradcam_sweep_matches_eager(dt):
     """the hipGraph form of the default-target Grad-CAM replays the same launches: bit-identical maps, new inputs each call"""
     torch.manual_seed(5)
-    net = brainxai.build_multimodal(19, 2000, 4, dropout=0.5).to(DEV).train()
+    net = brainxai.build_multimodal(19, 2000, 4, dropout=0.5, compute_dtype=dt).to(DEV).train()
     eeg, spec = torch.randn(4, 1, 19, 2000, device=DEV), torch.rand(4, 4, 64, 128, device=DEV)
     sweep = brainxai.GradCamSweep(net, eeg, spec, class_idx="all")
     assert net.training, "the sweep leaves the module's mode alone"
@@ -938,6 +939,40 @@ def test_gradcam_sweep_matches_eager():
     assert len(sweep._graphs) == 2 and torch.equal(sweep(e2, s2), want)
     with pytest.raises(RuntimeError, match="bad batch"):
         sweep(eeg[:2], spec[:3])
+    # round 3: a replay reads the caller's fp32 batch through device pointer slots (no copy into the static buffers) ...
+    entry = sweep._graphs[(tuple(e2.shape), tuple(s2.shape))]
+    # (fp32 storage converts the spectrogram's layout in a kernel of its own, which reads the static buffer)
+    assert entry[4] is not None and entry[6] == (True, dt == torch.bfloat16), "inputs go through their slots at the default geometry"
+    entry[1].fill_(7.0); entry[2].fill_(7.0)                      # poison the static buffers: a replay must not read them
+    assert torch.equal(sweep(e2, s2), want)
+    # ... inputs that are not slot-ready (a strided view, another dtype) still go through the static buffers
+    e_str = torch.randn(4, 1, 19, 4000, device=DEV)[..., ::2]
+    s_half = s2.double()
+    assert not e_str.is_contiguous()
+    assert torch.equal(sweep(e_str, s_half), brainxai.grad_cam(net, e_str.contiguous(), s_half.float(), class_idx="all"))
+    # ... and the captured launches hold no weight-packing jobs: a replay repacks first when a parameter changed since the last
+    # pack -- in place through torch (version counters) or by the fused optimizer's kernel (ops.PARAM_EPOCH)
+    plan = net.spectrogram_model._pack_plan
+    assert plan.fresh()
+    with torch.no_grad():
+        net.spectrogram_model.block5.conv3.weight.mul_(1.5)
+    assert not plan.fresh()
+    got = sweep(e2, s2).clone()
+    want2 = brainxai.grad_cam(net, e2, s2, class_idx="all")
+    assert torch.equal(got, want2) and not torch.equal(got, want) and plan.fresh()
+    opt = brainxai.FlatAdamW(net.parameters(), lr=1e-2)           # moves the parameters into a flat arena: new operand buffers
+    try:
+        y = torch.softmax(torch.randn(4, 6, device=DEV), 1)
+        brainxai.train_step(net, opt, e2, s2, y, brainxai.KLDivLoss())
+        got = sweep(e2, s2).clone()
+        want3 = brainxai.grad_cam(net, e2, s2, class_idx="all")
+        assert torch.equal(got, want3) and not torch.equal(got, want2)
+        brainxai.train_step(net, opt, e2, s2, y, brainxai.KLDivLoss())      # same storage, the kernel rewrote the arena
+        assert not net.spectrogram_model._pack_plan.fresh()
+        got = sweep(e2, s2).clone()
+        assert torch.equal(got, brainxai.grad_cam(net, e2, s2, class_idx="all")) and not torch.equal(got, want3)
+    finally:
+        opt.close()
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
