@@ -184,6 +184,13 @@ int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void* x, const 
  * every workgroup a drained store + ticket round trip and was 4-10 us SLOWER per pass than the ~6.5 us launch it removes
  * (DESIGN section 6).  Results do not depend on the choice beyond the rounding of double-precision sums. */
 int bx_set_tree_max_rows(int rows);
+/* Folded finalizes (round 3): the cross-workgroup sum of a statistics pass moves to the START of the kernel that consumes it -- every
+ * workgroup of the apply kernel sums the producer's partial rows itself, in one fixed order, so no finalize launch (k_bn_finalize /
+ * k_tail_bwd_mid) and no atomics are needed.  mask: bit 0 = backward passes, bit 1 = forward passes; default 3 (or the environment
+ * variable BX_TAIL_FOLD at first use); a pass is folded only while rows x C stays small (the backward reduction launches
+ * BX_TAIL_FOLD_RC / C rows, default 8192 / C; the forward folds when its producer wrote at most BX_TAIL_FOLD_RC_FWD / C rows,
+ * default 16384 / C -- the late stages).  Results do not depend on the choice beyond the rounding of double-precision sums. */
+int bx_set_tail_fold(int mask);
 /* conv3 + tail forward in two launches (bf16 storage, MFMA-capable C; otherwise BX_EUNSUPPORTED and the caller uses
  * bx_conv3x3 + bx_block_tail_fwd): y3 = relu(conv3x3(y2, w3) + b3) is stored for backward, and conv3's epilogue also
  * writes pooled = pool2x2(y3) and the batch statistics, so the pool never re-reads y3 from HBM.  w3_mfma is conv3's

@@ -93,6 +93,7 @@ SIGNATURES = {
     "bx_block_tail_workspace": (sz, [P(TailDesc)]),
     "bx_block_tail_fwd": (i32, [P(TailDesc), vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "bx_set_tree_max_rows": (i32, [i32]),
+    "bx_set_tail_fold": (i32, [i32]),
     "bx_block_conv3_tail_fwd": (i32, [P(TailDesc), vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "bx_block_tail_bwd": (i32, [P(TailDesc), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "bx_relu": (i32, [vp, vp, sz, i32, vp]),

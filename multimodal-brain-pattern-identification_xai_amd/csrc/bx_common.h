@@ -327,9 +327,63 @@ __device__ __forceinline__ bool bx_stat_tree_arrive(const BxStatTree& t, int dom
   return true;
 }
 
+// ---- consumer-side finish of a statistics pass (round 3) -------------------------------------------------------------------
+// The in-launch tree above puts the cross-workgroup sum at the END of the producer (tickets: every workgroup waits for a write-through
+// store and an atomic round trip before it retires -- measured slower than the finalize launch it removes).  This form puts it at the
+// START of the consumer instead: the producer writes its rows with plain stores (the kernel boundary publishes them), and EVERY
+// workgroup of the consuming kernel sums the rows itself, in one fixed order, while its first data loads are in flight -- no atomics,
+// no finalize launch, the same totals in every workgroup.  It pays when rows x C is small (<= 8192: at most 8 NV 16-byte loads per
+// thread, rows x NV x C x 4 bytes of L2 reads per consumer workgroup); the launchers choose the producer's row count accordingly.
+// rows[r][k][C] floats; all 256 threads call; C % 4 == 0 and (C / 4) divides 256.  On return (after its closing barrier) the totals
+// are sp[k * C + c] as doubles.  sp: BX_ROWS_TOTAL_LDS(NV) bytes of LDS, 8-byte aligned.
+#define BX_ROWS_TOTAL_LDS(NV) ((NV) * 1024 * 8)
+template <int NV>
+__device__ __forceinline__ void bx_rows_total(const float* __restrict__ rows, int nrows, int C, double* sp) {
+  const int q = C >> 2, nsl = 256 / q, c4 = threadIdx.x % q, sl = threadIdx.x / q;
+  double acc[NV][4];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0;
+  for (int r0 = sl; r0 < nrows; r0 += 4 * nsl) {            // 4 NV 16-byte loads in flight; adds stay in row order
+    float4 t[4][NV];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * nsl < nrows ? r0 + u * nsl : r0;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) t[u][k] = *reinterpret_cast<const float4*>(rows + ((size_t)r * NV + k) * C + c4 * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (r0 + u * nsl < nrows) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { acc[k][0] += (double)t[u][k].x; acc[k][1] += (double)t[u][k].y; acc[k][2] += (double)t[u][k].z; acc[k][3] += (double)t[u][k].w; }
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sp[((size_t)sl * NV + k) * C + c4 * 4 + i] = acc[k][i];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < NV * C; idx += 256) {   // slice 0's entry idx is read by this thread only: the total goes there
+    double s = sp[idx];
+    for (int j = 1; j < nsl; ++j) s += sp[(size_t)j * NV * C + idx];
+    sp[idx] = s;
+  }
+  __syncthreads();
+}
+static inline bool bx_rows_total_ok(int C) { return C % 4 == 0 && C >= 4 && C <= 1024 && 256 % (C / 4) == 0; }
+
 static inline int bx_finalize_cg(int C) { return C < 16 ? C : 16; }      // channels per finalize workgroup
 static inline int bx_finalize_grid(int C) { const int cg = bx_finalize_cg(C); return (C + cg - 1) / cg; }
 
+// (sum, sum of squares) of one channel -> batch mean, 1/sqrt(var + eps) and the unbiased variance of the running-stat update
+__device__ __forceinline__ void bx_bn_batch_stats(double sum, double sumsq, double count, float eps, float& mean, float& invstd, double& unbiased) {
+  const double m = sum / count;
+  double var = sumsq / count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean = (float)m;
+  invstd = (float)(1.0 / sqrt(var + (double)eps));
+  unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+}
 // batch statistics of one channel -> (scale, shift), saved statistics, running-stat update (unbiased variance, momentum)
 __device__ __forceinline__ void bx_bn_finalize_channel(int c, bool training, double sum, double sumsq, double count, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
@@ -337,12 +391,8 @@ __device__ __forceinline__ void bx_bn_finalize_channel(int c, bool training, dou
                                                        float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
   float mean, invstd;
   if (training) {
-    const double m = sum / count;
-    double var = sumsq / count - m * m;
-    if (var < 0.0) var = 0.0;
-    mean = (float)m;
-    invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    double unbiased;
+    bx_bn_batch_stats(sum, sumsq, count, eps, mean, invstd, unbiased);
     rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
     rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
     if (c == 0 && nbt) nbt[0] += 1;

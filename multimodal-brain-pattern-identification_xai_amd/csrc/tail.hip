@@ -177,19 +177,44 @@ __device__ __forceinline__ void skip_sample(const T* __restrict__ x, const TailG
 // RPT = weight rows per trip of the 1x1 loop (2 RPT loads in flight).  The late stages take ~12 us here whatever Cin_p is
 // (32, 64 or 128 rows): neither 16 rows per trip nor 4 pixels per thread (4x fewer weight loads, 14 us) moved it -- the time is
 // the fixed chain of cold round trips after the kernel boundary (scale/shift, skip input, first weight rows), not the loop.
+// Folded finalize (round 3, TailFwdPro.rows != NULL): no k_bn_finalize launch between the statistics pass and this kernel -- every
+// workgroup sums the producer's partial rows itself (bx_rows_total) and derives (scale, shift); workgroup 0 also writes the running
+// statistics and the saved mean / invstd the backward reads.
+struct TailFwdPro { const float* rows; int nrows; BxBnFinalize fin; };
 template <typename T, int RPT>
 __global__ __launch_bounds__(256, 4) void k_tail_apply(const T* __restrict__ pooled, const T* __restrict__ x, const float* __restrict__ wT,
     int Cin, const float* __restrict__ b1x1, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, T* __restrict__ out, TailGeom g,
     const float* __restrict__ ev_gamma, const float* __restrict__ ev_beta, const float* __restrict__ ev_rmean,
-    const float* __restrict__ ev_rvar, float eps, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    const float* __restrict__ ev_rvar, float eps, float* __restrict__ save_mean, float* __restrict__ save_invstd, TailFwdPro pro) {
   extern __shared__ float xs[];  // [slots][Cin_p + 1]
   const int cg = threadIdx.x % g.ncg, slot = threadIdx.x / g.ncg;
   const int xstride = g.Cin_p + 1, nci8 = g.Cin_p / 8;
   const uint64_t sd = (dropout_p > 0.f && seed) ? seed[0] : 0;
   const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
   float sc[8], sh[8], bb[8];
-  if (ev_gamma) {
+  if (pro.rows) {
+    __shared__ __attribute__((aligned(8))) double sp[BX_ROWS_TOTAL_LDS(2) / 8];
+    __shared__ float ssc[2][256];
+    bx_rows_total<2>(pro.rows, pro.nrows, g.C, sp);
+    if ((int)threadIdx.x < g.C) {
+      const int c = threadIdx.x;
+      const BxBnFinalize& f = pro.fin;
+      float mean, invstd; double unbiased;
+      bx_bn_batch_stats(sp[c], sp[g.C + c], f.count, f.eps, mean, invstd, unbiased);
+      const float s_ = f.gamma[c] * invstd, h_ = f.beta[c] - mean * s_;
+      ssc[0][c] = s_; ssc[1][c] = h_;
+      if (blockIdx.x == 0) {                              // the one writer of the module's state and of what the backward reads
+        f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * mean;
+        f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * (float)unbiased;
+        if (c == 0 && f.nbt) f.nbt[0] += 1;
+        f.scale[c] = s_; f.shift[c] = h_; f.save_mean[c] = mean; f.save_invstd[c] = invstd;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = ssc[0][cg * 8 + j]; sh[j] = ssc[1][cg * 8 + j]; bb[j] = b1x1[cg * 8 + j]; }
+  } else if (ev_gamma) {
     // eval mode: scale / shift come straight from the running statistics (no finalize launch); workgroup 0 also
     // publishes them as the saved mean / invstd an eval-mode backward (saliency, IG, inner Grad-CAM targets) reads
 #pragma unroll
@@ -268,6 +293,30 @@ extern "C" int bx_set_tree_max_rows(int rows) {
   g_tree_max_rows = rows;
   return BX_OK;
 }
+// Folded finalizes (consumer-side sums, bx_rows_total): BX_TAIL_FOLD bit 0 = backward (no k_tail_bwd_mid), bit 1 = forward (no
+// k_bn_finalize); default 3.  BX_TAIL_FOLD_RC bounds rows x C of a folded pass (the backward reduction role launches that many rows,
+// the forward folds only when its producer wrote no more), BX_TAIL_FOLD_GRID caps the consuming kernel's workgroups (each re-reads the rows).
+static int g_tail_fold = -1;
+static int tail_fold() {
+  if (g_tail_fold < 0) { const char* e = getenv("BX_TAIL_FOLD"); g_tail_fold = e ? atoi(e) & 3 : 3; }
+  return g_tail_fold;
+}
+extern "C" int bx_set_tail_fold(int mask) {
+  BX_REQUIRE(mask >= 0 && mask <= 3, "bx_set_tail_fold: mask is a combination of 1 (backward) and 2 (forward)");
+  g_tail_fold = mask;
+  return BX_OK;
+}
+static int tail_fold_rc(bool fwd) {
+  static const int rc_b = getenv("BX_TAIL_FOLD_RC") ? atoi(getenv("BX_TAIL_FOLD_RC")) : 8192;
+  static const int rc_f = getenv("BX_TAIL_FOLD_RC_FWD") ? atoi(getenv("BX_TAIL_FOLD_RC_FWD")) : 16384;
+  return fwd ? rc_f : rc_b;
+}
+static int tail_fold_grid() {
+  static const int v = getenv("BX_TAIL_FOLD_GRID") ? atoi(getenv("BX_TAIL_FOLD_GRID")) : 512;       // measured: 512 1.498 ms, 1024 1.500, 4096 1.514
+  return v < 1 ? 1 : v;
+}
+static bool tail_fold_ok(const TailGeom& g) { return g.C <= 256 && bx_rows_total_ok(g.C); }
+static int tail_fold_rows(int C) { const int r = tail_fold_rc(false) / C; return r < 16 ? 16 : r > TAIL_MAX_BLOCKS ? TAIL_MAX_BLOCKS : r; }
 // rows of forward partial sums: the pooling kernel writes at most TAIL_MAX_BLOCKS, conv3's pooled epilogue one per 8 x 16 (or larger) tile
 static size_t tail_rows_cap(const bxTailDesc* d) {
   const size_t conv_rows = (size_t)d->B * ((d->H + 7) / 8) * ((d->W + 15) / 16);
@@ -326,16 +375,23 @@ extern "C" int bx_block_tail_fwd(const bxTailDesc* d, const void* y3, const void
     hipLaunchKernelGGL((k_pool_stats<T>), dim3(nblk), dim3(256), 0, s, (const T*)y3, (T*)pooled, partials, g, d->pool, d->training,
                        w1x1, Cin, wT, tree, fin));
   BX_CHECK_LAUNCH("bx_block_tail_fwd(pool)");
-  if (d->training && !in_launch) {
+  // folded finalize: the apply kernel's workgroups sum the partial rows themselves (no k_bn_finalize launch)
+  const bool fold = d->training && !in_launch && (tail_fold() & 2) && tail_fold_ok(g) && (long long)nblk * g.C <= tail_fold_rc(true);
+  TailFwdPro pro = {};
+  if (fold)
+    pro = TailFwdPro{partials, nblk, BxBnFinalize{bn_weight, bn_bias, running_mean, running_var, num_batches_tracked, d->momentum, d->eps, scale, shift,
+                                                 save_mean, save_invstd, (double)g.npool}};
+  if (d->training && !in_launch && !fold) {
     hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.C)), dim3(1024), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight, bn_bias,
                        running_mean, running_var, num_batches_tracked, d->momentum, d->eps, scale, shift, save_mean, save_invstd);
     BX_CHECK_LAUNCH("bx_block_tail_fwd(finalize)");
   }
   const bool ev = !d->training;
+  const int napply = fold && tail_blocks_all(g) > tail_fold_grid() ? tail_fold_grid() : tail_blocks_all(g);
   BX_DISPATCH_DTYPE(d->dtype, T,
-    hipLaunchKernelGGL((k_tail_apply<T, 8>), dim3(tail_blocks_all(g)), dim3(256), xs_bytes, s, (const T*)pooled, (const T*)x, wT, Cin, b1x1,
+    hipLaunchKernelGGL((k_tail_apply<T, 8>), dim3(napply), dim3(256), xs_bytes, s, (const T*)pooled, (const T*)x, wT, Cin, b1x1,
                        scale, shift, seed, p, d->salt, (T*)out, g, ev ? bn_weight : (const float*)nullptr, bn_bias, (const float*)running_mean,
-                       (const float*)running_var, d->eps, save_mean, save_invstd));
+                       (const float*)running_var, d->eps, save_mean, save_invstd, pro));
   BX_CHECK_LAUNCH("bx_block_tail_fwd(apply)");
   return BX_OK;
 }
@@ -381,16 +437,21 @@ extern "C" int bx_block_conv3_tail_fwd(const bxTailDesc* d, const void* y2, cons
   if (g_bx_prof_ev[1]) (void)hipEventRecord(g_bx_prof_ev[1], s);
   g_bx_prof_ev[0] = g_bx_prof_ev[1] = nullptr;
   if (rc != BX_OK) return rc;
-  if (d->training && !pe.tree.cnt) {                    // many partial rows: the separate finalize launch (its workgroups split the channels)
+  // few partial rows (the late stages: one per 8 x 32 tile or per image): the apply kernel's workgroups sum them themselves
+  const bool fold = d->training && !pe.tree.cnt && (tail_fold() & 2) && tail_fold_ok(g) && (long long)pe.tree.nrows * g.C <= tail_fold_rc(true);
+  TailFwdPro pro = {};
+  if (fold) pro = TailFwdPro{partials, pe.tree.nrows, pe.fin};
+  if (d->training && !pe.tree.cnt && !fold) {           // many partial rows: the separate finalize launch (its workgroups split the channels)
     hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.C)), dim3(1024), 0, s, partials, pe.tree.nrows, (double)g.npool, g.C, 1, bn_weight, bn_bias,
                        running_mean, running_var, num_batches_tracked, d->momentum, d->eps, scale, shift, save_mean, save_invstd);
     BX_CHECK_LAUNCH("bx_block_conv3_tail_fwd(finalize)");
   }
   const float p = d->training ? d->dropout_p : 0.f;
   const bool ev = !d->training;
-  hipLaunchKernelGGL((k_tail_apply<bf16_t, 8>), dim3(tail_blocks_all(g)), dim3(256), xs_bytes, s, (const bf16_t*)pooled, (const bf16_t*)x, wT, Cin, b1x1,
+  const int napply = fold && tail_blocks_all(g) > tail_fold_grid() ? tail_fold_grid() : tail_blocks_all(g);
+  hipLaunchKernelGGL((k_tail_apply<bf16_t, 8>), dim3(napply), dim3(256), xs_bytes, s, (const bf16_t*)pooled, (const bf16_t*)x, wT, Cin, b1x1,
                      scale, shift, seed, p, d->salt, (bf16_t*)out, g, ev ? bn_weight : (const float*)nullptr, bn_bias, (const float*)running_mean,
-                     (const float*)running_var, d->eps, save_mean, save_invstd);
+                     (const float*)running_var, d->eps, save_mean, save_invstd, pro);
   BX_CHECK_LAUNCH("bx_block_conv3_tail_fwd(apply)");
   return BX_OK;
 }
@@ -496,12 +557,15 @@ __device__ __forceinline__ void w1x1_sum_group(const float* __restrict__ wpart, 
   }
 }
 struct TailWsum { const float* wpart; float* dw; int nchunk, Cin, S, n_apply; };     // n_apply = workgroups of the apply role (0: no sum role)
+// folded finalize (round 3): rows != NULL -- no k_tail_bwd_mid launch; every apply workgroup sums the reduction role's partial rows
+// itself (bx_rows_total) and derives the three coefficients, workgroup 0 writes the parameter gradients
+struct TailBwdPro { const float* rows; int nrows; TailBwdFin fin; };
 
 // apply: dP = a*(dD - k1 - xhat*k2); route through the 2x2 pool and conv3's ReLU to full resolution
 template <typename T>
 __global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ dout, const T* __restrict__ pooled, const T* __restrict__ y3,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
-    const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, int pool, T* __restrict__ dz3, TailGeom g, TailWsum ws) {
+    const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, int pool, T* __restrict__ dz3, TailGeom g, TailWsum ws, TailBwdPro pro) {
   if (ws.n_apply && (int)blockIdx.x >= ws.n_apply) {            // extra workgroups: the 1x1 weight-gradient sum rides here
     __shared__ float sm[256];
     w1x1_sum_group(ws.wpart, ws.dw, ws.nchunk, g.C, ws.Cin, g.Cin_p, ws.S, (int)blockIdx.x - ws.n_apply, threadIdx.x, sm);
@@ -511,10 +575,31 @@ __global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ do
   const uint64_t sd = (dropout_p > 0.f && seed) ? seed[0] : 0;
   const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
   float mu[8], is[8], a[8], k1[8], k2[8];
+  if (pro.rows) {
+    __shared__ __attribute__((aligned(8))) double sp[BX_ROWS_TOTAL_LDS(3) / 8];
+    __shared__ float cf[3][256];
+    bx_rows_total<3>(pro.rows, pro.nrows, g.C, sp);
+    if ((int)threadIdx.x < g.C) {
+      const int c = threadIdx.x;
+      const double st[3] = {sp[c], sp[g.C + c], sp[2 * g.C + c]};
+      const TailBwdFin& f = pro.fin;
+      cf[0][c] = f.gamma[c] * f.invstd[c];
+      cf[1][c] = f.training ? (float)(st[0] / f.count) : 0.f;
+      cf[2][c] = f.training ? (float)(st[1] / f.count) : 0.f;
+      if (blockIdx.x == 0) tail_bwd_finalize_channel(c, g.C, st, f);       // parameter gradients (+ the coefficients, for inspection)
+    }
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = cg * 8 + j;
-    mu[j] = mean[c]; is[j] = invstd[c]; a[j] = coef[c]; k1[j] = coef[g.C + c]; k2[j] = coef[2 * g.C + c];
+    for (int j = 0; j < 8; ++j) {
+      const int c = cg * 8 + j;
+      mu[j] = mean[c]; is[j] = invstd[c]; a[j] = cf[0][c]; k1[j] = cf[1][c]; k2[j] = cf[2][c];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cg * 8 + j;
+      mu[j] = mean[c]; is[j] = invstd[c]; a[j] = coef[c]; k1[j] = coef[g.C + c]; k2[j] = coef[2 * g.C + c];
+    }
   }
   const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const long long napply = ws.n_apply ? ws.n_apply : (int)gridDim.x;
@@ -982,6 +1067,9 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
   const int n_w = nchunk * wg_y * wg_z;
   const size_t front_lds = (dx_skip && !mf) ? (size_t)64 * g.Cin_p * sizeof(float) : 0;
   const bool in_launch = d->sync && 256 % g.C == 0 && nblk <= bx_tree_max_rows();
+  // folded finalize: the reduction role writes few rows (rows x C <= BX_TAIL_FOLD_RC), every apply workgroup sums them itself
+  const bool fold = !in_launch && (tail_fold() & 1) && tail_fold_ok(g);
+  const int nred = fold && nblk > tail_fold_rows(g.C) ? tail_fold_rows(g.C) : nblk;
   BxStatTree tree = {};
   TailBwdFin fin = {};
   if (in_launch) {
@@ -995,9 +1083,9 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
     TailFrontArgs<T> a;
     a.dout = (const T*)dout; a.pooled = (const T*)pooled; a.x = (const T*)x; a.mean = save_mean; a.invstd = save_invstd; a.w1x1 = w1x1;
     a.seed = seed; a.partials = partials; a.wpart = wpart; a.dxs = dxs; a.dx_even = even ? (T*)dx_skip : (T*)nullptr;
-    a.dropout_p = p; a.salt = d->salt; a.n_red = nblk; a.n_w = n_w; a.wg_x = nchunk > 0 ? nchunk : 1; a.wg_y = wg_y; a.ppc = ppc; a.Cin = Cin;
+    a.dropout_p = p; a.salt = d->salt; a.n_red = nred; a.n_w = n_w; a.wg_x = nchunk > 0 ? nchunk : 1; a.wg_y = wg_y; a.ppc = ppc; a.Cin = Cin;
     a.tree = tree; a.fin = fin;
-    const dim3 grid(nblk + n_w + n_dxs);
+    const dim3 grid(nred + n_w + n_dxs);
     if (mf == 16) hipLaunchKernelGGL((k_tail_bwd_front<T, 8, 16>), grid, dim3(256), front_lds, s, a, g);
     else if (mf == 32) hipLaunchKernelGGL((k_tail_bwd_front<T, 8, 32>), grid, dim3(256), front_lds, s, a, g);
     else if (mf == 64) hipLaunchKernelGGL((k_tail_bwd_front<T, 8, 64>), grid, dim3(256), front_lds, s, a, g);
@@ -1011,8 +1099,16 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
   const int n_sum_elems = g.C * g.Cin_p;
   const int S = d_w1x1 ? bx_partial_slices(n_sum_elems, nchunk) : 4;
   TailWsum wsum = {};
+  TailBwdPro pro = {};
   int n_sum256 = 0;
-  if (!in_launch) {
+  const int napply = fold && tail_blocks_all(g) > tail_fold_grid() ? tail_fold_grid() : tail_blocks_all(g);
+  if (fold) {
+    pro = TailBwdPro{partials, nred, TailBwdFin{bn_weight, save_invstd, coef, d_bn_weight, d_bn_bias, d_b1x1, (double)g.npool, d->training}};
+    if (d_w1x1) {
+      n_sum256 = bx_ceil_div(n_sum_elems, 256 / S);
+      wsum = TailWsum{wpart, d_w1x1, nchunk, Cin, S, napply};
+    }
+  } else if (!in_launch) {
     const int n_fin = bx_finalize_grid(g.C);
     const int n_sum = d_w1x1 ? bx_ceil_div(n_sum_elems, 4 * (256 / S)) : 0;
     hipLaunchKernelGGL(k_tail_bwd_mid, dim3(n_fin + n_sum), dim3(1024), 0, s, partials, nblk, (double)g.npool, g.C, d->training, bn_weight,
@@ -1020,11 +1116,11 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
     BX_CHECK_LAUNCH("bx_block_tail_bwd(mid)");
   } else if (d_w1x1) {
     n_sum256 = bx_ceil_div(n_sum_elems, 256 / S);
-    wsum = TailWsum{wpart, d_w1x1, nchunk, Cin, S, tail_blocks_all(g)};
+    wsum = TailWsum{wpart, d_w1x1, nchunk, Cin, S, napply};
   }
   BX_DISPATCH_DTYPE(d->dtype, T,
-    hipLaunchKernelGGL((k_tail_bwd_apply<T>), dim3(tail_blocks_all(g) + n_sum256), dim3(256), 0, s, (const T*)dout, (const T*)pooled, (const T*)y3,
-                       save_mean, save_invstd, coef, seed, p, d->salt, d->pool, (T*)dz3, g, wsum));
+    hipLaunchKernelGGL((k_tail_bwd_apply<T>), dim3(napply + n_sum256), dim3(256), 0, s, (const T*)dout, (const T*)pooled, (const T*)y3,
+                       save_mean, save_invstd, coef, seed, p, d->salt, d->pool, (T*)dz3, g, wsum, pro));
   BX_CHECK_LAUNCH("bx_block_tail_bwd(apply)");
   if (dx_skip) {
     if (!even) {

@@ -15,11 +15,12 @@ DEV = torch.device("cuda:0")
 CASES = [(4, 16, 16, 128, 128), (16, 32, 8, 32, 64), (128, 256, 4, 8, 16), (64, 128, 6, 16, 32)]
 
 
-def _run(in_launch, dtype, case, pool, fuse_pool=False, max_rows=1 << 20):
+def _run(in_launch, dtype, case, pool, fuse_pool=False, max_rows=1 << 20, fold=0):
     cin, cout, batch, h, w = case
     old = ops.TAIL_IN_LAUNCH, ops.FUSE_POOL
     ops.TAIL_IN_LAUNCH, ops.FUSE_POOL = in_launch, fuse_pool
     L.check(L.load().bx_set_tree_max_rows(max_rows), "bx_set_tree_max_rows")      # the default policy (0) never finalizes in-launch
+    L.check(L.load().bx_set_tail_fold(fold), "bx_set_tail_fold")                  # these tests pin the folded form off unless asked
     try:
         torch.manual_seed(3)
         blk = brainxai.Block(cin, cout, pool, (2, 2), dropout_p=0.25).to(DEV).train()
@@ -42,6 +43,7 @@ def _run(in_launch, dtype, case, pool, fuse_pool=False, max_rows=1 << 20):
     finally:
         ops.TAIL_IN_LAUNCH, ops.FUSE_POOL = old
         L.load().bx_set_tree_max_rows(0)
+        L.load().bx_set_tail_fold(3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -64,6 +66,22 @@ def test_conv3_pooled_epilogue_equals_pooling_kernel(case, pool):
     _compare(a, b, torch.bfloat16)
     c = _run(True, torch.bfloat16, case, pool, fuse_pool=True, max_rows=0)       # pooled epilogue writes rows, separate finalize launch
     _compare(c, b, torch.bfloat16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fuse_pool", [False, True])
+@pytest.mark.parametrize("case", CASES + [(16, 16, 5, 18, 34), (16, 16, 3, 20, 24)])
+def test_folded_finalize_equals_finalize_launches(case, fuse_pool, dtype):
+    """round 3: no k_bn_finalize / k_tail_bwd_mid launch -- every workgroup of the apply kernels sums the partial rows itself
+    (bx_rows_total).  Same float rows, double sums in another grouping (and, in the backward, fewer rows from the reduction role)."""
+    if fuse_pool and dtype != torch.bfloat16:
+        pytest.skip("the pooled conv3 epilogue is a bf16 kernel")
+    pool = "max" if case[0] % 3 else "avg"
+    a = _run(False, dtype, case, pool, fuse_pool=fuse_pool, max_rows=0, fold=3)
+    b = _run(False, dtype, case, pool, fuse_pool=fuse_pool, max_rows=0, fold=0)
+    _compare(a, b, dtype)
+    for mask in (1, 2):                                                           # each direction alone
+        _compare(_run(False, dtype, case, pool, fuse_pool=fuse_pool, max_rows=0, fold=mask), b, dtype)
 
 
 def _compare(a, b, dtype):
