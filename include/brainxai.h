@@ -164,7 +164,14 @@ typedef struct {
                          * (the library leaves them zero): where bx_set_tree_max_rows allows it, the batch-statistics
                          * finalizes ride in the kernels that produce the partial sums (last workgroup to arrive).
                          * One block instance must not run on two streams at once with the same words. */
+  void* route;          /* NULL, or bx_block_tail_route_bytes(d) bytes: one NIBBLE per pooled element saying which positions of its
+                         * 2x2 window (bit q = row-major position q) receive its gradient -- the arg-max if positive (max pool,
+                         * first maximum as ATen) or the positive ones (average pool).  That is all the backward needs of conv3's
+                         * full-resolution output: bx_block_conv3_tail_fwd writes the nibbles (and may then be given y3 = NULL:
+                         * the output is not stored), bx_block_tail_bwd reads them instead of y3 (which may be NULL).  1/16 of the
+                         * bytes of y3 in each direction.  bf16 fused path only; ignored by bx_block_tail_fwd. */
 } bxTailDesc;
+size_t bx_block_tail_route_bytes(const bxTailDesc* d);
 #define BX_TAIL_SYNC_WORDS 8192
 #define BX_TAIL_SYNC_FWD 0          /* word offsets inside sync: forward statistics | backward statistics */
 #define BX_TAIL_SYNC_BWD 4096

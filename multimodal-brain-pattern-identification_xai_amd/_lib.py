@@ -23,7 +23,7 @@ vp, i32, i64, u32, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_flo
 
 class TailDesc(C.Structure):
     _fields_ = [("B", i32), ("H", i32), ("W", i32), ("Cin_p", i32), ("C", i32), ("pool", i32), ("training", i32),
-                ("eps", f32), ("momentum", f32), ("dropout_p", f32), ("salt", u32), ("dtype", i32), ("sync", vp)]
+                ("eps", f32), ("momentum", f32), ("dropout_p", f32), ("salt", u32), ("dtype", i32), ("sync", vp), ("route", vp)]
 
 
 class EegDesc(C.Structure):
@@ -94,6 +94,7 @@ SIGNATURES = {
     "bx_block_tail_fwd": (i32, [P(TailDesc), vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "bx_set_tree_max_rows": (i32, [i32]),
     "bx_set_tail_fold": (i32, [i32]),
+    "bx_block_tail_route_bytes": (sz, [vp]),
     "bx_block_conv3_tail_fwd": (i32, [P(TailDesc), vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "bx_block_tail_bwd": (i32, [P(TailDesc), vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "bx_relu": (i32, [vp, vp, sz, i32, vp]),

@@ -425,6 +425,11 @@ struct BxConvPoolEpi {
   int Cin1, Cin1_p;
   size_t rows_cap_floats; int cnt_cap_words;
   int tree_max_rows;              // more partial rows than this: rows only (tree.cnt is cleared), the caller launches the finalize
+  // round 3: what the backward needs of conv3's output is only WHERE each pooled element's gradient goes -- one nibble per pooled
+  // element, bit q = position q of the 2x2 window (row-major) receives it (max pool: the arg-max if it is positive; average pool: the
+  // positive ones).  route != NULL: the nibbles are written ([B,Ho,Wo,C] nibbles, channel pairs per byte, low nibble = even channel);
+  // store_y = 0: the full-resolution output is not stored at all (1/16 of its bytes are).
+  void* route; uint32_t route_bytes; int store_y;
 };
 // in-launch finalize only for trees of at most this many rows (BX_TREE_MAX_ROWS; 0 = always a separate finalize launch)
 int bx_tree_max_rows();

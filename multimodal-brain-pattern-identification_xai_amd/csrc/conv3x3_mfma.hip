@@ -251,6 +251,7 @@ template <int MP, int NC, int TPR, typename PixFn>
 __device__ __forceinline__ void conv_pool_tiles(const f32x4 (&q)[MP][NC], const BxConvPoolEpi& pe, const __amdgpu_buffer_rsrc_t& pres, int Co,
                                                 int co_base, PixFn pix, float (&st)[2][NC][4]) {
   const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(pe.route, 0, pe.route ? pe.route_bytes : 0u, 0x00020000);
 #pragma unroll
   for (int i = 0; i < MP; ++i) {
     if ((i / TPR) % 2) continue;                       // bottom rows are consumed by the tile above (MP = 2*TPR*IMGS)
@@ -261,14 +262,26 @@ __device__ __forceinline__ void conv_pool_tiles(const f32x4 (&q)[MP][NC], const 
 #pragma unroll
     for (int n = 0; n < NC; ++n) {
       float v[4];
+      uint32_t code = 0;                                // four route nibbles (this lane's four channels), see BxConvPoolEpi.route
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float t0 = q[i][n][r], b0 = q[i + TPR][n][r];
         const float t1 = dpp16<0xB1>(t0), b1 = dpp16<0xB1>(b0);          // the horizontal neighbour (lane ^ 1)
         v[r] = pe.pool == BX_POOL_MAX ? fmaxf(fmaxf(t0, t1), fmaxf(b0, b1)) : 0.25f * (t0 + t1 + b0 + b1);
+        if (pe.route) {                                // (workgroup-uniform: evaluation sweeps and inference skip the nibbles)
+          uint32_t nib;
+          if (pe.pool == BX_POOL_MAX) {                // first maximum in row-major window order (ATen), and only a positive one passes ReLU
+            nib = t0 == v[r] ? 1u : t1 == v[r] ? 2u : b0 == v[r] ? 4u : 8u;
+            nib = v[r] > 0.f ? nib : 0u;
+          } else {
+            nib = (t0 > 0.f ? 1u : 0u) | (t1 > 0.f ? 2u : 0u) | (b0 > 0.f ? 4u : 0u) | (b1 > 0.f ? 8u : 0u);
+          }
+          code |= nib << (4 * r);
+        }
       }
       const uint32_t lo = pack2bf(v[0], v[1]), hi = pack2bf(v[2], v[3]);
       __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, pres, po + (uint32_t)(n * 32), 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b16((short)code, rres, own ? (po >> 2) + (uint32_t)(n * 8) : 0x80000000u, 0, 0);   // (zero-sized resource when not wanted)
       if (own) {                                       // statistics of the pooled values as stored
         const float w[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
 #pragma unroll
@@ -485,7 +498,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const bf16_t* __restrict__ x,
         const float v[4] = {fmaxf(acc[i][n][0] + bz[n].x, 0.f), fmaxf(acc[i][n][1] + bz[n].y, 0.f), fmaxf(acc[i][n][2] + bz[n].z, 0.f),
                             fmaxf(acc[i][n][3] + bz[n].w, 0.f)};
         const u32x2 out = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        __builtin_amdgcn_raw_buffer_store_b64(out, yres, offs[i][n], 0, 0);
+        if (pe.store_y) __builtin_amdgcn_raw_buffer_store_b64(out, yres, offs[i][n], 0, 0);
         acc[i][n] = (f32x4){__uint_as_float(out.x << 16), __uint_as_float(out.x & 0xffff0000u), __uint_as_float(out.y << 16),
                             __uint_as_float(out.y & 0xffff0000u)};
       }
@@ -706,7 +719,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_c(const bf16_t* __restrict__ 
         const float v[4] = {fmaxf(acc[i][n][0] + bz[n].x, 0.f), fmaxf(acc[i][n][1] + bz[n].y, 0.f), fmaxf(acc[i][n][2] + bz[n].z, 0.f),
                             fmaxf(acc[i][n][3] + bz[n].w, 0.f)};
         const u32x2 out = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        __builtin_amdgcn_raw_buffer_store_b64(out, yres, offs[i] + (uint32_t)(n * 32), 0, 0);
+        if (pe.store_y) __builtin_amdgcn_raw_buffer_store_b64(out, yres, offs[i] + (uint32_t)(n * 32), 0, 0);
         acc[i][n] = (f32x4){__uint_as_float(out.x << 16), __uint_as_float(out.x & 0xffff0000u), __uint_as_float(out.y << 16),
                             __uint_as_float(out.y & 0xffff0000u)};
       }
@@ -944,7 +957,7 @@ __global__ __launch_bounds__(256, (CK == 16 && NC == 1 && TW == 32 && !POOL) ? 4
           const float v[4] = {fmaxf(acc[i][n][0] + bz[n].x, 0.f), fmaxf(acc[i][n][1] + bz[n].y, 0.f), fmaxf(acc[i][n][2] + bz[n].z, 0.f),
                               fmaxf(acc[i][n][3] + bz[n].w, 0.f)};
           const u32x2 out = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-          __builtin_amdgcn_raw_buffer_store_b64(out, yres, offs[i][n], 0, 0);
+          if (pe.store_y) __builtin_amdgcn_raw_buffer_store_b64(out, yres, offs[i][n], 0, 0);
           acc[i][n] = (f32x4){__uint_as_float(out.x << 16), __uint_as_float(out.x & 0xffff0000u), __uint_as_float(out.y << 16),
                               __uint_as_float(out.y & 0xffff0000u)};
         }

@@ -322,6 +322,11 @@ static size_t tail_rows_cap(const bxTailDesc* d) {
   const size_t conv_rows = (size_t)d->B * ((d->H + 7) / 8) * ((d->W + 15) / 16);
   return conv_rows > TAIL_MAX_BLOCKS ? conv_rows : TAIL_MAX_BLOCKS;
 }
+extern "C" size_t bx_block_tail_route_bytes(const bxTailDesc* d) {
+  TailGeom g;
+  if (!d || make_geom(d, &g)) return 0;
+  return (size_t)g.npool * g.C / 2;                       // C % 8 == 0: a thread's 8 channels are one 32-bit word
+}
 extern "C" size_t bx_block_tail_workspace(const bxTailDesc* d) {
   TailGeom g;
   if (!d || make_geom(d, &g)) return 0;
@@ -404,8 +409,8 @@ extern "C" int bx_block_conv3_tail_fwd(const bxTailDesc* d, const void* y2, cons
                                        float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                        const uint64_t* seed, void* pooled, void* out, float* save_mean, float* save_invstd,
                                        void* workspace, size_t workspace_bytes, bxStream stream) {
-  BX_REQUIRE(d && y2 && w3_mfma && b3 && y3 && x && w1x1 && b1x1 && bn_weight && bn_bias && running_mean && running_var && pooled && out && save_mean
-             && save_invstd, "bx_block_conv3_tail_fwd: null pointer");
+  BX_REQUIRE(d && y2 && w3_mfma && b3 && x && w1x1 && b1x1 && bn_weight && bn_bias && running_mean && running_var && pooled && out && save_mean
+             && save_invstd, "bx_block_conv3_tail_fwd: null pointer");            // (y3 may be NULL: conv3's output is then not stored)
   if (d->dtype != BX_BF16 || !bx_conv3x3_mfma_supported(d->C, d->C, d->dtype) || d->C < 16)
     BX_FAIL(BX_EUNSUPPORTED, "bx_block_conv3_tail_fwd: needs bf16 storage and an MFMA-capable channel count (C=%d dtype=%d)", d->C, d->dtype);
   TailGeom g;
@@ -426,6 +431,7 @@ extern "C" int bx_block_conv3_tail_fwd(const bxTailDesc* d, const void* y2, cons
   BxConvPoolEpi pe = {};
   pe.pooled = pooled; pe.pool = d->pool; pe.want_stats = d->training; pe.Ho = g.Ho; pe.Wo = g.Wo;
   pe.w1x1 = w1x1; pe.wT = wT; pe.Cin1 = Cin; pe.Cin1_p = g.Cin_p;
+  pe.route = d->route; pe.route_bytes = (uint32_t)bx_block_tail_route_bytes(d); pe.store_y = y3 != nullptr;
   if (d->training) {
     pe.tree.rows = partials; pe.tree.mid = (double*)(wT + (size_t)g.Cin_p * g.C); pe.tree.cnt = d->sync ? d->sync + BX_TAIL_SYNC_FWD : nullptr;
     pe.rows_cap_floats = tail_rows_cap(d) * 2 * g.C; pe.cnt_cap_words = BX_TAIL_SYNC_BWD - BX_TAIL_SYNC_FWD; pe.tree_max_rows = bx_tree_max_rows();
@@ -565,7 +571,8 @@ struct TailBwdPro { const float* rows; int nrows; TailBwdFin fin; };
 template <typename T>
 __global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ dout, const T* __restrict__ pooled, const T* __restrict__ y3,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
-    const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, int pool, T* __restrict__ dz3, TailGeom g, TailWsum ws, TailBwdPro pro) {
+    const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, int pool, T* __restrict__ dz3, TailGeom g, TailWsum ws, TailBwdPro pro,
+    const uint32_t* __restrict__ route) {
   if (ws.n_apply && (int)blockIdx.x >= ws.n_apply) {            // extra workgroups: the 1x1 weight-gradient sum rides here
     __shared__ float sm[256];
     w1x1_sum_group(ws.wpart, ws.dw, ws.nchunk, g.C, ws.Cin, g.Cin_p, ws.S, (int)blockIdx.x - ws.n_apply, threadIdx.x, sm);
@@ -575,6 +582,18 @@ __global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ do
   const uint64_t sd = (dropout_p > 0.f && seed) ? seed[0] : 0;
   const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
   float mu[8], is[8], a[8], k1[8], k2[8];
+  // Software pipeline: a pixel group's loads (dOut, pooled, route word) are issued one trip ahead -- the first group's before the
+  // folded finalize below, so its round trip hides under the row sums (the capped grid leaves only two workgroups per CU).
+  const long long napply = ws.n_apply ? ws.n_apply : (int)gridDim.x;
+  const long long pstep = napply * g.slots;
+  long long pp = (long long)blockIdx.x * g.slots + slot;
+  Raw8<T> gor, pvr;
+  uint32_t code = 0;
+  {
+    const size_t e = (size_t)(pp < g.npool ? pp : 0) * g.C + cg * 8;
+    gor.load(dout, e); pvr.load(pooled, e);
+    if (route) code = route[e >> 3];
+  }
   if (pro.rows) {
     __shared__ __attribute__((aligned(8))) double sp[BX_ROWS_TOTAL_LDS(3) / 8];
     __shared__ float cf[3][256];
@@ -602,13 +621,19 @@ __global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ do
     }
   }
   const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const long long napply = ws.n_apply ? ws.n_apply : (int)gridDim.x;
-  for (long long pp = (long long)blockIdx.x * g.slots + slot; pp < g.npool; pp += napply * g.slots) {
+  // (two trips ahead with two register sets: 28.1 -> 30.9 us at stage 1, occupancy 3 -- one trip ahead it stays)
+  for (; pp < g.npool; pp += pstep) {
     int ox, oy, b;
     px_decode(pp, g.Wo, g.Ho, ox, oy, b);
     float go[8], pv[8], dp[8];
-    ld8(dout, (size_t)pp * g.C + cg * 8, go);
-    ld8(pooled, (size_t)pp * g.C + cg * 8, pv);
+    gor.get(go); pvr.get(pv);
+    const uint32_t code_now = code;
+    {                                                   // the next trip's loads (clamped index: the values are unused past the end)
+      const long long pn = pp + pstep;
+      const size_t e = (size_t)(pn < g.npool ? pn : pp) * g.C + cg * 8;
+      gor.load(dout, e); pvr.load(pooled, e);
+      if (route) code = route[e >> 3];
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float dd = go[j];
@@ -618,6 +643,13 @@ __global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ do
     const size_t base = (((size_t)b * g.H + 2 * oy) * g.W + 2 * ox) * g.C + cg * 8;
     const size_t off[4] = {0, (size_t)g.C, (size_t)g.W * g.C, (size_t)g.W * g.C + g.C};
     float v[4][8], o[4][8];
+    if (route) {                                        // bxTailDesc.route: the forward wrote where each pooled element's gradient goes
+      const float share = pool == BX_POOL_MAX ? 1.f : 0.25f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q][j] = (code_now >> (4 * j + q)) & 1u ? share * dp[j] : 0.f;
+    } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) ld8(y3, base + off[q], v[q]);
 #pragma unroll
@@ -632,6 +664,7 @@ __global__ __launch_bounds__(256) void k_tail_bwd_apply(const T* __restrict__ do
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q][j] = v[q][j] > 0.f ? 0.25f * dp[j] : 0.f;
       }
+    }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) st8(dz3, base + off[q], o[q]);
@@ -1025,7 +1058,7 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
                                  const float* save_invstd, const uint64_t* seed, void* dz3, void* dx_skip,
                                  float* d_bn_weight, float* d_bn_bias, float* d_w1x1, float* d_b1x1,
                                  void* workspace, size_t workspace_bytes, bxStream stream) {
-  BX_REQUIRE(d && dout && y3 && x && pooled && w1x1 && bn_weight && save_mean && save_invstd && dz3, "bx_block_tail_bwd: null pointer");
+  BX_REQUIRE(d && dout && (y3 || d->route) && x && pooled && w1x1 && bn_weight && save_mean && save_invstd && dz3, "bx_block_tail_bwd: null pointer");
   BX_DTYPE_OK(d->dtype);
   TailGeom g;
   const int ge = make_geom(d, &g);
@@ -1120,7 +1153,7 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
   }
   BX_DISPATCH_DTYPE(d->dtype, T,
     hipLaunchKernelGGL((k_tail_bwd_apply<T>), dim3(napply + n_sum256), dim3(256), 0, s, (const T*)dout, (const T*)pooled, (const T*)y3,
-                       save_mean, save_invstd, coef, seed, p, d->salt, d->pool, (T*)dz3, g, wsum, pro));
+                       save_mean, save_invstd, coef, seed, p, d->salt, d->pool, (T*)dz3, g, wsum, pro, (const uint32_t*)d->route));
   BX_CHECK_LAUNCH("bx_block_tail_bwd(apply)");
   if (dx_skip) {
     if (!even) {

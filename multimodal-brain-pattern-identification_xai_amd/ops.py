@@ -439,6 +439,8 @@ WGRAD_CARRY = _os.environ.get("BX_WGRAD_CARRY", "1") == "1"
 TAIL_IN_LAUNCH = _os.environ.get("BX_TAIL_IN_LAUNCH", "1") == "1"
 # conv3 of a Block pools and sums the batch statistics in its epilogue (bx_block_conv3_tail_fwd); 0 = conv3, then the pooling kernel
 FUSE_POOL = _os.environ.get("BX_FUSE_POOL", "1") == "1"
+# ... and writes where each pooled element's gradient goes as a nibble (bxTailDesc.route) instead of storing conv3's output; 0 = store y3
+TAIL_ROUTE = _os.environ.get("BX_TAIL_ROUTE", "1") == "1"
 # the pair launch also writes the ReLU decisions as bits and the data gradients read those (BX_EPI_MASK_BITS); 0 = read the activations
 MASK_BITS = _os.environ.get("BX_MASK_BITS", "1") == "1"
 # stage 1's conv1 and conv2 in one launch (bx_conv3x3_pair); 0 = two bx_conv3x3 launches
@@ -504,10 +506,10 @@ def _wgrad(x, dz, w: torch.Tensor, b: torch.Tensor, chain: bool = False):
     return dw, db
 
 
-def _tail_desc(x, y3, cfg) -> L.TailDesc:
-    B, H, W, Cc = y3.shape
+def _tail_desc(x, shape, dt, cfg, route=None) -> L.TailDesc:
+    B, H, W, Cc = shape
     return L.TailDesc(B, H, W, x.shape[3], Cc, L.BX_POOL_MAX if cfg.pool == "max" else L.BX_POOL_AVG, 1 if cfg.training else 0,
-                      cfg.eps, cfg.momentum, float(cfg.dropout_p), cfg.salt, bx_dtype(y3.dtype), _p(cfg.sync))
+                      cfg.eps, cfg.momentum, float(cfg.dropout_p), cfg.salt, bx_dtype(dt), _p(cfg.sync), _p(route))
 
 
 class BlockFn(torch.autograd.Function):
@@ -574,9 +576,17 @@ class BlockFn(torch.autograd.Function):
         out = torch.empty_like(pooled)
         mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
         invstd = torch.empty_like(mean)
+        route = None
         if packed3 is not None:
-            y3 = torch.empty(B, H, W, Cc, dtype=dt, device=x.device)
-            desc = _tail_desc(x, y3, cfg)
+            # What a backward pass needs of conv3's output is only where each pooled element's gradient goes: the fused launch writes
+            # that as one nibble per pooled element (bxTailDesc.route) and conv3's full-resolution output is not stored at all --
+            # unless a debugging hook asked for the activations.  Without a backward in sight (Grad-CAM sweeps, inference): neither.
+            need_bwd = getattr(cfg, "grad_mode", True) and any(ctx.needs_input_grad[:11])
+            use_route = TAIL_ROUTE and cfg.keep is None
+            y3 = torch.empty(B, H, W, Cc, dtype=dt, device=x.device) if (cfg.keep is not None or (need_bwd and not use_route)) else None
+            if need_bwd and use_route:
+                route = torch.empty(B * (H // 2) * (W // 2) * Cc // 2, dtype=torch.uint8, device=x.device)
+            desc = _tail_desc(x, (B, H, W, Cc), dt, cfg, route)
             ws = workspace(lib.bx_block_tail_workspace(C.byref(desc)), x.device)
             if CONV_PROFILE is not None:                    # the library records the pair around the convolution kernel of this call
                 pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -589,13 +599,15 @@ class BlockFn(torch.autograd.Function):
             acts.append(y3)
         else:
             y3 = acts[3]
-            desc = _tail_desc(x, y3, cfg)
+            desc = _tail_desc(x, tuple(y3.shape), dt, cfg)
             ws = workspace(lib.bx_block_tail_workspace(C.byref(desc)), x.device)
             L.check(lib.bx_block_tail_fwd(C.byref(desc), _p(y3), _p(x), _p(w11), w11.shape[1], _p(b11), _p(bnw), _p(bnb), _p(rm), _p(rv), _p(nbt),
                                           _p(seed), _p(pooled), _p(out), _p(mean), _p(invstd), _p(ws), ws.numel(), _stream()), "bx_block_tail_fwd")
         ctx.cfg, ctx.desc, ctx.seed = cfg, desc, seed
         ctx.masks = masks                                   # (plain attributes: uint8 side outputs of the pair launch, never differentiated)
-        ctx.save_for_backward(x, acts[1], acts[2], y3, pooled, mean, invstd, w1, b1, w2, b2, w3, b3, bnw, bnb, w11, b11)
+        ctx.route, ctx.y3_shape = route, (B, H, W, Cc)
+        ctx.save_for_backward(x, acts[1], acts[2], y3 if y3 is not None else x.new_empty(0), pooled, mean, invstd, w1, b1, w2, b2, w3, b3,
+                              bnw, bnb, w11, b11)
         if pre is not None:
             cfg.capture["act"] = pre
         if cfg.keep is not None:                            # debugging / parity tooling: see keep_block_activations()
@@ -611,7 +623,9 @@ class BlockFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         need_w = any(ctx.needs_input_grad[1:11])
         dout = dout.contiguous()
-        dz3 = torch.empty_like(y3)
+        dz3 = torch.empty(ctx.y3_shape, dtype=dt, device=x.device)
+        if y3.numel() == 0:
+            y3 = None                                       # not stored: the route nibbles of the descriptor stand in for it
         dx_skip = torch.empty_like(x) if need_dx else None
         # arena slices only for gradients autograd asked for (a frozen attribution pass must not touch the trainer's arena)
         need_bn = ctx.needs_input_grad[7] or ctx.needs_input_grad[8]

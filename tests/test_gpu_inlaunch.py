@@ -15,10 +15,10 @@ DEV = torch.device("cuda:0")
 CASES = [(4, 16, 16, 128, 128), (16, 32, 8, 32, 64), (128, 256, 4, 8, 16), (64, 128, 6, 16, 32)]
 
 
-def _run(in_launch, dtype, case, pool, fuse_pool=False, max_rows=1 << 20, fold=0):
+def _run(in_launch, dtype, case, pool, fuse_pool=False, max_rows=1 << 20, fold=0, route=True):
     cin, cout, batch, h, w = case
-    old = ops.TAIL_IN_LAUNCH, ops.FUSE_POOL
-    ops.TAIL_IN_LAUNCH, ops.FUSE_POOL = in_launch, fuse_pool
+    old = ops.TAIL_IN_LAUNCH, ops.FUSE_POOL, ops.TAIL_ROUTE
+    ops.TAIL_IN_LAUNCH, ops.FUSE_POOL, ops.TAIL_ROUTE = in_launch, fuse_pool, route
     L.check(L.load().bx_set_tree_max_rows(max_rows), "bx_set_tree_max_rows")      # the default policy (0) never finalizes in-launch
     L.check(L.load().bx_set_tail_fold(fold), "bx_set_tail_fold")                  # these tests pin the folded form off unless asked
     try:
@@ -41,7 +41,7 @@ def _run(in_launch, dtype, case, pool, fuse_pool=False, max_rows=1 << 20, fold=0
             assert blk._sync is None
         return outs
     finally:
-        ops.TAIL_IN_LAUNCH, ops.FUSE_POOL = old
+        ops.TAIL_IN_LAUNCH, ops.FUSE_POOL, ops.TAIL_ROUTE = old
         L.load().bx_set_tree_max_rows(0)
         L.load().bx_set_tail_fold(3)
 
@@ -82,6 +82,20 @@ def test_folded_finalize_equals_finalize_launches(case, fuse_pool, dtype):
     _compare(a, b, dtype)
     for mask in (1, 2):                                                           # each direction alone
         _compare(_run(False, dtype, case, pool, fuse_pool=fuse_pool, max_rows=0, fold=mask), b, dtype)
+
+
+@pytest.mark.parametrize("pool", ["max", "avg"])
+@pytest.mark.parametrize("case", CASES + [(16, 16, 5, 18, 34), (32, 64, 3, 9, 50)])
+def test_route_nibbles_equal_the_stored_conv3_output(case, pool):
+    """round 3: the fused conv3 + pool launch writes WHERE each pooled element's gradient goes (one nibble per pooled element,
+    bxTailDesc.route) and does not store conv3's full-resolution output; the backward reads the nibbles.  Same decisions as reading
+    the stored output (arg-max with ATen's first-maximum rule and the ReLU test for the max pool, the four ReLU tests for the
+    average pool), so every result is bit-identical -- including maps with odd sizes and tiles that leave the image."""
+    a = _run(False, torch.bfloat16, case, pool, fuse_pool=True, max_rows=0, fold=3, route=True)
+    b = _run(False, torch.bfloat16, case, pool, fuse_pool=True, max_rows=0, fold=3, route=False)
+    for ra, rb in zip(a, b):
+        for k, (ta, tb) in enumerate(zip(ra, rb)):
+            assert torch.equal(ta, tb), k
 
 
 def _compare(a, b, dtype):
