@@ -2035,11 +2035,22 @@ extern "C" int bx_debug_wgrad_stamps(unsigned long long* host_out) {
 #else
 #define BX_STAMP(i) do { } while (0)
 #endif
-template <int TW, int OCC, int DEPTH>
+// DL (round 3): the tiles go from HBM / L2 straight into one of THREE LDS images, two tiles ahead (buffer_load ... lds: no staging
+// registers, no LDS write instructions, one barrier per tile).  The in-kernel stamps showed the register-staged loop at one exposed
+// global-load latency per tile (2500 cycles per 8 x 16 tile for 4 x 144 cycles of MFMA, 4500 per 8 x 32 tile): with one tile ahead and
+// two workgroups per CU there is nothing else to run while a load is in flight.  A lane's 16 bytes land at (wave base) + 16 lane, so
+// the swizzle moves to the SOURCE side: LDS slot L = 4 p + c' of pixel p takes channel unit c = ((c' >> 1) ^ (px >> 3)) << 1 | (c' & 1)
+// -- the image is byte for byte what stage() writes.  TH = 4 with 32-wide tiles keeps three images at 74 KB (two workgroups per CU).
+// SHIFT (round 3): the loop is bound by LDS READ bandwidth, not by latency (which is why DL did not pay: 2 workgroups x 4 waves x 20
+// ds_read_b64_tr_b16 x 512 bytes per K-step = 2560 cycles per pair of tiles at 128 bytes/clk -- exactly the stamps).  The nine tap
+// fragments of a K-step are three shifted windows per tile row: a lane's 8 pixels of tap dx are pixels dx .. dx + 7 of the 10 it would
+// read for dx = 0 .. 2 together.  So each row is read ONCE as 12 pixels (three transposing reads) and the dx = 1 / 2 fragments are
+// built in registers (dword re-indexing and four v_alignbit): 9 + 2 reads per K-step instead of 18 + 2.
+template <int TW, int OCC, int DEPTH, int TH = 8, bool DL = false, bool SHIFT = true>
 __global__ __launch_bounds__(256, OCC) void k_wgrad_own(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dz, float* __restrict__ partial,
     int H, int W, int Ci_p, int Co, int tiles_x, int tiles_y, int ntiles, int tiles_per_split, int nsplit, int ytiles, int ztiles,
     WgradRedJob prev, int nred) {
-  constexpr int TH = 8, HWID = TW + 2, HH = TH + 2, CIT = 32, COT = 32, XB = 64, ZB = 64;
+  constexpr int HWID = TW + 2, HH = TH + 2, CIT = 32, COT = 32, XB = 64, ZB = 64;
   constexpr int KSTEPS = TH * TW / 32, ROWS_PER_STEP = 32 / TW;   // TW = 32: one tile row per K-step; TW = 16: two
   constexpr int XS_BYTES = HH * HWID * XB;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -2072,7 +2083,9 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_own(const bf16_t* __restrict
   const int t_end = t_begin + tiles_per_split < ntiles ? t_begin + tiles_per_split : ntiles;
   constexpr int NXU = HH * HWID * (CIT / 8), NZU = TH * TW * (COT / 8);
   constexpr int NX = (NXU + 255) / 256, NZ = (NZU + 255) / 256;
-  uint4 rxa[NX], rza[NZ], rxb[NX], rzb[NZ];        // two tiles in flight (OCC = 3 leaves the registers): fetch distance 2
+  constexpr int IMG_BYTES = (NX + NZ) * 256 * 16;                // DL: one LDS image = x units padded to whole waves, then the dZ units
+  if constexpr (DL) zs = lds + NX * 256 * 16;
+  uint4 rxa[DL ? 1 : NX], rza[DL ? 1 : NZ], rxb[DL ? 1 : NX], rzb[DL ? 1 : NZ];        // two tiles in flight (OCC = 3 leaves the registers): fetch distance 2
   const int nimg = ntiles / (tiles_x * tiles_y);
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (uint32_t)((size_t)nimg * H * W * Ci_p * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t zres = __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, (uint32_t)((size_t)nimg * H * W * Co * 2), 0x00020000);
@@ -2081,20 +2094,39 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_own(const bf16_t* __restrict
 #pragma unroll
   for (int k = 0; k < NX; ++k) {
     const int u = threadIdx.x + k * 256;
-    const int p = u / (CIT / 8), c = u % (CIT / 8);
+    const int p = u / (CIT / 8), px = p % HWID;
+    const int cu = u % (CIT / 8), c = DL ? (((((cu >> 1) ^ (px >> 3)) & 1) << 1) | (cu & 1)) : cu;     // DL: u is the LDS slot
     const bool live = u < NXU && ci0 + c * 8 < Ci_p;
-    const int px = p % HWID;
     xpp[k] = ((live ? p / HWID - 1 : -20000) << 16) | ((px - 1) & 0xffff);
     xrel[k] = (uint32_t)((((p / HWID - 1) * W + (px - 1)) * Ci_p + ci0 + c * 8) * 2);
   }
 #pragma unroll
   for (int k = 0; k < NZ; ++k) {
     const int u = threadIdx.x + k * 256;
-    const int p = u / (COT / 8), c = u % (COT / 8);
-    const int px = p % TW;
+    const int p = u / (COT / 8), px = p % TW;
+    const int cu = u % (COT / 8), c = DL ? (((((cu >> 1) ^ (px >> 3)) & 1) << 1) | (cu & 1)) : cu;
     zpp[k] = ((u < NZU ? p / TW : 20000) << 16) | px;
     zrel[k] = (uint32_t)((((p / TW) * W + px) * Co + co0 + c * 8) * 2);
   }
+  auto fetch_lds = [&](int tile, int img) {                    // DL: lane l of wave w lands at image + (k * 256 + w * 64 + l) * 16
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    const uint32_t pix0 = (uint32_t)((b * H + y0) * W + x0);
+    const uint32_t xb = pix0 * (uint32_t)(Ci_p * 2), zb = pix0 * (uint32_t)(Co * 2);
+    char* base = lds + img * IMG_BYTES + wave * 64 * 16;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const bool ok = (unsigned)(y0 + (xpp[k] >> 16)) < (unsigned)H && (unsigned)(x0 + (int)(short)(xpp[k] & 0xffff)) < (unsigned)W;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (__attribute__((address_space(3))) void*)(base + k * 256 * 16), 16,
+                                               (int)(ok ? xb + xrel[k] : 0x80000000u), 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) {
+      const bool ok = (unsigned)(y0 + (zpp[k] >> 16)) < (unsigned)H && (unsigned)(x0 + (zpp[k] & 0xffff)) < (unsigned)W;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(zres, (__attribute__((address_space(3))) void*)(base + (NX + k) * 256 * 16), 16,
+                                               (int)(ok ? zb + zrel[k] : 0x80000000u), 0, 0, 0);
+    }
+  };
   auto fetch = [&](int tile, uint4 (&rx)[NX], uint4 (&rz)[NZ]) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int y0 = ty * TH, x0 = tx * TW;
@@ -2140,13 +2172,36 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_own(const bf16_t* __restrict
   // The K-steps of a staged tile with the operand fragments of step k+1 requested BEFORE the nine MFMAs of step k.  Written
   // as plain "read, then use" the compiler waits for each fragment right before its MFMA: the in-kernel stamps (tools/
   // wgrad_stamps.py) showed 560 cycles per K-step for 144 cycles of MFMA -- nine exposed LDS latencies.
+  int img_off = 0;                                               // DL: byte offset of the image being consumed
+  int xbase2;                                                    // SHIFT: pixels 8 .. 11 past the lane group's first (third transposing read)
+  {
+    const int kp = 8 * g + q;
+    const int r = TW == 32 ? 0 : (kp >> 4), c = (TW == 32 ? kp : (kp & 15)) + 8;
+    xbase2 = (r * HWID + c) * XB + (((m ^ (c >> 3)) & 1) << 5) + pc * 8;
+  }
   auto load_frags = [&](int ks, bf16x8 (&a)[9], bf16x8& b) {
     const int r0 = ks * ROWS_PER_STEP;
-    b = tr_read8(zs, zbase[0] + r0 * TW * ZB, zbase[1] + r0 * TW * ZB);
+    b = tr_read8(zs + img_off, zbase[0] + r0 * TW * ZB, zbase[1] + r0 * TW * ZB);
+    if constexpr (SHIFT) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap % 3;
-      a[tap] = tr_read8(xs, xbase[0][dx] + (r0 + dy) * HWID * XB, xbase[1][dx] + (r0 + dy) * HWID * XB);
+      for (int dy = 0; dy < 3; ++dy) {
+        const int ro = (r0 + dy) * HWID * XB;
+        const char* xi = xs + img_off;
+        const u32x2 p0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xi + xbase[0][0] + ro)));
+        const u32x2 p1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xi + xbase[1][0] + ro)));
+        const u32x2 p2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xi + xbase2 + ro)));
+        const uint32_t d0 = p0.x, d1 = p0.y, d2 = p1.x, d3 = p1.y, d4 = p2.x;       // pixel pairs (0,1) (2,3) (4,5) (6,7) (8,9)
+        a[dy * 3 + 0] = __builtin_bit_cast(bf16x8, (u32x4){d0, d1, d2, d3});
+        a[dy * 3 + 1] = __builtin_bit_cast(bf16x8, (u32x4){__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16),
+                                                           __builtin_amdgcn_alignbit(d3, d2, 16), __builtin_amdgcn_alignbit(d4, d3, 16)});
+        a[dy * 3 + 2] = __builtin_bit_cast(bf16x8, (u32x4){d1, d2, d3, d4});
+      }
+    } else {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        a[tap] = tr_read8(xs + img_off, xbase[0][dx] + (r0 + dy) * HWID * XB, xbase[1][dx] + (r0 + dy) * HWID * XB);
+      }
     }
   };
   auto mma = [&](const bf16x8 (&a)[9], const bf16x8& b) {
@@ -2168,7 +2223,24 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_own(const bf16_t* __restrict
       if (ks + 1 < KSTEPS) mma(a1, b1);
     }
   };
-  if (DEPTH == 2) {                                              // two tiles in flight (needs the 256-register budget of OCC = 2)
+  if constexpr (DL) {
+    static_assert(NX + NZ <= 15, "vmcnt immediate");
+    if (t_begin < t_end) fetch_lds(t_begin, 0);
+    if (t_begin + 1 < t_end) fetch_lds(t_begin + 1, 1);
+    int it = 0;
+    for (int tile = t_begin; tile < t_end; ++tile, ++it) {
+      // this wave's loads of `tile` have landed (vmcnt counts in issue order: only the NX + NZ loads of the tile after it may still be
+      // in flight), then everybody's; the image about to be refilled was last read before this barrier
+      if (tile + 1 < t_end) __builtin_amdgcn_s_waitcnt(0x0F70 | (NX + NZ));
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      if (tile == t_begin) BX_STAMP(1);
+      if (tile + 2 < t_end) fetch_lds(tile + 2, (it + 2) % 3);
+      img_off = (it % 3) * IMG_BYTES;
+      compute();
+      if (tile - t_begin < 4) BX_STAMP(2 + tile - t_begin);
+    }
+  } else if (DEPTH == 2) {                                       // two tiles in flight (needs the 256-register budget of OCC = 2)
     if (t_begin < t_end) fetch(t_begin, rxa, rza);
     if (t_begin + 1 < t_end) fetch(t_begin + 1, rxb, rzb);
     for (int tile = t_begin; tile < t_end; tile += 2) {
@@ -2214,13 +2286,24 @@ __global__ __launch_bounds__(256, OCC) void k_wgrad_own(const bf16_t* __restrict
   BX_STAMP(6);
 }
 
-struct WgradPlan { int ma, nb, tw, tiles_x, tiles_y, ntiles, ytiles, ztiles, nsplit, tps; size_t lds; };
+struct WgradPlan { int ma, nb, tw, th, tiles_x, tiles_y, ntiles, ytiles, ztiles, nsplit, tps; size_t lds; };
+// tile-owner kernel with direct-to-LDS tiles (k_wgrad_own<.., DL>): BX_WGRAD_DL=1; default is the register-staged loop
+static bool wgrad_own_dl() {
+  static const bool v = getenv("BX_WGRAD_DL") && atoi(getenv("BX_WGRAD_DL")) != 0;     // opt-in: measured slower (1.501 vs 1.476 ms/step)
+  return v;
+}
+static bool wgrad_own_on() {
+  static const bool v = !(getenv("BX_WGRAD_OWN") && atoi(getenv("BX_WGRAD_OWN")) == 0);
+  return v;
+}
 static WgradPlan wgrad_plan(int B, int H, int W, int Ci_p, int Co) {
   WgradPlan p;
   p.ma = Ci_p >= 32 ? 2 : 1;
   p.nb = Co >= 32 ? 2 : 1;
   p.tw = W <= 16 ? 16 : 32;
-  p.tiles_x = (W + p.tw - 1) / p.tw; p.tiles_y = (H + 7) / 8; p.ntiles = p.tiles_x * p.tiles_y * B;
+  // 4-row tiles for the direct-to-LDS form of the tile-owner kernel at 32-wide tiles (three LDS images, two workgroups per CU)
+  p.th = (p.ma == 2 && p.nb == 2 && p.tw == 32 && wgrad_own_on() && wgrad_own_dl()) ? 4 : 8;
+  p.tiles_x = (W + p.tw - 1) / p.tw; p.tiles_y = (H + p.th - 1) / p.th; p.ntiles = p.tiles_x * p.tiles_y * B;
   p.ytiles = (Ci_p + 16 * p.ma - 1) / (16 * p.ma); p.ztiles = Co / (16 * p.nb);
   // two rounds of 256 workgroups for every tile shape: with the partial sum riding in the next layer's launch, more (smaller)
   // splits only add partial traffic (sweep of BX_WGRAD_WANT on the training step: 384 1.789, 512 1.733, 576 1.745, 768 1.870,
@@ -2292,7 +2375,7 @@ int bx_wgrad_mfma_launch(const void* x, const void* dz, float* dw, float* db, in
     prev = wgrad_job_from(pending, true);
     zextra = (prev.nblocks + p.nsplit * p.ytiles - 1) / (p.nsplit * p.ytiles);
   }
-  static const bool own = !(getenv("BX_WGRAD_OWN") && atoi(getenv("BX_WGRAD_OWN")) == 0);
+  const bool own = wgrad_own_on();
   if (own && p.ma == 2 && p.nb == 2) {
     // tile-owner kernel (k_wgrad_own): 1-D grid = [reduce-role workgroups, padded to a multiple of 8][8 XCD lanes x slots]
     const int nred = pending && pending->valid ? (prev.nblocks + 7) / 8 * 8 : 0;
@@ -2302,10 +2385,34 @@ int bx_wgrad_mfma_launch(const void* x, const void* dz, float* dw, float* db, in
     // two workgroups per CU (256-register budget: 36 accumulators + two fragment sets of 40 + 40 staging registers); BX_WGRAD_DEPTH=2
     // keeps two tiles in flight instead of one
     static const int depth = getenv("BX_WGRAD_DEPTH") ? atoi(getenv("BX_WGRAD_DEPTH")) : 1;
-#define BX_OWN(TW_, D_) hipLaunchKernelGGL((k_wgrad_own<TW_, 2, D_>), dim3(nwg), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)dz, part, H, W, \
-                                           Ci_p, Co, p.tiles_x, p.tiles_y, p.ntiles, p.tps, p.nsplit, p.ytiles, p.ztiles, prev, nred)
-    if (p.tw == 16) { if (depth == 2) BX_OWN(16, 2); else BX_OWN(16, 1); }
-    else            { if (depth == 2) BX_OWN(32, 2); else BX_OWN(32, 1); }
+    static const bool shift = !(getenv("BX_WGRAD_SHIFT") && atoi(getenv("BX_WGRAD_SHIFT")) == 0);      // (the third read of the last halo row reaches 128 bytes past the x tile: lds + 256)
+    if (wgrad_own_dl()) {
+      // three LDS images of (x halo units + dZ units, each padded to whole 256-lane trips) x 16 bytes
+      const int nxu = (p.th + 2) * (p.tw + 2) * 4, nzu = p.th * p.tw * 4;
+      const size_t lds_dl = (size_t)3 * ((nxu + 255) / 256 + (nzu + 255) / 256) * 256 * 16;
+      static bool attr16 = false, attr32 = false;
+      if (p.tw == 16) {
+        if (!attr16 && lds_dl > 64 * 1024) {
+          if (hipFuncSetAttribute((const void*)k_wgrad_own<16, 2, 1, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dl) != hipSuccess)
+            BX_FAIL(BX_EHIP, "bx_conv3x3_wgrad(mfma): cannot reserve %zu bytes of LDS", lds_dl);
+          attr16 = true;
+        }
+        hipLaunchKernelGGL((k_wgrad_own<16, 2, 1, 8, true>), dim3(nwg), dim3(256), lds_dl, s, (const bf16_t*)x, (const bf16_t*)dz, part, H, W,
+                           Ci_p, Co, p.tiles_x, p.tiles_y, p.ntiles, p.tps, p.nsplit, p.ytiles, p.ztiles, prev, nred);
+      } else {
+        if (!attr32 && lds_dl > 64 * 1024) {
+          if (hipFuncSetAttribute((const void*)k_wgrad_own<32, 2, 1, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dl) != hipSuccess)
+            BX_FAIL(BX_EHIP, "bx_conv3x3_wgrad(mfma): cannot reserve %zu bytes of LDS", lds_dl);
+          attr32 = true;
+        }
+        hipLaunchKernelGGL((k_wgrad_own<32, 2, 1, 4, true>), dim3(nwg), dim3(256), lds_dl, s, (const bf16_t*)x, (const bf16_t*)dz, part, H, W,
+                           Ci_p, Co, p.tiles_x, p.tiles_y, p.ntiles, p.tps, p.nsplit, p.ytiles, p.ztiles, prev, nred);
+      }
+    } else
+#define BX_OWN(TW_, D_, SH_) hipLaunchKernelGGL((k_wgrad_own<TW_, 2, D_, 8, false, SH_>), dim3(nwg), dim3(256), lds + 256, s, (const bf16_t*)x, \
+                                           (const bf16_t*)dz, part, H, W, Ci_p, Co, p.tiles_x, p.tiles_y, p.ntiles, p.tps, p.nsplit, p.ytiles, p.ztiles, prev, nred)
+    if (p.tw == 16) { if (depth == 2) BX_OWN(16, 2, false); else if (shift) BX_OWN(16, 1, true); else BX_OWN(16, 1, false); }
+    else            { if (depth == 2) BX_OWN(32, 2, false); else if (shift) BX_OWN(32, 1, true); else BX_OWN(32, 1, false); }
 #undef BX_OWN
   } else
 #define BX_WG(MA_, NB_) do { if (p.tw == 16) launch_wgrad<MA_, NB_, 16>(p, x, dz, part, H, W, Ci_p, Co, prev, zextra, s); \
