@@ -506,6 +506,11 @@ def main():
                                 "mfma_frac": round(sps / world * GRADCAM_FLOPS / 1e12 / (MFMA_PEAK_TFLOPS["bf16"] / mfma_per_product), 5),
                                 "note": "per GPU; SURVEY 8(d): forward 15.7 MB (bf16) + 1.90 GFLOP per sample, + the 6 upsampled fp32 maps written"},
                    "map_checksum": float(checksum)}
+        # the synthetic training state often leaves the class scores' Grad-CAM maps negative almost everywhere, so the sum of the ReLU'd
+        # maps can be ~0: also report the pre-ReLU maps of the first batch (same launches, relu off) so that a zero is not mistaken for
+        # an empty result
+        raw0 = brainxai.grad_cam(model, sweep_eeg[:B], sweep_spec[:B], class_idx="all", relu=False)
+        gradcam["first_batch_pre_relu"] = {"abs_sum": float(raw0.abs().sum(dtype=torch.float64)), "min": float(raw0.min()), "max": float(raw0.max())}
         if m32 is not None:                                 # the same sweep through the fp32-storage path (first 2 048 samples)
             m32.eval()
             n32s = min(n_mine, 2048) // B * B
