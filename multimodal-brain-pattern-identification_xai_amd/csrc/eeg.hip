@@ -313,25 +313,29 @@ __global__ void k_eeg_bn_elu_pool(const float* __restrict__ in, const float* __r
 // wave-uniform float4 of weights (broadcast): 21 LDS reads feed 256 FMAs (the previous thread-per-time-step layout
 // issued 17 reads per 16 FMAs and was LDS bound).  BatchNorm partial sums: one [2][16] row per workgroup.
 #define SEP_TT 256
+// NO = output maps per wave (round 3): grid.z = 4 / NO workgroups share a (time chunk, sample) and split the 16 outputs -- at T1 = 500
+// the (2, B) grid was 128 workgroups of 4 096 FMAs per lane on half of the CUs (14.4 us); the weights a workgroup does not use are
+// not staged.  Same sums in the same order per output, so results do not depend on NO.
+template <int NO>
 __global__ __launch_bounds__(256) void k_eeg_sep(const float* __restrict__ p1, const float* __restrict__ ws, float* __restrict__ s,
                                                   float* __restrict__ partials, EegGeom g, int want_stats) {
-  constexpr int TP = SEP_TT + 16;
+  constexpr int TP = SEP_TT + 16, OG = 4 * NO;                      // OG outputs per workgroup
   __shared__ __attribute__((aligned(16))) float sp[16 * TP];        // index j <-> t = t0 + j - padl2 (zero outside [0, T1))
-  __shared__ __attribute__((aligned(16))) float sw[16 * 16 * 16];   // [fd][k][o]
-  const int b = blockIdx.y, t0 = blockIdx.x * SEP_TT;
+  __shared__ __attribute__((aligned(16))) float sw[16 * 16 * OG];   // [fd][k][o - o0]
+  const int b = blockIdx.y, t0 = blockIdx.x * SEP_TT, o0 = blockIdx.z * OG;
   {
     const int T1 = g.T1, pl = g.padl2;
     const float* pb = p1 + (size_t)b * g.FD * T1;
-    lds_fill<16>(sw, 4096, [&](int j) { return ws[((j & 15) * 16 + (j >> 8)) * 16 + ((j >> 4) & 15)]; });   // [fd][k][o] <- [o][fd][k]
+    lds_fill<OG>(sw, 256 * OG, [&](int j) { return ws[((o0 + j % OG) * 16 + j / (16 * OG)) * 16 + (j / OG) % 16]; });   // [fd][k][o] <- [o][fd][k]
     lds_fill<17>(sp, 16 * TP, [&](int i) { const int fd = i / TP, tt = t0 + i % TP - pl; return (tt >= 0 && tt < T1) ? pb[(size_t)fd * T1 + tt] : 0.f; });
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tl = 4 * lane;
-  float acc[4][4];
+  float acc[4][NO];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int o = 0; o < 4; ++o) acc[j][o] = 0.f;
+    for (int o = 0; o < NO; ++o) acc[j][o] = 0.f;
   for (int fd = 0; fd < 16; ++fd) {
     const float* row = sp + fd * TP + tl;
     float4 cur = *reinterpret_cast<const float4*>(row);
@@ -341,36 +345,37 @@ __global__ __launch_bounds__(256) void k_eeg_sep(const float* __restrict__ p1, c
       const float win[8] = {cur.x, cur.y, cur.z, cur.w, nxt.x, nxt.y, nxt.z, nxt.w};
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const float4 wq = *reinterpret_cast<const float4*>(sw + (fd * 16 + 4 * kq + kk) * 16 + 4 * wave);
-        const float wv[4] = {wq.x, wq.y, wq.z, wq.w};
+        float wv[NO];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) wv[o] = sw[(fd * 16 + 4 * kq + kk) * OG + NO * wave + o];      // wave-uniform (broadcast) reads
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int o = 0; o < 4; ++o) acc[j][o] = fmaf(wv[o], win[kk + j], acc[j][o]);
+          for (int o = 0; o < NO; ++o) acc[j][o] = fmaf(wv[o], win[kk + j], acc[j][o]);
       }
       cur = nxt;
     }
   }
-  float su[4], sq[4];
+  float su[NO], sq[NO];
 #pragma unroll
-  for (int o = 0; o < 4; ++o) {
+  for (int o = 0; o < NO; ++o) {
     su[o] = sq[o] = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int tt = t0 + tl + j;
       if (tt < g.T1) {
-        s[((size_t)b * g.F2 + 4 * wave + o) * g.T1 + tt] = acc[j][o];
+        s[((size_t)b * g.F2 + o0 + NO * wave + o) * g.T1 + tt] = acc[j][o];
         su[o] += acc[j][o]; sq[o] += acc[j][o] * acc[j][o];
       }
     }
   }
   if (!want_stats) return;
 #pragma unroll
-  for (int o = 0; o < 4; ++o) {
+  for (int o = 0; o < NO; ++o) {
     const float a = wave_sum(su[o]), q = wave_sum(sq[o]);
     if (lane == 0) {
-      partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 4 * wave + o] = a;
-      partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 16 + 4 * wave + o] = q;
+      partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + o0 + NO * wave + o] = a;
+      partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 16 + o0 + NO * wave + o] = q;
     }
   }
 }
@@ -468,7 +473,16 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
     BX_CHECK_LAUNCH("eeg pool1");
   }
   dim3 gsep(bx_ceil_div(g.T1, SEP_TT), g.B);
-  hipLaunchKernelGGL(k_eeg_sep, gsep, dim3(256), 0, s, p1, p->sep_w, smap, part, g, tr);
+  {
+    // outputs per wave: split the 16 outputs over 2 or 4 workgroups while that is what it takes to give every CU one (BX_EEG_SEP_NO overrides)
+    static const int no_env = getenv("BX_EEG_SEP_NO") ? atoi(getenv("BX_EEG_SEP_NO")) : 0;
+    const long long wgs = (long long)gsep.x * gsep.y;
+    // measured at B = 64, T1 = 500 (training step, same box): NO = 4 1.483 ms, 2 1.479, 1 1.486 (one 4-byte weight read per 4 FMAs)
+    const int no = no_env == 1 || no_env == 2 || no_env == 4 ? no_env : wgs >= 512 ? 4 : 2;
+    if (no == 4) hipLaunchKernelGGL(k_eeg_sep<4>, gsep, dim3(256), 0, s, p1, p->sep_w, smap, part, g, tr);
+    else if (no == 2) hipLaunchKernelGGL(k_eeg_sep<2>, dim3(gsep.x, gsep.y, 2), dim3(256), 0, s, p1, p->sep_w, smap, part, g, tr);
+    else hipLaunchKernelGGL(k_eeg_sep<1>, dim3(gsep.x, gsep.y, 4), dim3(256), 0, s, p1, p->sep_w, smap, part, g, tr);
+  }
   BX_CHECK_LAUNCH("eeg sepconv");
   if (tr)
     hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.F2)), dim3(1024), 0, s, part, (int)(gsep.x * gsep.y), (double)g.B * g.T1, g.F2, tr, p->bn3_w, p->bn3_b,
@@ -603,17 +617,21 @@ __global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ d
                                                       const float* __restrict__ mean, const float* __restrict__ inv, const float* __restrict__ coef) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int T1 = g.T1, TP = eeg_sepb_pitch(T1);
+  // round 3: with grid (B, 8) the two halves run in DIFFERENT workgroups -- blockIdx.y < 4: (a) for quarter q, >= 4: (b) -- each staging
+  // only what it reads (LDS: ds + weights, or ds + p1: two workgroups per CU), so that B = 64 launches 512 workgroups of half the work
+  // instead of 256 at one per CU (27 us).  grid (B, 4): both halves in one workgroup as before (role 2).  Same sums either way.
+  const int role = gridDim.y == 8 ? (int)(blockIdx.y >> 2) : 2;
   float* sds = sm;                 // [16][TP]  index t + 8
-  float* sp1 = sm + 16 * TP;       // [16][TP]  index t + 7
-  float* sw = sp1 + 16 * TP;       // [o][fd][k]
-  const int b = blockIdx.x, q = blockIdx.y;
+  float* sp1 = sm + 16 * TP;       // [16][TP]  index t + 7          (roles 1, 2)
+  float* sw = role == 0 ? sm + 16 * TP : sp1 + 16 * TP;       // [o][fd][k]   (roles 0, 2)
+  const int b = blockIdx.x, q = blockIdx.y & 3;
   {
     const float* dsb = ds + (size_t)b * 16 * T1;
     const float* p1b = p1 + (size_t)b * 16 * T1;
     if ((T1 & 3) == 0) {
       // zero the halos, then copy the rows as float4s (8 + 8 loads in flight per thread)
       float4* z = reinterpret_cast<float4*>(sm);
-      for (int i = threadIdx.x; i < 2 * 16 * TP / 4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = threadIdx.x; i < (role == 0 ? 1 : 2) * 16 * TP / 4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       __syncthreads();
       const int n4 = T1 / 4, tot = 16 * n4;
       for (int i0 = threadIdx.x; i0 < tot; i0 += 256 * 8) {
@@ -622,7 +640,7 @@ __global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ d
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int i = i0 + u * 256, ic = i < tot ? i : 0;      // (clamped, unconditional loads: a conditionally filled array went to scratch memory)
-          a[u] = reinterpret_cast<const float4*>(dsb)[ic]; p[u] = reinterpret_cast<const float4*>(p1b)[ic];
+          a[u] = reinterpret_cast<const float4*>(dsb)[ic]; p[u] = reinterpret_cast<const float4*>(role == 0 ? dsb : p1b)[ic];
           q8[u] = reinterpret_cast<const float4*>(preb)[ic];
         }
 #pragma unroll
@@ -636,8 +654,10 @@ __global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ d
               a[u].z = ca * (a[u].z - k1 - (q8[u].z - mu) * is * k2); a[u].w = ca * (a[u].w - k1 - (q8[u].w - mu) * is * k2);
             }
             *reinterpret_cast<float4*>(sds + f * TP + 8 + 4 * c) = a[u];
-            float* q = sp1 + f * TP + 7 + 4 * c;
-            q[0] = p[u].x; q[1] = p[u].y; q[2] = p[u].z; q[3] = p[u].w;
+            if (role != 0) {
+              float* q = sp1 + f * TP + 7 + 4 * c;
+              q[0] = p[u].x; q[1] = p[u].y; q[2] = p[u].z; q[3] = p[u].w;
+            }
           }
         }
       }
@@ -649,14 +669,14 @@ __global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ d
         if (!pre) return d;
         return coef[f] * (d - coef[EEG_MAXF + f] - (pre[((size_t)b * 16 + f) * T1 + ta] - mean[f]) * inv[f] * coef[2 * EEG_MAXF + f]);
       });
-      lds_fill<16>(sp1, 16 * TP, [&](int i) { const int f = i / TP, tb = i % TP - 7; return (tb >= 0 && tb < T1) ? p1b[(size_t)f * T1 + tb] : 0.f; });
+      if (role != 0) lds_fill<16>(sp1, 16 * TP, [&](int i) { const int f = i / TP, tb = i % TP - 7; return (tb >= 0 && tb < T1) ? p1b[(size_t)f * T1 + tb] : 0.f; });
     }
-    lds_fill<16>(sw, 4096, [&](int i) { return ws[i]; });
+    if (role != 1) lds_fill<16>(sw, 4096, [&](int i) { return ws[i]; });
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // (a)
-  {
+  if (role != 1) {
     const int fd = 4 * q + wave;
     for (int t8 = lane; t8 * 8 < T1; t8 += 64) {
       const int tb = t8 * 8;
@@ -687,7 +707,7 @@ __global__ __launch_bounds__(256) void k_eeg_sep_bwd(const float* __restrict__ d
     }
   }
   // (b)
-  {
+  if (role != 0) {
     const int o = threadIdx.x >> 4, fd = threadIdx.x & 15;
     const int n4 = (T1 + 3) / 4;
     const int c0 = n4 * q / 4, c1 = n4 * (q + 1) / 4;
@@ -1031,11 +1051,16 @@ extern "C" int bx_eeg_features_bwd(const bxEegDesc* d, const bxEegParams* p, con
   BX_CHECK_LAUNCH("eeg bn3 bwd finalize");
   // separable conv (the BatchNorm3 backward apply rides in its staging)
   {
-    const size_t lds = ((size_t)2 * 16 * eeg_sepb_pitch(g.T1) + 4096) * sizeof(float);
+    // the two halves of the kernel in separate workgroups while that is what gives every CU two (BX_EEG_SEPB_SPLIT=0|1 overrides);
+    // B = 64: 27.0 -> 24.0 us
+    static const int split_env = getenv("BX_EEG_SEPB_SPLIT") ? atoi(getenv("BX_EEG_SEPB_SPLIT")) : -1;
+    const bool split = split_env >= 0 ? split_env != 0 : g.B * 4 < 1024;
+    const size_t tile = (size_t)16 * eeg_sepb_pitch(g.T1);
+    const size_t lds = (split ? (tile + (tile > 4096 ? tile : 4096)) : (2 * tile + 4096)) * sizeof(float);
     BX_REQUIRE(lds <= 160 * 1024, "bx_eeg_features_bwd: T/P1 too long for the LDS tile (%zu bytes)", lds);
     if (hipFuncSetAttribute((const void*)k_eeg_sep_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       BX_FAIL(BX_EHIP, "bx_eeg_features_bwd: cannot reserve %zu bytes of LDS", lds);
-    hipLaunchKernelGGL(k_eeg_sep_bwd, dim3(g.B, 4), dim3(256), lds, s, du3, p1, p->sep_w, dp1, sepp, g, smap, st.mean3, st.inv3, (const float*)coef3);
+    hipLaunchKernelGGL(k_eeg_sep_bwd, dim3(g.B, split ? 8 : 4), dim3(256), lds, s, du3, p1, p->sep_w, dp1, sepp, g, smap, st.mean3, st.inv3, (const float*)coef3);
     BX_CHECK_LAUNCH("eeg sep bwd");
   }
   // pool1/dropout/ELU/BN2
