@@ -29,7 +29,8 @@ def _eval_frozen(model):
     for p, _ in flags:
         p.requires_grad_(False)
     try:
-        yield
+        with ops.pack_reuse():                            # the weights stand for the whole pass: packed once, on its first forward
+            yield
     finally:
         for p, f in flags:
             p.requires_grad_(f)
@@ -142,6 +143,10 @@ class GradCamSweep:
     so the sweep runs at GPU speed instead of at the host's launch rate.  The returned tensor is that graph's static output
     buffer: clone it if it must outlive the next call with the same shape.
 
+    The captured launches hold no weight-packing jobs: a call re-packs first when a parameter changed since the last pack -- as far
+    as torch's version counters and this library's own optimizer kernels can tell.  A parameter rewritten through a ``.data`` view
+    between two calls is NOT seen: call ``invalidate()`` after such an edit.
+
         sweep = GradCamSweep(model, eeg_batch, spec_batch, class_idx="all")
         for eeg, spec in loader:
             maps = sweep(eeg, spec)          # [B, 6, H, W]
@@ -153,6 +158,10 @@ class GradCamSweep:
         self.model, self.args = model, (class_idx, upsample, relu)
         self._graphs = {}
         self._capture(eeg, spec)
+
+    def invalidate(self):
+        """Force the next call to re-pack the weights (after parameter edits torch cannot see, e.g. through ``.data``)."""
+        ops.bump_param_epoch()
 
     @staticmethod
     def _slot_ready(t):
@@ -173,16 +182,17 @@ class GradCamSweep:
         was_training = model.training
         model.eval()
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):                       # allocate workspaces / pack tables on the capture stream
-                    _grad_cam_last_stage(model, s_eeg, s_spec, class_idx, upsample, relu, False)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = _grad_cam_last_stage(model, s_eeg, s_spec, class_idx, upsample, relu, False)
+            with ops.pack_reuse():                       # (bumps the parameter epoch: the first warm-up run packs the weights)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):                   # allocate workspaces / pack tables on the capture stream
+                        _grad_cam_last_stage(model, s_eeg, s_spec, class_idx, upsample, relu, False)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = _grad_cam_last_stage(model, s_eeg, s_spec, class_idx, upsample, relu, False)
         finally:
             model.train(was_training)
             used = (False, False)

@@ -121,7 +121,7 @@ class Spectrogram_Model(nn.Module):
         elif seed_pair:
             res = (plan.run(x if raw else None),) + tuple(ops.next_seed_pair(x.device))
         else:
-            res = plan.run(x if raw else None, reuse=not self.training)     # evaluation sweeps: no repack while the weights stand
+            res = plan.run(x if raw else None, reuse=not self.training and ops.PACK_REUSE[0])     # frozen-weight scopes: no repack while the weights stand
         for bi, blk in enumerate(blocks):
             blk._prepacked, blk._pack_base = plan, 3 * bi
         return res

@@ -284,6 +284,23 @@ def bump_param_epoch():
     PARAM_EPOCH[0] += 1
 
 
+# Evaluation-mode forwards skip the weight-packing jobs (PackPlan.run(reuse=True)) only inside a scope that owns the contract
+# "parameters are frozen here": attribution passes (explain._eval_frozen) and GradCamSweep.  Elsewhere every forward re-packs, because
+# a parameter rewritten through a `.data` view (old-style code, `dist.broadcast(p.data, 0)`) changes neither its version counter nor
+# PARAM_EPOCH.  Entering the scope bumps the epoch, so the first forward inside it always packs.
+PACK_REUSE = [False]
+
+
+class pack_reuse:
+    def __enter__(self):
+        self.prev = PACK_REUSE[0]
+        bump_param_epoch()
+        PACK_REUSE[0] = True
+
+    def __exit__(self, *exc):
+        PACK_REUSE[0] = self.prev
+
+
 # data_ptr of a static graph input -> address of the DEVICE word its kernels read the batch's address from (GradCamSweep: a replay
 # is pointed at the caller's batch with bx_store_u64x2 instead of copying the batch into the static buffer)
 INPUT_SLOTS = {}

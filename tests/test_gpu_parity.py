@@ -960,6 +960,11 @@ def test_gradcam_sweep_matches_eager(dt):
     got = sweep(e2, s2).clone()
     want2 = brainxai.grad_cam(net, e2, s2, class_idx="all")
     assert torch.equal(got, want2) and not torch.equal(got, want) and plan.fresh()
+    net.spectrogram_model.block5.conv3.weight.data.mul_(0.5)      # through .data: no version bump, the documented blind spot ...
+    sweep.invalidate()                                            # ... which invalidate() covers
+    got = sweep(e2, s2).clone()
+    want2 = brainxai.grad_cam(net, e2, s2, class_idx="all")
+    assert torch.equal(got, want2)
     opt = brainxai.FlatAdamW(net.parameters(), lr=1e-2)           # moves the parameters into a flat arena: new operand buffers
     try:
         y = torch.softmax(torch.randn(4, 6, device=DEV), 1)
