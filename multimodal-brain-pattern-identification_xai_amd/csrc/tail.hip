@@ -182,7 +182,7 @@ __device__ __forceinline__ void skip_sample(const T* __restrict__ x, const TailG
 // statistics and the saved mean / invstd the backward reads.
 struct TailFwdPro { const float* rows; int nrows; BxBnFinalize fin; };
 template <typename T, int RPT>
-__global__ __launch_bounds__(256, 4) void k_tail_apply(const T* __restrict__ pooled, const T* __restrict__ x, const float* __restrict__ wT,
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void k_tail_apply(const T* __restrict__ pooled, const T* __restrict__ x, const float* __restrict__ wT,
     int Cin, const float* __restrict__ b1x1, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint64_t* __restrict__ seed, float dropout_p, uint32_t salt, T* __restrict__ out, TailGeom g,
     const float* __restrict__ ev_gamma, const float* __restrict__ ev_beta, const float* __restrict__ ev_rmean,
