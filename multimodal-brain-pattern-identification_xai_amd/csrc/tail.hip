@@ -803,8 +803,15 @@ __global__ __launch_bounds__(256) void k_skip_scatter(const float* __restrict__ 
 template <typename T>
 __device__ __forceinline__ void w1x1_grad_body(const T* __restrict__ dout, const T* __restrict__ x, float* __restrict__ partial,
                                                int pix_per_chunk, const TailGeom& g, int bx, int by, int bz) {
-  __shared__ float sd[64][17], sxs[64][17];
-  const int c = threadIdx.x >> 4, ci = threadIdx.x & 15;
+  // Operand tiles TRANSPOSED in LDS ([channel][pixel], round 3): a thread reads four pixels of its dOut channel and of its input
+  // channel as two 16-byte reads per four FMAs.  The [pixel][channel] form took two 4-byte reads per FMA and the role was bound by
+  // LDS instruction issue (stage 1 alone: 28 us for 51 MB).  Pitch 68: 16-byte aligned rows, four banks apart.
+  __shared__ __attribute__((aligned(16))) float sdT[16][68], sxsT[16][68];
+  // With at most 8 input channels (stage 1) the two halves of a 16-lane row would compute padding: they split the trip's pixels instead
+  // (lane bit 3 = pixel half) and the halves are added at the end.
+  const bool ksplit = g.Cin_p <= 8;
+  const int c = threadIdx.x >> 4, ci = ksplit ? (threadIdx.x & 7) : (threadIdx.x & 15), kh = ksplit ? ((threadIdx.x >> 3) & 1) : 0;
+  const int q_lo = ksplit ? 32 * kh : 0, q_n = ksplit ? 32 : 64;
   const int c0 = by * 16, ci0 = bz * 16;
   float acc = 0.f;
   const long long p_begin = (long long)bx * pix_per_chunk;
@@ -832,15 +839,23 @@ __device__ __forceinline__ void w1x1_grad_body(const T* __restrict__ dout, const
   if (p_begin < p_end) fetch(p_begin);
   for (long long p0 = p_begin; p0 < p_end; p0 += 64) {
     __syncthreads();
-    float* dst = is_d ? &sd[px][half * 8] : &sxs[px][half * 8];
+    float (*dst)[68] = is_d ? sdT : sxsT;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dst[j] = v[j];
+    for (int j = 0; j < 8; ++j) dst[half * 8 + j][px] = v[j];
     __syncthreads();
     if (p0 + 64 < p_end) fetch(p0 + 64);
-#pragma unroll 8
-    for (int q = 0; q < 64; ++q) acc = fmaf(sd[q][c], sxs[q][ci], acc);
+    for (int q = q_lo; q < q_lo + q_n; q += 16) {           // 4 x (2 reads, 4 FMAs) per step, pixels in ascending order
+      float4 dv[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { dv[u] = *reinterpret_cast<const float4*>(&sdT[c][q + 4 * u]); xv[u] = *reinterpret_cast<const float4*>(&sxsT[ci][q + 4 * u]); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc = fmaf(dv[u].x, xv[u].x, acc); acc = fmaf(dv[u].y, xv[u].y, acc); acc = fmaf(dv[u].z, xv[u].z, acc); acc = fmaf(dv[u].w, xv[u].w, acc);
+      }
+    }
   }
-  if (ci0 + ci < g.Cin_p) partial[((size_t)bx * g.C + c0 + c) * g.Cin_p + ci0 + ci] = acc;
+  if (ksplit) acc += __shfl_xor(acc, 8, 64);                // the other pixel half of the same output (lanes l, l ^ 8)
+  if (ci0 + ci < g.Cin_p && kh == 0) partial[((size_t)bx * g.C + c0 + c) * g.Cin_p + ci0 + ci] = acc;
 }
 
 // Late-stage variant (C and Cin_p multiples of 64): 64 x 64 output tile per workgroup, a thread owns 4 x 4 outputs and one
@@ -1087,7 +1102,12 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
     // up to ~4096 workgroups in total; partial buffer = nchunk * C * Cin_p floats <= 2048*256 + 64*C*Cin_p (workspace formula)
     const int otiles = wg_y * wg_z;
     nchunk = (int)((g.npool + 63) / 64);
-    int cap = otiles == 1 ? 1024 : 4096 / otiles;            // one output tile (first stage): 1024 chunks, the partial sum walks them all
+    // one output tile (first stage): 1 024 chunks of eight 64-pixel trips; more, shorter chunks do not help (BX_TAIL_W1_CAP sweep:
+    // 1024 1.472, 2048 1.474, 4096 1.479 ms/step) -- the role is bound by its per-trip work, not by the chain of trips.  Role times at
+    // stage 1, measured by launching the front kernel with one role at a time: BN reduction 16.9 us, this role 28.4 -> 23.5 us with
+    // the transposed tiles, together 36.8 -> 33.8 us.
+    static const int cap1 = getenv("BX_TAIL_W1_CAP") ? atoi(getenv("BX_TAIL_W1_CAP")) : 1024;
+    int cap = otiles == 1 ? cap1 : 4096 / otiles;
     if (cap < 64) cap = 64;
     while ((size_t)cap * g.C * g.Cin_p > (size_t)2048 * 256 + (size_t)64 * g.C * g.Cin_p) cap /= 2;
     if (nchunk > cap) nchunk = cap;
@@ -1116,7 +1136,8 @@ extern "C" int bx_block_tail_bwd(const bxTailDesc* d, const void* dout, const vo
     TailFrontArgs<T> a;
     a.dout = (const T*)dout; a.pooled = (const T*)pooled; a.x = (const T*)x; a.mean = save_mean; a.invstd = save_invstd; a.w1x1 = w1x1;
     a.seed = seed; a.partials = partials; a.wpart = wpart; a.dxs = dxs; a.dx_even = even ? (T*)dx_skip : (T*)nullptr;
-    a.dropout_p = p; a.salt = d->salt; a.n_red = nred; a.n_w = n_w; a.wg_x = nchunk > 0 ? nchunk : 1; a.wg_y = wg_y; a.ppc = ppc; a.Cin = Cin;
+    a.dropout_p = p; a.salt = d->salt; a.n_red = nred; a.n_w = n_w;
+ a.wg_x = nchunk > 0 ? nchunk : 1; a.wg_y = wg_y; a.ppc = ppc; a.Cin = Cin;
     a.tree = tree; a.fin = fin;
     const dim3 grid(nred + n_w + n_dxs);
     if (mf == 16) hipLaunchKernelGGL((k_tail_bwd_front<T, 8, 16>), grid, dim3(256), front_lds, s, a, g);
