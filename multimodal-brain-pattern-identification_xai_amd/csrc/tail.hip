@@ -475,7 +475,7 @@ __device__ __forceinline__ void tail_bwd_finalize_channel(int c, int C, const do
   f.coef[C + c] = f.training ? (float)(s[0] / f.count) : 0.f;
   f.coef[2 * C + c] = f.training ? (float)(s[1] / f.count) : 0.f;
 }
-template <typename T>
+template <typename T, int NPT = 2>
 __device__ __forceinline__ void tail_bwd_reduce_body(const T* __restrict__ dout, const T* __restrict__ pooled,
     const float* __restrict__ mean, const float* __restrict__ invstd, const uint64_t* __restrict__ seed, float dropout_p,
     uint32_t salt, float* partials, const TailGeom& g, int bid, int nblocks, const BxStatTree& tree, const TailBwdFin& fin) {
@@ -487,17 +487,19 @@ __device__ __forceinline__ void tail_bwd_reduce_body(const T* __restrict__ dout,
 #pragma unroll
   for (int j = 0; j < 8; ++j) { mu[j] = mean[cg * 8 + j]; is[j] = invstd[cg * 8 + j]; acc[0][j] = acc[1][j] = acc[2][j] = 0.f; }
   const long long stride = (long long)nblocks * g.slots;
-  for (long long pp0 = (long long)bid * g.slots + slot; pp0 < g.npool; pp0 += 2 * stride) {   // two pixels per trip
-    float go[2][8], pv[2][8];
-    bool ok[2];
+  // NPT pixels per trip: 4 in the first stage's launch (MF = 0: with 2 the role moved 34 MB in 16.9 us; front kernel 33.8 -> 31.9 us),
+  // 2 elsewhere (4 costs the MFMA instantiations a workgroup per CU: stage 2 20.5 -> 23.2 us)
+  for (long long pp0 = (long long)bid * g.slots + slot; pp0 < g.npool; pp0 += NPT * stride) {
+    float go[NPT][8], pv[NPT][8];
+    bool ok[NPT];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NPT; ++h) {
       const long long pp = pp0 + h * stride;
       ok[h] = pp < g.npool;
       if (ok[h]) { ld8(dout, (size_t)pp * g.C + cg * 8, go[h]); ld8(pooled, (size_t)pp * g.C + cg * 8, pv[h]); }
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NPT; ++h) {
       if (!ok[h]) continue;
       const long long pp = pp0 + h * stride;
 #pragma unroll
@@ -1043,7 +1045,7 @@ struct TailFrontArgs {
 template <typename T, int CIV, int MF>      // MF = Cin_p of the MFMA input-gradient role, 0 = VALU role with CIV channels per thread
 __global__ __launch_bounds__(256) void k_tail_bwd_front(TailFrontArgs<T> a, TailGeom g) {
   int bid = blockIdx.x;
-  if (bid < a.n_red) { tail_bwd_reduce_body<T>(a.dout, a.pooled, a.mean, a.invstd, a.seed, a.dropout_p, a.salt, a.partials, g, bid, a.n_red, a.tree, a.fin); return; }
+  if (bid < a.n_red) { tail_bwd_reduce_body<T, MF == 0 ? 4 : 2>(a.dout, a.pooled, a.mean, a.invstd, a.seed, a.dropout_p, a.salt, a.partials, g, bid, a.n_red, a.tree, a.fin); return; }
   bid -= a.n_red;
   if (bid < a.n_w) {
     const int bx = bid % a.wg_x, r = bid / a.wg_x;
