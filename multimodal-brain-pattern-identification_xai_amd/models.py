@@ -337,8 +337,22 @@ class MultimodalModel(nn.Module):
                 # both branches' dropout seeds ride in the weight-packing launch, which therefore opens the step
                 xi, ss, se = sm._pack_all(spectrogram_data, seed_pair=True)
                 packed = (xi,)
-            ef = em.features(eeg_data, seed=se)
-            sf = sm.features(spectrogram_data, seed=ss, packed=packed)
+            if ops.OVERLAP_EEG and eeg_data.is_cuda and ops.CONV_PROFILE is None:
+                # Round 3: the EEG branch (twenty small-grid, latency-bound launches, ~180 us of the step) runs on a side stream beside
+                # the spectrogram branch -- ONE fork after the packing launch (its seeds feed both branches) and one join in front of
+                # the head; autograd replays the branch's backward on the stream its forward ran on, so the backward overlaps the same
+                # way.  Inside a captured step these are two parallel chains of the graph.
+                cur = torch.cuda.current_stream()
+                side = ops.side_stream("eeg", eeg_data.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    ef = em.features(eeg_data, seed=se)
+                sf = sm.features(spectrogram_data, seed=ss, packed=packed)
+                cur.wait_stream(side)
+                ef.record_stream(cur)
+            else:
+                ef = em.features(eeg_data, seed=se)
+                sf = sm.features(spectrogram_data, seed=ss, packed=packed)
             if ef.shape[1] != em.dense.in_features:
                 raise RuntimeError(f"EEGNet: {ef.shape[1]} features but dense expects {em.dense.in_features} (Samples mismatch)")
             return ops.MultimodalHeadFn.apply(sf.permute(0, 2, 3, 1), ef, sm.fc.weight, sm.fc.bias, em.dense.weight, em.dense.bias,

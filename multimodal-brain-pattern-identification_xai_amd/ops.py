@@ -25,6 +25,7 @@ CONV_PROFILE = None               # bench.py sets a list: every conv launch appe
 # so it is OFF by default; BX_OVERLAP=1 turns it on.
 import os as _os
 OVERLAP = _os.environ.get("BX_OVERLAP", "0") == "1"
+OVERLAP_EEG = _os.environ.get("BX_OVERLAP_EEG", "0") == "1"    # only the EEG branch on its side stream (one fork / join per direction)
 FUSED_HEAD = _os.environ.get("BX_FUSED_HEAD", "1") == "1"    # MultimodalModel: GAP+fc, dense and the fusion head in one launch
 _SIDE = {}
 
