@@ -433,6 +433,7 @@ struct BxConvPoolEpi {
 };
 // in-launch finalize only for trees of at most this many rows (BX_TREE_MAX_ROWS; 0 = always a separate finalize launch)
 int bx_tree_max_rows();
+int bx_tail_fold_mask();          // folded finalizes: bit 0 backward, bit 1 forward (bx_set_tail_fold / BX_TAIL_FOLD)
 int bx_conv3x3_mfma_supported(int Ci, int Co, int dtype);
 int bx_conv3x3_mfma_pool_launch(const void* x, const void* packed_mfma, const float* bias, void* y, int B, int H, int W, int Ci, int Co,
                                 BxConvPoolEpi* pe, hipStream_t s);

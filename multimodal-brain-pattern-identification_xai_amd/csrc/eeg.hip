@@ -286,9 +286,33 @@ __global__ __launch_bounds__(128) void k_eeg_dw(const T* __restrict__ c1, const 
 __device__ __forceinline__ float elu1(float u) { return u > 0.f ? u : expm1f(u); }
 
 // E3/E5: BN apply + ELU + average pool (1xP, floor) + dropout.  in [B,F,Tin] -> out [B,F,Tout]
-__global__ void k_eeg_bn_elu_pool(const float* __restrict__ in, const float* __restrict__ sc, const float* __restrict__ sh,
+// Folded finalize (round 3, fold.rows != NULL; F == 16, 256 threads): no k_bn_finalize launch in front of this kernel -- every
+// workgroup sums the producer's partial rows ([row][2][16]) itself (bx_rows_total) and derives (scale, shift); workgroup 0 writes the
+// running statistics and what the backward reads.
+struct EegBnFold { const float* rows; int nrows; BxBnFinalize fin; };
+__global__ __launch_bounds__(256) void k_eeg_bn_elu_pool(const float* __restrict__ in, const float* __restrict__ sc, const float* __restrict__ sh,
                                   float* __restrict__ out, int B, int F, int Tin, int Tout, int P, const uint64_t* __restrict__ seed,
-                                  float dropout_p, uint32_t salt) {
+                                  float dropout_p, uint32_t salt, EegBnFold fold) {
+  __shared__ float ssc[2][16];
+  if (fold.rows) {
+    __shared__ __attribute__((aligned(8))) double sp[BX_ROWS_TOTAL_LDS(2) / 8];
+    bx_rows_total<2>(fold.rows, fold.nrows, 16, sp);
+    if (threadIdx.x < 16) {
+      const int c = threadIdx.x;
+      const BxBnFinalize& f = fold.fin;
+      float mean, invstd; double unbiased;
+      bx_bn_batch_stats(sp[c], sp[16 + c], f.count, f.eps, mean, invstd, unbiased);
+      const float s_ = f.gamma[c] * invstd, h_ = f.beta[c] - mean * s_;
+      ssc[0][c] = s_; ssc[1][c] = h_;
+      if (blockIdx.x == 0) {
+        f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * mean;
+        f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * (float)unbiased;
+        if (c == 0 && f.nbt) f.nbt[0] += 1;
+        f.scale[c] = s_; f.shift[c] = h_; f.save_mean[c] = mean; f.save_invstd[c] = invstd;
+      }
+    }
+    __syncthreads();
+  }
   const long long n = (long long)B * F * Tout;
   const uint64_t sd = (dropout_p > 0.f && seed) ? seed[0] : 0;
   const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
@@ -297,7 +321,7 @@ __global__ void k_eeg_bn_elu_pool(const float* __restrict__ in, const float* __r
     const int to = (int)(i32 - bfu * (unsigned)Tout);
     const long long bf = (long long)bfu;
     const int f = (int)(bfu % (unsigned)F);
-    const float a = sc[f], c = sh[f];
+    const float a = fold.rows ? ssc[0][f] : sc[f], c = fold.rows ? ssc[1][f] : sh[f];
     const float* src = in + bf * Tin + (size_t)to * P;
     float s = 0.f;
     for (int j = 0; j < P; ++j) s += elu1(src[j] * a + c);
@@ -428,6 +452,7 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
                        p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, g.F2, st.sc3, st.sh3, st.mean3, st.inv3, d->eps);
     BX_CHECK_LAUNCH("eeg eval stats");
   }
+  EegBnFold fold2 = {}, fold3 = {};                       // BatchNorm2 / BatchNorm3 finalizes folded into the pooling kernels (few partial rows)
   if (eeg_collapsed_eval(d)) {
     const int rc = bx_eegc_forward_eval(x, p->conv1_w, p->dw_w, st.sc1, st.sh1, dmap, g.B, g.Ch, g.T, s, d->x_slot);
     BX_REQUIRE(rc == 0, "bx_eeg_features_fwd: collapsed evaluation-mode front end failed (code %d)", rc);
@@ -437,9 +462,14 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
     const int rc = bx_eegc_forward(x, p->conv1_w, p->dw_w, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, p->bn1_nbt, d->momentum, d->eps, st.mean1, st.inv1,
                                    st.sc1, st.sh1, (double*)c1, (float*)((char*)workspace + w.off_w1p), dmap, part, &rows2, g.B, g.Ch, g.T, s);
     BX_REQUIRE(rc == 0, "bx_eeg_features_fwd: collapsed front end failed (code %d)", rc);
+    if (tr && (bx_tail_fold_mask() & 2) && g.FD == 16 && (long long)rows2 * 16 <= 8192) {
+      fold2 = EegBnFold{part, rows2, BxBnFinalize{p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, p->bn2_nbt, d->momentum, d->eps, st.sc2, st.sh2, st.mean2,
+                                                  st.inv2, (double)g.B * g.T}};
+    } else {
     hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.FD)), dim3(1024), 0, s, part, rows2, (double)g.B * g.T, g.FD, tr, p->bn2_w, p->bn2_b,
                        p->bn2_rm, p->bn2_rv, p->bn2_nbt, d->momentum, d->eps, st.sc2, st.sh2, st.mean2, st.inv2);
     BX_CHECK_LAUNCH("eeg bn2 (collapsed front end)");
+    }
   } else {
   // bf16 storage with the reference's 64-tap kernel: the temporal convolution runs on the matrix cores (eeg_mfma.hip)
   const bool no_mfma = getenv("BX_EEG_NO_MFMA") != nullptr;          // read per call: tests flip it to compare both paths
@@ -468,8 +498,9 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
   }
   {
     const long long n = (long long)g.B * g.FD * g.T1;
-    hipLaunchKernelGGL(k_eeg_bn_elu_pool, dim3(bx_ceil_div(n, 256)), dim3(256), 0, s, dmap, st.sc2, st.sh2, p1, g.B, g.FD, g.T, g.T1, g.P1,
-                       seed, pdrop, d->salt);
+    const long long nb = bx_ceil_div(n, 256);
+    hipLaunchKernelGGL(k_eeg_bn_elu_pool, dim3((unsigned)(fold2.rows && nb > 512 ? 512 : nb)), dim3(256), 0, s, dmap, st.sc2, st.sh2, p1, g.B, g.FD, g.T,
+                       g.T1, g.P1, seed, pdrop, d->salt, fold2);      // (folded: every workgroup re-reads the rows -- at most 512 of them)
     BX_CHECK_LAUNCH("eeg pool1");
   }
   dim3 gsep(bx_ceil_div(g.T1, SEP_TT), g.B);
@@ -484,14 +515,18 @@ extern "C" int bx_eeg_features_fwd(const bxEegDesc* d, const bxEegParams* p, con
     else hipLaunchKernelGGL(k_eeg_sep<1>, dim3(gsep.x, gsep.y, 4), dim3(256), 0, s, p1, p->sep_w, smap, part, g, tr);
   }
   BX_CHECK_LAUNCH("eeg sepconv");
-  if (tr)
+  if (tr && (bx_tail_fold_mask() & 2) && g.F2 == 16 && (long long)gsep.x * gsep.y * 16 <= 8192)
+    fold3 = EegBnFold{part, (int)(gsep.x * gsep.y), BxBnFinalize{p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, p->bn3_nbt, d->momentum, d->eps, st.sc3, st.sh3,
+                                                                  st.mean3, st.inv3, (double)g.B * g.T1}};
+  else if (tr)
     hipLaunchKernelGGL(k_bn_finalize, dim3(bx_finalize_grid(g.F2)), dim3(1024), 0, s, part, (int)(gsep.x * gsep.y), (double)g.B * g.T1, g.F2, tr, p->bn3_w, p->bn3_b,
                      p->bn3_rm, p->bn3_rv, p->bn3_nbt, d->momentum, d->eps, st.sc3, st.sh3, st.mean3, st.inv3);
   BX_CHECK_LAUNCH("eeg bn3");
   {
     const long long n = (long long)g.B * g.F2 * g.T2;
-    hipLaunchKernelGGL(k_eeg_bn_elu_pool, dim3(bx_ceil_div(n, 256)), dim3(256), 0, s, smap, st.sc3, st.sh3, feat, g.B, g.F2, g.T1, g.T2, g.P2,
-                       seed, pdrop2, d->salt + 1);
+    const long long nb = bx_ceil_div(n, 256);
+    hipLaunchKernelGGL(k_eeg_bn_elu_pool, dim3((unsigned)(fold3.rows && nb > 512 ? 512 : nb)), dim3(256), 0, s, smap, st.sc3, st.sh3, feat, g.B, g.F2, g.T1,
+                       g.T2, g.P2, seed, pdrop2, d->salt + 1, fold3);
     BX_CHECK_LAUNCH("eeg pool2");
   }
   return BX_OK;

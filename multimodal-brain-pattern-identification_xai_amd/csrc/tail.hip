@@ -301,6 +301,7 @@ static int tail_fold() {
   if (g_tail_fold < 0) { const char* e = getenv("BX_TAIL_FOLD"); g_tail_fold = e ? atoi(e) & 3 : 3; }
   return g_tail_fold;
 }
+int bx_tail_fold_mask() { return tail_fold(); }            // (the EEG branch's forward finalizes follow bit 1 too)
 extern "C" int bx_set_tail_fold(int mask) {
   BX_REQUIRE(mask >= 0 && mask <= 3, "bx_set_tail_fold: mask is a combination of 1 (backward) and 2 (forward)");
   g_tail_fold = mask;
@@ -308,7 +309,7 @@ extern "C" int bx_set_tail_fold(int mask) {
 }
 static int tail_fold_rc(bool fwd) {
   static const int rc_b = getenv("BX_TAIL_FOLD_RC") ? atoi(getenv("BX_TAIL_FOLD_RC")) : 8192;
-  static const int rc_f = getenv("BX_TAIL_FOLD_RC_FWD") ? atoi(getenv("BX_TAIL_FOLD_RC_FWD")) : 16384;
+  static const int rc_f = getenv("BX_TAIL_FOLD_RC_FWD") ? atoi(getenv("BX_TAIL_FOLD_RC_FWD")) : 32768;   // (16384 and 32768 measure the same; 32768 also folds stage 3: one launch fewer)
   return fwd ? rc_f : rc_b;
 }
 static int tail_fold_grid() {
@@ -444,7 +445,10 @@ extern "C" int bx_block_conv3_tail_fwd(const bxTailDesc* d, const void* y2, cons
   g_bx_prof_ev[0] = g_bx_prof_ev[1] = nullptr;
   if (rc != BX_OK) return rc;
   // few partial rows (the late stages: one per 8 x 32 tile or per image): the apply kernel's workgroups sum them themselves
-  const bool fold = d->training && !pe.tree.cnt && (tail_fold() & 2) && tail_fold_ok(g) && (long long)pe.tree.nrows * g.C <= tail_fold_rc(true);
+  // (and at most 1 024 rows: stage 1's 2 048 rows x 16 channels fit the rows x C bound, but its apply kernel -- HBM-bound, 4 096 one-trip
+  // workgroups -- loses more under the 512-workgroup cap of a folded consumer (23 -> 33 us) than the 8 us finalize launch costs)
+  const bool fold = d->training && !pe.tree.cnt && (tail_fold() & 2) && tail_fold_ok(g) && (long long)pe.tree.nrows * g.C <= tail_fold_rc(true)
+                    && pe.tree.nrows <= 1024;
   TailFwdPro pro = {};
   if (fold) pro = TailFwdPro{partials, pe.tree.nrows, pe.fin};
   if (d->training && !pe.tree.cnt && !fold) {           // many partial rows: the separate finalize launch (its workgroups split the channels)
