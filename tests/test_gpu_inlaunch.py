@@ -98,6 +98,31 @@ def test_route_nibbles_equal_the_stored_conv3_output(case, pool):
             assert torch.equal(ta, tb), k
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_eeg_folded_finalizes_equal_finalize_launches(dtype):
+    """round 3: BatchNorm2 (collapsed front end, bf16 storage) and BatchNorm3 of EEGNet are finalized inside the pooling kernels
+    (k_eeg_bn_elu_pool sums the partial rows itself); against the k_bn_finalize launches: outputs, input-free parameter gradients
+    and running statistics agree to the rounding of the double sums."""
+    res = []
+    for mask in (3, 0):
+        L.check(L.load().bx_set_tail_fold(mask), "bx_set_tail_fold")
+        try:
+            torch.manual_seed(4)
+            net = brainxai.set_compute_dtype(brainxai.EEGNet(6, Chans=19, Samples=2000, dropoutRate=0.25), dtype).to(DEV).train()
+            ops.manual_seed(5, DEV)
+            x = torch.randn(8, 1, 19, 2000, generator=torch.Generator().manual_seed(6)).to(DEV)
+            out = net(x)
+            (out * torch.linspace(-1, 1, out.numel(), device=DEV).view_as(out)).sum().backward()
+            torch.cuda.synchronize()
+            res.append([out.detach().cpu()] + [p.grad.detach().cpu() for p in net.parameters()]
+                       + [b.detach().clone().cpu().float() for b in net.buffers()])
+        finally:
+            L.load().bx_set_tail_fold(3)
+    for k, (ta, tb) in enumerate(zip(*res)):
+        scale = float(tb.abs().max()) + 1e-30
+        assert float((ta - tb).abs().max()) / scale <= 2e-6, k
+
+
 def _compare(a, b, dtype):
     for it, (ra, rb) in enumerate(zip(a, b)):
         for k, (ta, tb) in enumerate(zip(ra, rb)):
