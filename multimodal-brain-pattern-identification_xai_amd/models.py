@@ -345,6 +345,11 @@ class MultimodalModel(nn.Module):
                 cur = torch.cuda.current_stream()
                 side = ops.side_stream("eeg", eeg_data.device)
                 side.wait_stream(cur)
+                # tensors allocated on this stream and read on the side stream (forward AND backward): the allocator must not hand their
+                # memory to a later main-stream allocation while the side stream may still read it
+                if se is not None:
+                    se.record_stream(side)
+                eeg_data.record_stream(side)
                 with torch.cuda.stream(side):
                     ef = em.features(eeg_data, seed=se)
                 sf = sm.features(spectrogram_data, seed=ss, packed=packed)

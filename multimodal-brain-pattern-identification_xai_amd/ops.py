@@ -897,6 +897,8 @@ class EegFeaturesFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeat):
         lib = L.load()
+        if OVERLAP_EEG:
+            dfeat.record_stream(torch.cuda.current_stream())   # produced on the main stream, read here on the branch's stream
         x, saved, c1w, bn1w, bn1b, dww, bn2w, bn2b, sepw, bn3w, bn3b = ctx.saved_tensors
         need_w = any(ctx.needs_input_grad[1:10])
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
