@@ -97,6 +97,8 @@ def _grad_cam_last_stage(model, eeg, spec, class_idx, upsample, relu, return_par
         H, W = spec.shape[-2:]
         if upsample and not return_parts and W % 4 == 0 and hasattr(model, "_fusable") and model._fusable():
             # sweep form: the EEG branch's dense + LogSoftmax and the up-sampling ride in the head launch (two launches fewer per batch)
+            # (the EEG branch beside the spectrogram branch, as the captured training step runs them, does not pay here: 440 vs 433 us
+            # per batch -- the evaluation-mode branch is 55 us of five launches and the fork / join costs about as much as it hides)
             ef = em.features(eeg).contiguous()
             A = sm.features(spec).permute(0, 2, 3, 1).contiguous()
             B, h, w, C = A.shape

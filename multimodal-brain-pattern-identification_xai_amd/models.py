@@ -314,8 +314,16 @@ class MultimodalModel(nn.Module):
             if self.training and em.dropout.p > 0 and any(getattr(sm, f"block{i}").dropout.p > 0 for i in range(1, 6)):
                 xi, ss, se = sm._pack_all(spectrogram_data, seed_pair=True)
                 packed = (xi,)
-            ef = em.features(eeg_data, seed=se)
-            sf = sm.features(spectrogram_data, seed=ss, cut=cut, packed=packed)
+            if eeg_data.is_cuda and ops.overlap_eeg_now():      # (see the fused path below)
+                cur, side = ops.fork_eeg(eeg_data.device, se, eeg_data)
+                with torch.cuda.stream(side):
+                    ef = em.features(eeg_data, seed=se)
+                sf = sm.features(spectrogram_data, seed=ss, cut=cut, packed=packed)
+                cur.wait_stream(side)
+                ef.record_stream(cur)
+            else:
+                ef = em.features(eeg_data, seed=se)
+                sf = sm.features(spectrogram_data, seed=ss, cut=cut, packed=packed)
             return ops.MultimodalHeadFn.apply(sf.permute(0, 2, 3, 1), ef, sm.fc.weight, sm.fc.bias, em.dense.weight, em.dense.bias,
                                               self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
         if ops.OVERLAP and eeg_data.is_cuda and ops.CONV_PROFILE is None:
@@ -337,19 +345,12 @@ class MultimodalModel(nn.Module):
                 # both branches' dropout seeds ride in the weight-packing launch, which therefore opens the step
                 xi, ss, se = sm._pack_all(spectrogram_data, seed_pair=True)
                 packed = (xi,)
-            if ops.OVERLAP_EEG and eeg_data.is_cuda and ops.CONV_PROFILE is None:
+            if eeg_data.is_cuda and ops.overlap_eeg_now():
                 # Round 3: the EEG branch (twenty small-grid, latency-bound launches, ~180 us of the step) runs on a side stream beside
                 # the spectrogram branch -- ONE fork after the packing launch (its seeds feed both branches) and one join in front of
                 # the head; autograd replays the branch's backward on the stream its forward ran on, so the backward overlaps the same
                 # way.  Inside a captured step these are two parallel chains of the graph.
-                cur = torch.cuda.current_stream()
-                side = ops.side_stream("eeg", eeg_data.device)
-                side.wait_stream(cur)
-                # tensors allocated on this stream and read on the side stream (forward AND backward): the allocator must not hand their
-                # memory to a later main-stream allocation while the side stream may still read it
-                if se is not None:
-                    se.record_stream(side)
-                eeg_data.record_stream(side)
+                cur, side = ops.fork_eeg(eeg_data.device, se, eeg_data)
                 with torch.cuda.stream(side):
                     ef = em.features(eeg_data, seed=se)
                 sf = sm.features(spectrogram_data, seed=ss, packed=packed)

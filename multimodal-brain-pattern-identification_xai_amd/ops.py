@@ -25,7 +25,26 @@ CONV_PROFILE = None               # bench.py sets a list: every conv launch appe
 # so it is OFF by default; BX_OVERLAP=1 turns it on.
 import os as _os
 OVERLAP = _os.environ.get("BX_OVERLAP", "0") == "1"
-OVERLAP_EEG = _os.environ.get("BX_OVERLAP_EEG", "0") == "1"    # only the EEG branch on its side stream (one fork / join per direction)
+# The EEG branch on a side stream beside the spectrogram branch (one fork / join per direction; round 3).  BX_OVERLAP_EEG: 0 = never,
+# 1 (default) = inside captured hipGraphs (GraphedTrainStep, GradCamSweep: two parallel chains of the graph), 2 = also when launching
+# eagerly (host-side stream switches make that slower than the serial order).  Same kernels, same arithmetic: the overlapped step
+# walks the serial trajectory bit for bit (tests/test_gpu_bench_config.py, tools/trajectory_check.py).
+OVERLAP_EEG = int(_os.environ.get("BX_OVERLAP_EEG", "1"))
+
+
+def overlap_eeg_now() -> bool:
+    return CONV_PROFILE is None and (OVERLAP_EEG >= 2 or (OVERLAP_EEG == 1 and torch.cuda.is_current_stream_capturing()))
+
+
+def fork_eeg(device, *read_on_side):
+    """(main, side) streams with the side stream waiting for the main one; tensors the side stream will read are recorded on it."""
+    cur = torch.cuda.current_stream()
+    side = side_stream("eeg", device)
+    side.wait_stream(cur)
+    for t in read_on_side:
+        if t is not None:
+            t.record_stream(side)
+    return cur, side
 FUSED_HEAD = _os.environ.get("BX_FUSED_HEAD", "1") == "1"    # MultimodalModel: GAP+fc, dense and the fusion head in one launch
 _SIDE = {}
 

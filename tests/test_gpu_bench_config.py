@@ -200,6 +200,63 @@ def test_bench_config_graph_replay_equals_eager_bf16():
     assert torch.equal(finals[0][1], finals[1][1])
 
 
+def test_overlapped_graph_walks_the_serial_trajectory():
+    """round 3: inside a captured step the EEG branch runs on a side stream beside the spectrogram branch (ops.OVERLAP_EEG = 1, the
+    default).  Same kernels, same arithmetic, so the replayed step must walk the SERIAL eager trajectory bit for bit -- 30 steps at the
+    benchmark's shape, dropout on -- and 100 replays of the captured forward must reproduce the serial forward's branch outputs.
+    (This is the test that found hipcc's packed-fp32 code misbehaving beside another kernel: build.py compiles without it.)"""
+    assert ops.OVERLAP_EEG == 1, "the default is what bench.py measures"
+    eeg, spec, labels = (t.to(DEV) for t in _bench_inputs())
+    finals = []
+    for graphed in (False, True):
+        torch.manual_seed(11)
+        net = brainxai.build_multimodal(CHANS, T, CIN, dropout=0.5, compute_dtype=torch.bfloat16).to(DEV).train()
+        opt = brainxai.FlatAdamW(net.parameters(), lr=1e-3)
+        crit = brainxai.KLDivLoss()
+        ops.manual_seed(78)
+        try:
+            if graphed:
+                step = brainxai.GraphedTrainStep(net, opt, crit)
+                losses = [float(step([eeg, spec], labels)[0]) for _ in range(30)]     # (the graph's loss is one static buffer: read it per step)
+                assert step.enabled and len(step._graphs) == 1
+            else:
+                losses = [float(brainxai.train_step(net, opt, eeg, spec, labels, crit)[0]) for _ in range(30)]
+            torch.cuda.synchronize()
+            finals.append((losses, opt.flat_p.clone()))
+        finally:
+            ops.clear_grad_views()
+    assert finals[0][0] == finals[1][0], [(i, a, b) for i, (a, b) in enumerate(zip(*[f[0] for f in finals])) if a != b][:3]
+    assert torch.equal(finals[0][1], finals[1][1])
+    # the forward alone, replayed: both branches' outputs against the serial launch order
+    sm, em = net.spectrogram_model, net.eeg_model
+
+    def fwd():
+        with torch.no_grad():
+            xi, ss, se = sm._pack_all(spec, seed_pair=True)
+            if ops.overlap_eeg_now():
+                cur, side = ops.fork_eeg(DEV, se, eeg)
+                with torch.cuda.stream(side):
+                    ef = em.features(eeg, seed=se)
+                sf = sm.features(spec, seed=ss, packed=(xi,))
+                cur.wait_stream(side)
+                ef.record_stream(cur)
+                return ef, sf
+            return em.features(eeg, seed=se), sm.features(spec, seed=ss, packed=(xi,))
+    ops.manual_seed(1234)
+    ref = [t.clone() for t in fwd()]
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fwd()
+    bad = 0
+    for _ in range(100):
+        ops.manual_seed(1234)
+        graph.replay()
+        torch.cuda.synchronize()
+        bad += int(not (torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])))
+    assert bad == 0, f"{bad} of 100 replays of the overlapped forward differ from the serial forward"
+
+
 def test_config0_spectrogram_model_alone():
     """configs[0]: Spectrogram_Model (4-plane block1) on 32 synthetic [4,128,256] spectrograms, 6 classes -- the reference's
     CPU-runnable plumbing case (debug_input_size 32, debug_batch_size 16: config.yml:565,569) on the HIP path: full-batch

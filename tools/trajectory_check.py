@@ -17,7 +17,7 @@ crit = brainxai.KLDivLoss()
 res = {}
 modes = ("eager", "graph") + (("serial",) if ops.OVERLAP_EEG else ())     # serial: the same kernels without the EEG side stream
 for mode in modes:
-    ops.OVERLAP_EEG = ops.OVERLAP_EEG_ENV and mode != "serial"
+    ops.OVERLAP_EEG = ops.OVERLAP_EEG_ENV if mode != "serial" else 0
     torch.manual_seed(9)
     m = brainxai.build_multimodal(19, 2000, 4, dropout=float(os.environ.get("TC_DROPOUT", "0.5")), compute_dtype=torch.bfloat16).to(dev).train()
     opt = brainxai.FlatAdamW(m.parameters(), lr=1e-3)
