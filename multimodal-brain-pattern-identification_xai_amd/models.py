@@ -314,10 +314,16 @@ class MultimodalModel(nn.Module):
             if self.training and em.dropout.p > 0 and any(getattr(sm, f"block{i}").dropout.p > 0 for i in range(1, 6)):
                 xi, ss, se = sm._pack_all(spectrogram_data, seed_pair=True)
                 packed = (xi,)
-            # (no side stream for the EEG branch here, unlike the fused path below: with it inside the one-graph data-parallel capture
-            # -- RCCL's stream is a third branch of that graph -- destroy_process_group() aborted in c10d at teardown)
-            ef = em.features(eeg_data, seed=se)
-            sf = sm.features(spectrogram_data, seed=ss, cut=cut, packed=packed)
+            if eeg_data.is_cuda and ops.overlap_eeg_now() and ops.OVERLAP_EEG_DDP:      # (see the fused path below)
+                cur, side = ops.fork_eeg(eeg_data.device, se, eeg_data)
+                with torch.cuda.stream(side):
+                    ef = em.features(eeg_data, seed=se)
+                sf = sm.features(spectrogram_data, seed=ss, cut=cut, packed=packed)
+                cur.wait_stream(side)
+                ef.record_stream(cur)
+            else:
+                ef = em.features(eeg_data, seed=se)
+                sf = sm.features(spectrogram_data, seed=ss, cut=cut, packed=packed)
             return ops.MultimodalHeadFn.apply(sf.permute(0, 2, 3, 1), ef, sm.fc.weight, sm.fc.bias, em.dense.weight, em.dense.bias,
                                               self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
         if ops.OVERLAP and eeg_data.is_cuda and ops.CONV_PROFILE is None:

@@ -30,6 +30,8 @@ OVERLAP = _os.environ.get("BX_OVERLAP", "0") == "1"
 # eagerly (host-side stream switches make that slower than the serial order).  Same kernels, same arithmetic: the overlapped step
 # walks the serial trajectory bit for bit (tests/test_gpu_bench_config.py, tools/trajectory_check.py).
 OVERLAP_EEG = int(_os.environ.get("BX_OVERLAP_EEG", "1"))
+# ... and inside the one-graph data-parallel capture (RCCL's stream is a third branch there).  BX_OVERLAP_EEG_DDP=0 keeps that capture serial.
+OVERLAP_EEG_DDP = _os.environ.get("BX_OVERLAP_EEG_DDP", "1") == "1"
 
 
 def overlap_eeg_now() -> bool:
@@ -129,6 +131,16 @@ _WS_RETIRED = []
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only scratch buffer per (device, stream): all uses of one buffer are ordered on its stream."""
+    if OVERLAP_EEG == 1 and not torch.cuda.is_current_stream_capturing():
+        # the EEG branch's side stream gets its scratch buffer NOW, outside any capture: allocated for the first time inside a captured
+        # step it would live in that graph's private pool for the rest of the process
+        sk = (device.index if device.index is not None else torch.cuda.current_device(), side_stream("eeg", device).cuda_stream)
+        sb = _WS.get(sk)
+        if sb is None or sb.numel() < nbytes:
+            if sb is not None:
+                _WS_RETIRED.append(sb)
+            with torch.cuda.stream(side_stream("eeg", device)):
+                _WS[sk] = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
