@@ -314,7 +314,7 @@ class MultimodalModel(nn.Module):
             if self.training and em.dropout.p > 0 and any(getattr(sm, f"block{i}").dropout.p > 0 for i in range(1, 6)):
                 xi, ss, se = sm._pack_all(spectrogram_data, seed_pair=True)
                 packed = (xi,)
-            if eeg_data.is_cuda and ops.overlap_eeg_now() and ops.OVERLAP_EEG_DDP:      # (see the fused path below)
+            if eeg_data.is_cuda and ops.OVERLAP_EEG_DDP and ops.overlap_eeg_now():      # (opt-in; see the fused path below and ops.overlap_eeg_now)
                 cur, side = ops.fork_eeg(eeg_data.device, se, eeg_data)
                 with torch.cuda.stream(side):
                     ef = em.features(eeg_data, seed=se)

@@ -36,7 +36,13 @@ OVERLAP_EEG_DDP = _os.environ.get("BX_OVERLAP_EEG_DDP", "0") == "1"
 
 
 def overlap_eeg_now() -> bool:
-    return CONV_PROFILE is None and (OVERLAP_EEG >= 2 or (OVERLAP_EEG == 1 and torch.cuda.is_current_stream_capturing()))
+    if CONV_PROFILE is not None or not (OVERLAP_EEG >= 2 or (OVERLAP_EEG == 1 and torch.cuda.is_current_stream_capturing())):
+        return False
+    # Not in a process that holds a process group (unless BX_OVERLAP_EEG_DDP=1): with multi-branch graphs captured while RCCL's communicator
+    # exists, destroy_process_group() aborted in c10d at teardown in 3 of 5 full-suite runs -- with any of the data-parallel step forms,
+    # not only the one-graph capture -- and never in the ~15 runs before the side stream existed.
+    import torch.distributed as dist
+    return OVERLAP_EEG_DDP or not (dist.is_available() and dist.is_initialized())
 
 
 def fork_eeg(device, *read_on_side):
@@ -132,7 +138,7 @@ _WS_RETIRED = []
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only scratch buffer per (device, stream): all uses of one buffer are ordered on its stream."""
-    if OVERLAP_EEG == 1 and not torch.cuda.is_current_stream_capturing():
+    if OVERLAP_EEG == 1 and not torch.cuda.is_current_stream_capturing() and torch.cuda.current_stream().cuda_stream != side_stream("eeg", device).cuda_stream:
         # the EEG branch's side stream gets its scratch buffer NOW, outside any capture: allocated for the first time inside a captured
         # step it would live in that graph's private pool for the rest of the process
         sk = (device.index if device.index is not None else torch.cuda.current_device(), side_stream("eeg", device).cuda_stream)
