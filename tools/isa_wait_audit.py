@@ -11,7 +11,7 @@ CSRC = os.path.join(ROOT, "multimodal-brain-pattern-identification_xai_amd", "cs
 files = sys.argv[1:] or sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 for path in files:
     extra = ["-ffp-contract=off"] if os.path.basename(path) in ("montage.hip", "specprep.hip") else ["-ffp-contract=fast"]
-    asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *extra, "-S", "--cuda-device-only", path, "-o", "-"],
+    asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", *extra, "-S", "--cuda-device-only", path, "-o", "-"],
                          capture_output=True, text=True).stdout
     parts = re.split(r"\n(_Z\w+|k_\w+):[ \t]*;[^\n]*\n", asm)
     names, bodies = parts[1::2], parts[2::2]

@@ -5,7 +5,8 @@ is placed in scratch memory."""
 import re, subprocess, sys
 src = sys.argv[1]
 pat = sys.argv[2] if len(sys.argv) > 2 else ""
-out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", src, "-o", "/tmp/_kr.o",
+out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-c", src,   # (the shipped build's code generation: build.py FLAGS)
+                      "-o", "/tmp/_kr.o",
                       "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
 cur = {}
 for line in out.splitlines():

@@ -17,7 +17,7 @@ out = "/tmp/libbrainxai_stamps.so"
 import importlib.util as _ilu
 _spec = _ilu.spec_from_file_location("_bx_build", os.path.join(PKG, "build.py")); _b = _ilu.module_from_spec(_spec); _spec.loader.exec_module(_b)
 srcs = _b.SOURCES
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-DBX_WGRAD_STAMPS", "-shared",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DBX_WGRAD_STAMPS", "-shared",
                        *[os.path.join(PKG, "csrc", f) for f in srcs], "-o", out])
 import torch  # noqa: E402
 import brainxai  # noqa: E402
